@@ -1,0 +1,327 @@
+"""Model weights for the MI355X CSS front end: state-dict walking, portable seeded weights, blob packing.
+
+The reference keeps its mask estimator in a torch ``state_dict`` whose key layout is fixed by
+``css/training/conformer_wrapper.py:51-56`` + ``css/css_with_conformer/nnet/conformer.py`` (listed in
+SURVEY.md App. A.4).  This module
+
+* enumerates that layout (``state_dict_spec``),
+* builds *portable* seeded weights with a counter-based PRNG that depends on numpy integer
+  arithmetic only (``portable_state_dict``) -- the GPU box regenerates bit-identical weights from a
+  seed, so no 237 MB checkpoint has to be committed or shipped,
+* packs a state dict into the flat float32 blob the C ABI consumes (``pack_blob``; layout documented
+  in ``include/css_mi355.h``), applying the load-time transformations the HIP kernels expect
+  (K padded to a multiple of 16, fused QKV, BatchNorm folded to alpha/beta exactly like ATen's
+  eval-mode CPU kernel, depthwise-conv taps transposed to [tap][channel]).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import zlib
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+PREFIX = "executor.nnet."
+
+
+@dataclasses.dataclass
+class ModelDesc:
+    """Mirror of ``CssModelDesc`` in include/css_mi355.h (same field order, all int32)."""
+    num_mics: int = 7
+    num_bins: int = 257
+    in_features: int = 1799
+    attention_dim: int = 512
+    attention_heads: int = 8
+    linear_units: int = 1024
+    num_blocks: int = 18
+    kernel_size: int = 33
+    num_spks: int = 3
+    num_nois: int = 1
+    frame_len: int = 512
+    frame_hop: int = 256
+    maxlen: int = 1000
+
+    @property
+    def k_in_padded(self) -> int:
+        return (self.in_features + 15) // 16 * 16
+
+    @property
+    def n_masks(self) -> int:
+        return self.num_spks + self.num_nois
+
+    @classmethod
+    def mc_v1(cls) -> "ModelDesc":
+        """configs/train_css/local/conformer_v1.0_mc.yaml:36-42"""
+        return cls()
+
+    @classmethod
+    def sc_v1(cls) -> "ModelDesc":
+        """configs/train_css/local/conformer_v1.0_sc.yaml:37-46 (ipd_index '', in_features 257)"""
+        return cls(num_mics=1, in_features=257)
+
+    @classmethod
+    def from_state_dict(cls, state: Dict[str, np.ndarray]) -> "ModelDesc":
+        st = strip_module_prefix(state)
+        emb = st[PREFIX + "conformer.embed.0.weight"]
+        pe = st[PREFIX + "conformer.pos_emb.pe_k.weight"]
+        d = emb.shape[0]
+        blocks = 0
+        while PREFIX + f"conformer.encoders.{blocks}.layer_norm.weight" in st:
+            blocks += 1
+        nb = 257
+        nout = st[PREFIX + "linear.weight"].shape[0]
+        return cls(num_mics=7 if emb.shape[1] > nb else 1, num_bins=nb, in_features=emb.shape[1],
+                   attention_dim=d, attention_heads=d // pe.shape[1],
+                   linear_units=st[PREFIX + "conformer.encoders.0.feed_forward_in.net.0.weight"].shape[0],
+                   num_blocks=blocks,
+                   kernel_size=st[PREFIX + "conformer.encoders.0.conv.dw_conv_1d.weight"].shape[2],
+                   num_spks=nout // nb - 1, num_nois=1, maxlen=pe.shape[0] // 2)
+
+
+def strip_module_prefix(state: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Checkpoints saved from DP/DDP carry a leading ``module.`` (css/helpers.py:32-36)."""
+    if any(k.startswith("module.") for k in state):
+        return {k[len("module."):]: v for k, v in state.items() if k.startswith("module.")}
+    return dict(state)
+
+
+# ----------------------------------------------------------------------------------------------
+# state-dict layout
+# ----------------------------------------------------------------------------------------------
+def state_dict_spec(d: ModelDesc) -> List[Tuple[str, Tuple[int, ...], str, int]]:
+    """[(key, shape, kind, fan_in)] in the reference's registration order.
+    kind: 'uniform' (U(+-1/sqrt(fan_in)), torch's Linear/Conv default), 'normal' (Embedding),
+    'ones', 'zeros', 'int' (num_batches_tracked)."""
+    D, FF, H = d.attention_dim, d.linear_units, d.attention_heads
+    out: List[Tuple[str, Tuple[int, ...], str, int]] = []
+    a = lambda k, s, kind, fan=0: out.append((PREFIX + k, tuple(s), kind, fan))
+    a("input_bias", (1, 1, d.in_features), "zeros")
+    a("input_scale", (1, 1, d.in_features), "ones")
+    a("conformer.embed.0.weight", (D, d.in_features), "uniform", d.in_features)
+    a("conformer.embed.0.bias", (D,), "uniform", d.in_features)
+    a("conformer.embed.1.weight", (D,), "ones")
+    a("conformer.embed.1.bias", (D,), "zeros")
+    a("conformer.pos_emb.pe_k.weight", (2 * d.maxlen, D // H), "normal")
+    for l in range(d.num_blocks):
+        p = f"conformer.encoders.{l}."
+        def feed_forward(ff):
+            a(p + ff + ".layer_norm.weight", (D,), "ones")
+            a(p + ff + ".layer_norm.bias", (D,), "zeros")
+            a(p + ff + ".net.0.weight", (FF, D), "uniform", D)
+            a(p + ff + ".net.0.bias", (FF,), "uniform", D)
+            a(p + ff + ".net.3.weight", (D, FF), "uniform", FF)
+            a(p + ff + ".net.3.bias", (D,), "uniform", FF)
+
+        feed_forward("feed_forward_in")
+        a(p + "self_attn.layer_norm.weight", (D,), "ones")
+        a(p + "self_attn.layer_norm.bias", (D,), "zeros")
+        for nm in ("q", "k", "v", "out"):
+            a(p + f"self_attn.linear_{nm}.weight", (D, D), "uniform", D)
+            a(p + f"self_attn.linear_{nm}.bias", (D,), "uniform", D)
+        a(p + "conv.layer_norm.weight", (D,), "ones")
+        a(p + "conv.layer_norm.bias", (D,), "zeros")
+        a(p + "conv.pw_conv_1.weight", (2, 1, 1, 1), "uniform", 1)
+        a(p + "conv.pw_conv_1.bias", (2,), "uniform", 1)
+        a(p + "conv.dw_conv_1d.weight", (D, 1, d.kernel_size), "uniform", d.kernel_size)
+        a(p + "conv.dw_conv_1d.bias", (D,), "uniform", d.kernel_size)
+        a(p + "conv.BN.weight", (D,), "ones")
+        a(p + "conv.BN.bias", (D,), "zeros")
+        a(p + "conv.BN.running_mean", (D,), "zeros")
+        a(p + "conv.BN.running_var", (D,), "ones")
+        a(p + "conv.BN.num_batches_tracked", (), "int")
+        a(p + "conv.pw_conv_2.weight", (1, 1, 1, 1), "uniform", 1)
+        a(p + "conv.pw_conv_2.bias", (1,), "uniform", 1)
+        feed_forward("feed_forward_out")
+        a(p + "layer_norm.weight", (D,), "ones")
+        a(p + "layer_norm.bias", (D,), "zeros")
+    nout = d.num_bins * d.n_masks
+    a("linear.weight", (nout, D), "uniform", D)
+    a("linear.bias", (nout,), "uniform", D)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# portable counter-based PRNG (numpy uint64 arithmetic only -> identical on every box)
+# ----------------------------------------------------------------------------------------------
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser."""
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def portable_uniform(seed: int, stream: int, n: int) -> np.ndarray:
+    """n float64 values in [0, 1) with 24 random bits each (exactly representable in float32)."""
+    with np.errstate(over="ignore"):
+        base = _mix64(np.array([np.uint64(seed) * _GOLD + np.uint64(stream)], dtype=np.uint64))[0]
+        idx = np.arange(n, dtype=np.uint64)
+        z = _mix64(base + (idx + np.uint64(1)) * _GOLD)
+    return (z >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
+
+
+def portable_normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """Box-Muller on two portable uniform streams (float64 math, rounded to float32 by the caller)."""
+    u1 = portable_uniform(seed, stream, n)
+    u2 = portable_uniform(seed, stream ^ 0x5BD1E995, n)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def _stream_of(key: str) -> int:
+    return zlib.crc32(key.encode("utf-8")) & 0xFFFFFFFF
+
+
+def portable_state_dict(d: ModelDesc, seed: int = 0, perturb_norms: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded weights with torch-default activation statistics.
+
+    ``perturb_norms`` additionally randomises LayerNorm/BatchNorm affine terms, BatchNorm running
+    statistics and the global input bias/scale so that no term of the network is trivially the
+    identity in parity tests."""
+    st: Dict[str, np.ndarray] = {}
+    for key, shape, kind, fan in state_dict_spec(d):
+        n = int(np.prod(shape)) if shape else 1
+        s = _stream_of(key)
+        if kind == "uniform":
+            bound = 1.0 / math.sqrt(fan)
+            v = (portable_uniform(seed, s, n) * 2.0 - 1.0) * bound
+        elif kind == "normal":
+            v = portable_normal(seed, s, n)
+        elif kind == "ones":
+            v = np.ones(n)
+            if perturb_norms:
+                if key.endswith("running_var"):
+                    v = 0.75 + 0.5 * portable_uniform(seed, s, n)
+                else:
+                    v = 1.0 + 0.1 * (portable_uniform(seed, s, n) * 2.0 - 1.0)
+        elif kind == "zeros":
+            v = np.zeros(n)
+            if perturb_norms:
+                v = 0.1 * (portable_uniform(seed, s, n) * 2.0 - 1.0)
+        elif kind == "int":
+            st[key] = np.zeros(shape, dtype=np.int64)
+            continue
+        else:
+            raise ValueError(kind)
+        st[key] = v.astype(np.float32).reshape(shape)
+    return st
+
+
+def apply_golden_recipe(state: Dict[str, np.ndarray], head_bias: np.ndarray = None,
+                        head_gain: float = 4.0, input_gain: float = 4.0) -> Dict[str, np.ndarray]:
+    """The conditioning recipe of SURVEY.md 8(d)/App. C.6: scale the mask head and the global input
+    scale, and (optionally) install a calibrated head bias that centres every logit row, so that all
+    four sources win a comparable share of frames in every bin (full-rank interference SCMs) while
+    the sigmoids stay unsaturated (no exact WTA ties)."""
+    st = dict(state)
+    st[PREFIX + "linear.weight"] = (st[PREFIX + "linear.weight"] * np.float32(head_gain)).astype(np.float32)
+    st[PREFIX + "input_scale"] = (st[PREFIX + "input_scale"] * np.float32(input_gain)).astype(np.float32)
+    if head_bias is not None:
+        st[PREFIX + "linear.bias"] = np.asarray(head_bias, dtype=np.float32).copy()
+    return st
+
+
+# ----------------------------------------------------------------------------------------------
+# blob packing (layout: include/css_mi355.h, "Weight blob")
+# ----------------------------------------------------------------------------------------------
+def blob_sections(d: ModelDesc) -> List[Tuple[str, int]]:
+    """[(name, n_floats)] in blob order; the C side (csrc/model.hpp: Weights::bind) walks the same list."""
+    D, FF, Kp = d.attention_dim, d.linear_units, d.k_in_padded
+    ks, dk = d.kernel_size, d.attention_dim // d.attention_heads
+    sec: List[Tuple[str, int]] = [
+        ("input_bias", Kp), ("input_scale", Kp),
+        ("embed_w", D * Kp), ("embed_b", D), ("embed_ln_w", D), ("embed_ln_b", D),
+        ("pe_k", 2 * d.maxlen * dk),
+    ]
+    for l in range(d.num_blocks):
+        b = f"b{l}."
+        ffn = lambda ff: [(b + ff + "_ln_w", D), (b + ff + "_ln_b", D), (b + ff + "_w1", FF * D),
+                          (b + ff + "_b1", FF), (b + ff + "_w2", D * FF), (b + ff + "_b2", D)]
+        sec += ffn("ffi")
+        sec += [(b + "att_ln_w", D), (b + "att_ln_b", D), (b + "wqkv", 3 * D * D), (b + "bqkv", 3 * D),
+                (b + "wo", D * D), (b + "bo", D)]
+        sec += [(b + "conv_ln_w", D), (b + "conv_ln_b", D), (b + "pw", 8), (b + "dw_wt", ks * D), (b + "dw_b", D),
+                (b + "bn_alpha", D), (b + "bn_beta", D)]
+        sec += ffn("ffo")
+        sec += [(b + "fin_ln_w", D), (b + "fin_ln_b", D)]
+    nout = d.num_bins * d.n_masks
+    sec += [("head_w", nout * D), ("head_b", nout)]
+    # every section starts on a 64-byte boundary (16 floats)
+    return sec
+
+
+def _padded(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def blob_num_floats(d: ModelDesc) -> int:
+    return sum(_padded(n) for _, n in blob_sections(d))
+
+
+def pack_blob(state: Dict[str, np.ndarray], d: ModelDesc = None) -> Tuple[np.ndarray, ModelDesc]:
+    """state dict (numpy arrays or anything np.asarray accepts) -> (float32 blob, desc)."""
+    st = {k: np.asarray(v) for k, v in strip_module_prefix(state).items()}
+    if d is None:
+        d = ModelDesc.from_state_dict(st)
+    g = lambda k: np.asarray(st[PREFIX + k], dtype=np.float32)
+    D, Kp = d.attention_dim, d.k_in_padded
+    vals: Dict[str, np.ndarray] = {}
+
+    def padk(v, rows):
+        out = np.zeros((rows, Kp), dtype=np.float32)
+        out[:, :d.in_features] = v.reshape(rows, d.in_features)
+        return out
+
+    vals["input_bias"] = padk(g("input_bias"), 1)
+    vals["input_scale"] = padk(g("input_scale"), 1)
+    vals["embed_w"] = padk(g("conformer.embed.0.weight"), D)
+    vals["embed_b"] = g("conformer.embed.0.bias")
+    vals["embed_ln_w"] = g("conformer.embed.1.weight")
+    vals["embed_ln_b"] = g("conformer.embed.1.bias")
+    vals["pe_k"] = g("conformer.pos_emb.pe_k.weight")
+    for l in range(d.num_blocks):
+        p, b = f"conformer.encoders.{l}.", f"b{l}."
+        for ff, name in (("ffi", "feed_forward_in"), ("ffo", "feed_forward_out")):
+            vals[b + ff + "_ln_w"] = g(p + name + ".layer_norm.weight")
+            vals[b + ff + "_ln_b"] = g(p + name + ".layer_norm.bias")
+            vals[b + ff + "_w1"] = g(p + name + ".net.0.weight")
+            vals[b + ff + "_b1"] = g(p + name + ".net.0.bias")
+            vals[b + ff + "_w2"] = g(p + name + ".net.3.weight")
+            vals[b + ff + "_b2"] = g(p + name + ".net.3.bias")
+        vals[b + "att_ln_w"] = g(p + "self_attn.layer_norm.weight")
+        vals[b + "att_ln_b"] = g(p + "self_attn.layer_norm.bias")
+        vals[b + "wqkv"] = np.concatenate([g(p + f"self_attn.linear_{n}.weight") for n in "qkv"], axis=0)
+        vals[b + "bqkv"] = np.concatenate([g(p + f"self_attn.linear_{n}.bias") for n in "qkv"], axis=0)
+        vals[b + "wo"] = g(p + "self_attn.linear_out.weight")
+        vals[b + "bo"] = g(p + "self_attn.linear_out.bias")
+        vals[b + "conv_ln_w"] = g(p + "conv.layer_norm.weight")
+        vals[b + "conv_ln_b"] = g(p + "conv.layer_norm.bias")
+        pw1w, pw1b = g(p + "conv.pw_conv_1.weight").reshape(2), g(p + "conv.pw_conv_1.bias").reshape(2)
+        pw2w, pw2b = g(p + "conv.pw_conv_2.weight").reshape(1), g(p + "conv.pw_conv_2.bias").reshape(1)
+        vals[b + "pw"] = np.array([pw1w[0], pw1b[0], pw1w[1], pw1b[1], pw2w[0], pw2b[0], 0, 0], dtype=np.float32)
+        vals[b + "dw_wt"] = np.ascontiguousarray(g(p + "conv.dw_conv_1d.weight")[:, 0, :].T)  # [tap][channel]
+        vals[b + "dw_b"] = g(p + "conv.dw_conv_1d.bias")
+        # eval-mode BatchNorm exactly as ATen's CPU kernel folds it: alpha = w * rsqrt(var+eps),
+        # beta = b - mean * alpha, y = x * alpha + beta
+        inv = np.float32(1.0) / np.sqrt(g(p + "conv.BN.running_var") + np.float32(1e-5))
+        alpha = (g(p + "conv.BN.weight") * inv).astype(np.float32)
+        vals[b + "bn_alpha"] = alpha
+        vals[b + "bn_beta"] = (g(p + "conv.BN.bias") - g(p + "conv.BN.running_mean") * alpha).astype(np.float32)
+        vals[b + "fin_ln_w"] = g(p + "layer_norm.weight")
+        vals[b + "fin_ln_b"] = g(p + "layer_norm.bias")
+    vals["head_w"] = g("linear.weight")
+    vals["head_b"] = g("linear.bias")
+
+    blob = np.zeros(blob_num_floats(d), dtype=np.float32)
+    off = 0
+    for name, n in blob_sections(d):
+        v = np.ascontiguousarray(vals[name], dtype=np.float32).reshape(-1)
+        assert v.size == n, (name, v.size, n)
+        blob[off:off + n] = v
+        off += _padded(n)
+    return blob, d
