@@ -1,0 +1,224 @@
+/*
+ * css_mi355.h -- C ABI of the MI355X-native continuous speech separation (CSS) front end.
+ *
+ * This is the drop-in boundary for the NOTSOFAR baseline's CSS hot path.  The reference is pure
+ * Python and has no FFI of its own; its boundary is a Python calling convention
+ * (css/css.py:51 css_inference, css/css.py:110 separate_and_stitch, and the separator protocol
+ * stft/separate/istft of css/training/conformer_wrapper.py:79-146).  Each entry point below names the
+ * reference function (file:line under the reference root) whose arithmetic it replaces; the Python
+ * shim in notsofar1-challenge_amd/ re-exposes them under the reference's names via ctypes
+ * (see INTEGRATION.md for the binding a maintainer would add on the reference side).
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned; "host" pointers are ordinary memory, "dev"
+ *     pointers are HIP device memory of the handle's device;
+ *   - every function returns a css_status (0 = ok, negative = error); css_last_error() gives text;
+ *     the negative codes map 1:1 onto the reference's asserts (css/css.py:139,196,202,224,297);
+ *   - a handle owns one HIP stream and its workspace; it is not thread-safe; there is no global state;
+ *   - all arithmetic is float32 like the reference, except the 7x7 spatial-covariance accumulation
+ *     and MVDR solve, which run in float64 (the reference's complex64 solve is
+ *     itself ~2e-5 from the exact answer; float64 keeps our distance from it at that floor).
+ *
+ * Device data layout (HBM, all row-major, last index fastest)
+ *   pcm_cm   [C][n_pad]                 channel-major samples (deinterleaved once on upload)
+ *   X        [C][2*F][T_ld]             STFT planes: rows 0..F-1 = Re, rows F..2F-1 = Im; time fastest
+ *   feat     [tokens][K_pad]            network input, token = local_segment*T_seg + t
+ *   masks    [(S+1)*F][tokens_total]    sigmoid masks, row = k*F + f, column = segment*T_seg + t
+ *   sep      [segments][S][F][T_seg]    separated segment spectra (interleaved re,im float2)
+ *   scm      [segments][S+1][F][49]     Hermitian 7x7 packed (7 real diag + 21 complex), float64
+ *   bfw      [segments][S][F][C]        MVDR weights, complex float64
+ *   mask_st  [S][F][T_long]             stitched masks
+ *   Y        [S][T_long][KI_pad]        gated stitched spectra for the inverse transform (Re | Im | 0-pad)
+ *   wav      [S][n_out]
+ */
+#ifndef CSS_MI355_H
+#define CSS_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct css_ctx* css_handle_t;
+
+typedef enum css_status {
+    CSS_OK = 0,
+    CSS_ERR_INVALID_ARG = -1,    /* css.py:139 (ndim), :196 (batch == 1), bad pointers / sizes          */
+    CSS_ERR_HIP = -2,            /* a HIP runtime call failed (text in css_last_error)                     */
+    CSS_ERR_ZERO_WEIGHT = -3,    /* css.py:297  "zero weights found. check hop_size, segment_size..."     */
+    CSS_ERR_MASK_FLOOR = -4,     /* css.py:224  assert mask_floor_db <= 0                                   */
+    CSS_ERR_SHAPE = -5,          /* css.py:202-203 mask / stft shape mismatch, channel count vs model      */
+    CSS_ERR_STATE = -6,          /* stage called before the stage it depends on                            */
+    CSS_ERR_NO_DEVICE = -7,      /* no usable gfx950 device                                                */
+    CSS_ERR_WEIGHT_WINDOW = -8   /* css.py:374  not enough frames to fit the weighting window              */
+} css_status;
+
+/* Architecture of the mask estimator.  Mirrors the dataclasses of
+ * css/training/conformer_wrapper.py:11-48 (ExtractorCfg / ConformerCfg / NnetCfg). */
+typedef struct CssModelDesc {
+    int32_t num_mics;        /* 7 (multi-channel) or 1 (single-channel)                 */
+    int32_t num_bins;        /* F = frame_len/2 + 1 = 257                               */
+    int32_t in_features;     /* 1799 = F*(1 + 6 IPD pairs), or 257                      */
+    int32_t attention_dim;   /* D = 512                                                 */
+    int32_t attention_heads; /* H = 8                                                   */
+    int32_t linear_units;    /* FF = 1024                                               */
+    int32_t num_blocks;      /* 18                                                      */
+    int32_t kernel_size;     /* depthwise conv taps, 33                                 */
+    int32_t num_spks;        /* S = 3                                                   */
+    int32_t num_nois;        /* 1                                                       */
+    int32_t frame_len;       /* 512                                                     */
+    int32_t frame_hop;       /* 256                                                     */
+    int32_t maxlen;          /* relative-position table half size, 1000 (conformer.py:213) */
+} CssModelDesc;
+
+/* Run-time knobs.  Mirrors the arithmetic-relevant fields of CssCfg (css/css.py:24-48) after the
+ * seconds->frames conversion of css/css.py:144-152, which the host shim performs with the same
+ * Python float expressions. */
+typedef struct CssRunCfg {
+    int32_t segment_frames;          /* 186  (css.py:147)                                         */
+    int32_t hop_frames;              /* 93   (css.py:148)                                         */
+    int32_t dilation_frames;         /* 24   (css.py:151)                                         */
+    int32_t erosion_frames;          /* 12   (css.py:152)                                         */
+    int32_t mc_mvdr;                 /* css.py:211                                                */
+    int32_t stitching_loss;          /* 0 = 'l1', 1 = 'mse'                  (css.py:263)         */
+    int32_t stitching_input;         /* 0 = 'mask', 1 = 'separation_result'  (css.py:267-271)     */
+    int32_t normalize_segment_power; /* css.py:233                                                */
+    float mask_floor;                /* 10^(mask_floor_db/20), 0 for -inf   (css.py:225)          */
+    float activity_th;               /* css.py:304                                                */
+    const float* w_first;            /* [segment_frames] calc_segment_weight(is_first_seg=True)   */
+    const float* w_mid;              /* [segment_frames] calc_segment_weight()                    */
+    const float* w_last;             /* [segment_frames] calc_segment_weight(is_last_seg=True)    */
+} CssRunCfg;
+
+/* Index arithmetic of css/css.py:155-171 for one input length. */
+typedef struct CssPlan {
+    int64_t n_samples;
+    int64_t stft_frames;   /* floor((N - frame_len)/hop) + 1 (feature.py:116), 0 if N < frame_len */
+    int64_t mix_frames;    /* max(stft_frames, segment_frames)     (css.py:159-164)                */
+    int64_t num_segments;  /* ceil((mix_frames - overlap)/hop)     (css.py:166-169)                */
+    int64_t n_out;         /* (mix_frames - 1)*hop + frame_len     (feature.py:162)                */
+    int32_t last_valid;    /* valid frames of the last segment     (css.py:185-190)                */
+    int32_t zero_weight;   /* 1 if css.py:297 would assert                                         */
+} CssPlan;
+
+/* Per-stage wall time of the last css_run*, measured with HIP events on the handle's stream (ms). */
+typedef struct CssTimings {
+    float upload, stft, features, masknet, mvdr, stitch, istft, download, total;
+    float gemm_ms;          /* sum of the durations of the MFMA GEMM launches inside masknet          */
+    int64_t gemm_launches;
+    double gemm_flops;      /* algorithmic FLOPs of those launches (2*M*N*K each)                     */
+} CssTimings;
+
+/* Identifiers of device buffers readable / writable through css_read_buffer / css_write_buffer
+ * (stage-level parity tests; SURVEY.md 8(b) "stage-level entry points"). */
+typedef enum css_buffer {
+    CSS_BUF_X = 0,          /* float  [C][2F][T_ld]                  (see css_buffer_dims)          */
+    CSS_BUF_FEATURES = 1,   /* float  [batch tokens][K_pad]          last processed batch           */
+    CSS_BUF_MASKS = 2,      /* float  [(S+1)F][num_segments*T_seg]                                  */
+    CSS_BUF_SCM = 3,        /* double [segments][S+1][F][49]                                        */
+    CSS_BUF_BFW = 4,        /* double [segments][S][F][C][2]                                        */
+    CSS_BUF_SEP = 5,        /* float  [segments][S][F][T_seg][2]                                    */
+    CSS_BUF_PIT_COST = 6,   /* double [segments-1][S*S]  raw (unpermuted) costs                     */
+    CSS_BUF_PERMS = 7,      /* int32  [segments][S]                                                 */
+    CSS_BUF_MASK_ST = 8,    /* float  [S][F][T_long]                                                */
+    CSS_BUF_ACTIVITY = 9,   /* float  [S][T_long]  mean over F of mask_st                           */
+    CSS_BUF_ACT_B = 10,     /* uint8  [S][T_long]  activity >= th                                   */
+    CSS_BUF_ACT_FINAL = 11, /* uint8  [S][T_long]  after dilate/erode                               */
+    CSS_BUF_Y = 12,         /* float  [S][T_long][KI_pad]                                           */
+    CSS_BUF_WAV = 13,       /* float  [S][n_out]                                                    */
+    CSS_BUF_HIDDEN = 14,    /* float  [batch tokens][D]  encoder output of the last batch           */
+    CSS_BUF_WTA_OVERRIDE = 15 /* uint8 [segments][F][T_seg]  (write-only) injected WTA decisions     */
+} css_buffer;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* css_version(void);
+/* Text of the last error of `h` (or of the last failed css_create when h == NULL). */
+const char* css_last_error(css_handle_t h);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int css_device_count(void);
+
+/* ---- model -------------------------------------------------------------------------------- */
+/* Size in floats of the weight blob css_create expects for `desc` (layout below). */
+int64_t css_blob_num_floats(const CssModelDesc* desc);
+
+/* Replaces css/helpers.py:14 load_css_model + nn.Module.to(device) (css.py:178): uploads the weights
+ * once; they stay resident in HBM for the life of the handle.
+ * `stream` is an existing hipStream_t to launch on (e.g. torch's current stream) or NULL to create one.
+ * `max_batch_segments` bounds the activation workspace (segments per batched network pass).
+ *
+ * Weight blob: float32 sections, each starting on a 16-float boundary, in this order
+ *   input_bias[Kp] input_scale[Kp] embed_w[D][Kp] embed_b[D] embed_ln_w[D] embed_ln_b[D] pe_k[2*maxlen][D/H]
+ *   per block: ffi{ln_w,ln_b,w1[FF][D],b1[FF],w2[D][FF],b2[D]} att_ln_w att_ln_b wqkv[3D][D] bqkv[3D] wo[D][D] bo[D]
+ *              conv_ln_w conv_ln_b pw[8]={pw1.w0,pw1.b0,pw1.w1,pw1.b1,pw2.w,pw2.b,0,0} dw_wt[taps][D] dw_b[D]
+ *              bn_alpha[D] bn_beta[D] ffo{...} fin_ln_w fin_ln_b
+ *   head_w[(S+1)F][D] head_b[(S+1)F]
+ * with Kp = in_features rounded up to a multiple of 32 (zero padded).  Built by
+ * notsofar1-challenge_amd/weights.py::pack_blob from a reference state_dict. */
+int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_floats, int device,
+               void* stream, int32_t max_batch_segments, css_handle_t* out);
+int css_destroy(css_handle_t h);
+
+/* ---- planning (pure host arithmetic, no GPU needed) ---------------------------------------- */
+/* css/css.py:155-171 + css.py:297: frames, segments, output length for an input of n_samples. */
+int css_plan(const CssModelDesc* desc, const CssRunCfg* cfg, int64_t n_samples, CssPlan* out);
+/* Sequential permutation scan of css/css.py:266-285 over raw PIT cost matrices (losses.py:32-48):
+ * costs [n_boundaries][S*S] -> perms [(n_boundaries+1)][S]; perms[0] = identity. */
+int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, int32_t* perms);
+
+/* ---- the hot path: css/css.py:110 separate_and_stitch -------------------------------------- */
+/* pcm_host [n_samples][n_ch] float32 (exactly css/helpers.py:40 load_audio's layout, batch squeezed)
+ * -> wav_host [S][n_out].  One H2D of the PCM, one D2H of the waveforms. */
+int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+            float* wav_host, int64_t wav_capacity_per_stream);
+/* Same with input and output resident in HBM (pcm_dev [n_samples][n_ch], wav_dev [S][n_out]). */
+int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                   float* wav_dev, int64_t wav_capacity_per_stream);
+int css_get_timings(css_handle_t h, CssTimings* out);
+/* enable != 0: bracket every MFMA GEMM launch of the mask estimator with HIP events on the handle's
+ * stream, so that CssTimings.gemm_ms / gemm_launches report the live average launch duration. */
+int css_set_profile(css_handle_t h, int enable);
+int css_get_plan(css_handle_t h, CssPlan* out);
+
+/* ---- stages (each replaces one reference function; state lives in the handle) -------------- */
+/* Begin a session: upload + deinterleave PCM, fix the plan.  (css.py:141-171) */
+int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device);
+/* ConformerCssWrapper.stft (conformer_wrapper.py:106, feature.py:88) over the whole recording. */
+int css_stage_stft(css_handle_t h);
+/* ConformerCssWrapper.separate (conformer_wrapper.py:79): features + Conformer for segments [lo, hi). */
+int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi);
+/* make_mvdr (mvdr_util.py:5) + mask floor/multiply (css.py:222-227) for segments [lo, hi). */
+int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi);
+/* Raw PIT costs (losses.py:50-71) for boundaries [lo, hi) (boundary b joins segments b, b+1). */
+int css_stage_pit_costs(css_handle_t h, int64_t b_lo, int64_t b_hi);
+/* Permutation scan on device over all boundaries (css.py:266-285). */
+int css_stage_pit_scan(css_handle_t h);
+/* Weighted overlap-add + activity gating (css.py:254-312) for frames [t_lo, t_hi). */
+int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi);
+/* ConformerCssWrapper.istft (conformer_wrapper.py:131, feature.py:138) for output frames
+ * [t_lo, t_hi): samples [t_lo*hop, (t_hi)*hop) (+ the tail when t_hi == mix_frames). */
+int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi);
+int css_sync(css_handle_t h);
+
+/* Separator-protocol helpers operating on caller data (host pointers):
+ * stft: pcm [n][C] -> X planes [C][2F][T] (T = stft_frames, tightly packed). */
+int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, float* x_planes, int64_t t_frames);
+/* separate (conformer_wrapper.py:79): X planes [C][2F][B*T] holding B independent segments of T frames
+ * back to back along time -> masks [(S+1)F][B*T] (row k*F + f, column b*T + t). */
+int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks);
+/* istft: Y [B][2F][T] planes (Re rows then Im rows, time fastest) -> wav [B][(T-1)*hop + frame_len]. */
+int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav);
+
+/* ---- buffer access for stage-level parity tests -------------------------------------------- */
+/* dims[0..3] (unused = 1) and element size of a buffer in the current session. */
+int css_buffer_dims(css_handle_t h, int which, int64_t dims[4], int32_t* elem_bytes);
+int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes);
+int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes);
+/* Device address of a buffer (for zero-copy wrapping, e.g. by torch for the RCCL all-gather). */
+int css_buffer_devptr(css_handle_t h, int which, void** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSS_MI355_H */

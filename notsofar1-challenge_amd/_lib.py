@@ -1,0 +1,320 @@
+"""ctypes binding of libcss_mi355.so (the C ABI declared in include/css_mi355.h).
+
+The product path has NO CPU fallback: if the shared library is missing or cannot be loaded, every
+compute entry point raises ``CssLibraryError`` (build it with ``python __graft_entry__.py`` or
+``make -C notsofar1-challenge_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcss_mi355.so")
+
+
+class CssLibraryError(RuntimeError):
+    pass
+
+
+class CssError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"css_mi355 error {code}: {text}")
+        self.code = code
+        self.text = text
+
+
+# status codes (include/css_mi355.h: css_status)
+CSS_OK, CSS_ERR_INVALID_ARG, CSS_ERR_HIP, CSS_ERR_ZERO_WEIGHT, CSS_ERR_MASK_FLOOR = 0, -1, -2, -3, -4
+CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW = -5, -6, -7, -8
+
+# buffer ids (css_buffer)
+(BUF_X, BUF_FEATURES, BUF_MASKS, BUF_SCM, BUF_BFW, BUF_SEP, BUF_PIT_COST, BUF_PERMS, BUF_MASK_ST, BUF_ACTIVITY,
+ BUF_ACT_B, BUF_ACT_FINAL, BUF_Y, BUF_WAV, BUF_HIDDEN, BUF_WTA_OVERRIDE) = range(16)
+_BUF_DTYPES = {BUF_SCM: np.float64, BUF_BFW: np.float64, BUF_PIT_COST: np.float64, BUF_PERMS: np.int32,
+               BUF_ACT_B: np.uint8, BUF_ACT_FINAL: np.uint8, BUF_WTA_OVERRIDE: np.uint8}
+
+
+class CssModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_mics", "num_bins", "in_features", "attention_dim", "attention_heads", "linear_units", "num_blocks",
+        "kernel_size", "num_spks", "num_nois", "frame_len", "frame_hop", "maxlen")]
+
+
+class CssRunCfg(C.Structure):
+    _fields_ = [("segment_frames", C.c_int32), ("hop_frames", C.c_int32), ("dilation_frames", C.c_int32),
+                ("erosion_frames", C.c_int32), ("mc_mvdr", C.c_int32), ("stitching_loss", C.c_int32),
+                ("stitching_input", C.c_int32), ("normalize_segment_power", C.c_int32),
+                ("mask_floor", C.c_float), ("activity_th", C.c_float),
+                ("w_first", C.POINTER(C.c_float)), ("w_mid", C.POINTER(C.c_float)), ("w_last", C.POINTER(C.c_float))]
+
+
+class CssPlan(C.Structure):
+    _fields_ = [("n_samples", C.c_int64), ("stft_frames", C.c_int64), ("mix_frames", C.c_int64),
+                ("num_segments", C.c_int64), ("n_out", C.c_int64), ("last_valid", C.c_int32),
+                ("zero_weight", C.c_int32)]
+
+
+class CssTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("upload", "stft", "features", "masknet", "mvdr", "stitch", "istft",
+                                          "download", "total", "gemm_ms")] + \
+               [("gemm_launches", C.c_int64), ("gemm_flops", C.c_double)]
+
+
+# name -> (restype, argtypes); exactly the symbols include/css_mi355.h declares
+_P = C.c_void_p
+_FP = C.POINTER(C.c_float)
+SIGNATURES = {
+    "css_version": (C.c_char_p, []),
+    "css_last_error": (C.c_char_p, [_P]),
+    "css_device_count": (C.c_int, []),
+    "css_blob_num_floats": (C.c_int64, [C.POINTER(CssModelDesc)]),
+    "css_create": (C.c_int, [C.POINTER(CssModelDesc), _P, C.c_int64, C.c_int, _P, C.c_int32, C.POINTER(_P)]),
+    "css_destroy": (C.c_int, [_P]),
+    "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
+    "css_pit_scan": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
+    "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
+    "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
+    "css_get_timings": (C.c_int, [_P, C.POINTER(CssTimings)]),
+    "css_set_profile": (C.c_int, [_P, C.c_int]),
+    "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
+    "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
+    "css_stage_stft": (C.c_int, [_P]),
+    "css_stage_masknet": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_mvdr": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_pit_costs": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_pit_scan": (C.c_int, [_P]),
+    "css_stage_stitch": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_istft": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_sync": (C.c_int, [_P]),
+    "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
+    "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    "css_buffer_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "css_read_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "css_write_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "css_buffer_devptr": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise loudly (no fallback) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CssLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            f"(or `make -C notsofar1-challenge_amd/csrc`). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise CssLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def check(handle, rc: int):
+    if rc != CSS_OK:
+        text = load().css_last_error(handle).decode("utf-8", "replace")
+        if rc == CSS_ERR_ZERO_WEIGHT:
+            # same exception type and text as the reference's assert (css/css.py:297)
+            raise AssertionError(text or "zero weights found. check hop_size, segment_size or m0, m1")
+        if rc == CSS_ERR_MASK_FLOOR:
+            raise AssertionError(text)  # css/css.py:224
+        raise CssError(rc, text)
+
+
+def make_desc(d) -> CssModelDesc:
+    return CssModelDesc(*[int(getattr(d, n)) for n, _ in CssModelDesc._fields_])
+
+
+class RunCfg:
+    """Owns the CssRunCfg struct together with the numpy weight windows it points to."""
+
+    def __init__(self, segment_frames, hop_frames, dilation_frames, erosion_frames, mc_mvdr, stitching_loss,
+                 stitching_input, normalize_segment_power, mask_floor, activity_th, w_first, w_mid, w_last):
+        self._w = [np.ascontiguousarray(w, dtype=np.float32) for w in (w_first, w_mid, w_last)]
+        for w in self._w:
+            assert w.shape == (segment_frames,)
+        self.c = CssRunCfg(int(segment_frames), int(hop_frames), int(dilation_frames), int(erosion_frames),
+                           int(bool(mc_mvdr)), int(stitching_loss), int(stitching_input),
+                           int(bool(normalize_segment_power)), float(mask_floor), float(activity_th),
+                           self._w[0].ctypes.data_as(_FP), self._w[1].ctypes.data_as(_FP),
+                           self._w[2].ctypes.data_as(_FP))
+
+
+def plan(desc, run_cfg: RunCfg, n_samples: int) -> CssPlan:
+    p = CssPlan()
+    rc = load().css_plan(C.byref(make_desc(desc)), C.byref(run_cfg.c), int(n_samples), C.byref(p))
+    if rc != CSS_OK:
+        raise CssError(rc, "css_plan: bad configuration")
+    return p
+
+
+def pit_scan(costs: np.ndarray, num_spks: int) -> np.ndarray:
+    costs = np.ascontiguousarray(costs, dtype=np.float64).reshape(-1, num_spks * num_spks)
+    perms = np.zeros((costs.shape[0] + 1, num_spks), dtype=np.int32)
+    rc = load().css_pit_scan(_np_ptr(costs), costs.shape[0], num_spks, _np_ptr(perms))
+    if rc != CSS_OK:
+        raise CssError(rc, "css_pit_scan")
+    return perms
+
+
+class Handle:
+    """One model resident on one GPU (css_create .. css_destroy)."""
+
+    def __init__(self, desc, blob: np.ndarray, device: int = 0, stream: int = 0, max_batch_segments: int = 64):
+        lib = load()
+        self.lib = lib
+        self.desc = desc
+        self._cdesc = make_desc(desc)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        need = lib.css_blob_num_floats(C.byref(self._cdesc))
+        if need != blob.size:
+            raise CssError(CSS_ERR_INVALID_ARG, f"weight blob has {blob.size} floats, library expects {need}")
+        h = C.c_void_p()
+        rc = lib.css_create(C.byref(self._cdesc), _np_ptr(blob), blob.size, int(device),
+                            C.c_void_p(stream) if stream else None, int(max_batch_segments), C.byref(h))
+        if rc != CSS_OK:
+            raise CssError(rc, lib.css_last_error(None).decode("utf-8", "replace"))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.css_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- fused path
+    def run(self, pcm: np.ndarray, cfg: RunCfg) -> np.ndarray:
+        """pcm [n, C] float32 host -> wav [S, n_out] float32 host (css/css.py:110)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        n, c = pcm.shape
+        p = plan(self.desc, cfg, n)
+        out = np.empty((self.desc.num_spks, p.n_out), dtype=np.float32)
+        check(self.h, self.lib.css_run(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), p.n_out))
+        return out
+
+    def run_device(self, pcm_ptr: int, n: int, c: int, cfg: RunCfg, wav_ptr: int, cap: int):
+        check(self.h, self.lib.css_run_device(self.h, C.c_void_p(pcm_ptr), n, c, C.byref(cfg.c),
+                                              C.c_void_p(wav_ptr), cap))
+
+    def timings(self) -> dict:
+        t = CssTimings()
+        check(self.h, self.lib.css_get_timings(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in CssTimings._fields_}
+
+    def set_profile(self, enable: bool):
+        check(self.h, self.lib.css_set_profile(self.h, int(enable)))
+
+    def get_plan(self) -> CssPlan:
+        p = CssPlan()
+        check(self.h, self.lib.css_get_plan(self.h, C.byref(p)))
+        return p
+
+    # ---- stages
+    def begin(self, pcm, n: int, c: int, cfg: RunCfg, device: bool = False):
+        if device:
+            ptr = C.c_void_p(int(pcm))
+        else:
+            self._pcm_keep = np.ascontiguousarray(pcm, dtype=np.float32)
+            ptr = _np_ptr(self._pcm_keep)
+        check(self.h, self.lib.css_begin(self.h, ptr, n, c, C.byref(cfg.c), int(device)))
+
+    def stage_stft(self):
+        check(self.h, self.lib.css_stage_stft(self.h))
+
+    def stage_masknet(self, lo, hi):
+        check(self.h, self.lib.css_stage_masknet(self.h, lo, hi))
+
+    def stage_mvdr(self, lo, hi):
+        check(self.h, self.lib.css_stage_mvdr(self.h, lo, hi))
+
+    def stage_pit_costs(self, lo, hi):
+        check(self.h, self.lib.css_stage_pit_costs(self.h, lo, hi))
+
+    def stage_pit_scan(self):
+        check(self.h, self.lib.css_stage_pit_scan(self.h))
+
+    def stage_stitch(self, lo, hi):
+        check(self.h, self.lib.css_stage_stitch(self.h, lo, hi))
+
+    def stage_istft(self, lo, hi):
+        check(self.h, self.lib.css_stage_istft(self.h, lo, hi))
+
+    def sync(self):
+        check(self.h, self.lib.css_sync(self.h))
+
+    # ---- separator protocol helpers
+    def stft_host(self, pcm: np.ndarray) -> np.ndarray:
+        """pcm [n, C] -> planes [C, 2F, T]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        n, c = pcm.shape
+        t = 0 if n < self.desc.frame_len else (n - self.desc.frame_len) // self.desc.frame_hop + 1
+        out = np.zeros((c, 2 * self.desc.num_bins, t), dtype=np.float32)
+        check(self.h, self.lib.css_stft_host(self.h, _np_ptr(pcm), n, c, _np_ptr(out), t))
+        return out
+
+    def separate_host(self, planes: np.ndarray, batch: int) -> np.ndarray:
+        """planes [C, 2F, B*T] (B segments back to back) -> masks [(S+1)F, B*T]."""
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        c, f2, tt = planes.shape
+        assert c == self.desc.num_mics and f2 == 2 * self.desc.num_bins and tt % batch == 0
+        out = np.empty(((self.desc.num_spks + self.desc.num_nois) * self.desc.num_bins, tt), dtype=np.float32)
+        check(self.h, self.lib.css_separate_host(self.h, _np_ptr(planes), batch, tt // batch, _np_ptr(out)))
+        return out
+
+    def istft_host(self, planes: np.ndarray) -> np.ndarray:
+        """planes [B, 2F, T] -> wav [B, (T-1)*hop + frame_len]."""
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        b, _, t = planes.shape
+        out = np.empty((b, (t - 1) * self.desc.frame_hop + self.desc.frame_len), dtype=np.float32)
+        check(self.h, self.lib.css_istft_host(self.h, _np_ptr(planes), b, t, _np_ptr(out)))
+        return out
+
+    # ---- buffers
+    def buffer_dims(self, which: int):
+        dims = (C.c_int64 * 4)()
+        el = C.c_int32()
+        check(self.h, self.lib.css_buffer_dims(self.h, which, dims, C.byref(el)))
+        return tuple(int(x) for x in dims), int(el.value)
+
+    def read(self, which: int) -> np.ndarray:
+        dims, el = self.buffer_dims(which)
+        dt = _BUF_DTYPES.get(which, np.float32)
+        out = np.empty(dims, dtype=dt)
+        assert out.itemsize == el
+        check(self.h, self.lib.css_read_buffer(self.h, which, _np_ptr(out), out.nbytes))
+        return out
+
+    def write(self, which: int, arr: np.ndarray):
+        dims, el = self.buffer_dims(which)
+        dt = _BUF_DTYPES.get(which, np.float32)
+        arr = np.ascontiguousarray(arr, dtype=dt)
+        assert arr.size == int(np.prod(dims)), (arr.shape, dims)
+        check(self.h, self.lib.css_write_buffer(self.h, which, _np_ptr(arr), arr.nbytes))
+
+    def devptr(self, which: int) -> int:
+        p = C.c_void_p()
+        check(self.h, self.lib.css_buffer_devptr(self.h, which, C.byref(p)))
+        return int(p.value or 0)

@@ -1,0 +1,887 @@
+// C ABI of libcss_mi355.so (include/css_mi355.h): handle, weights, session state, stage drivers.
+#include "../../include/css_mi355.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace css;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct BlockWeights {
+    const float *ffi_ln_w, *ffi_ln_b, *ffi_w1, *ffi_b1, *ffi_w2, *ffi_b2;
+    const float *att_ln_w, *att_ln_b, *wqkv, *bqkv, *wo, *bo;
+    const float *conv_ln_w, *conv_ln_b, *pw, *dw_wt, *dw_b, *bn_alpha, *bn_beta;
+    const float *ffo_ln_w, *ffo_ln_b, *ffo_w1, *ffo_b1, *ffo_w2, *ffo_b2;
+    const float *fin_ln_w, *fin_ln_b;
+};
+
+struct Weights {
+    const float *input_bias, *input_scale, *embed_w, *embed_b, *embed_ln_w, *embed_ln_b, *pe_k;
+    std::vector<BlockWeights> blocks;
+    const float *head_w, *head_b;
+};
+
+inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct css_ctx {
+    CssModelDesc d{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int max_batch = 64;
+    int Kp = 0, KIp = 0;
+    float* blob = nullptr;
+    Weights w;
+    float* dft_fwd = nullptr;    // [2F][frame_len]
+    float* dft_inv_t = nullptr;  // [frame_len][KIp]
+
+    // session
+    bool has_session = false;
+    CssRunCfg cfg{};
+    CssPlan plan{};
+    int n_ch = 0;
+    int64_t n_pad = 0, T_ld = 0;
+    bool stft_done = false, perms_done = false, have_override = false;
+    std::vector<float> w_host;
+    DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
+        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage;
+    int64_t last_batch_tokens = 0;
+
+    // timing
+    hipEvent_t ev[10]{};
+    CssTimings tim{};
+    bool profile_gemm = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
+    size_t gemm_events_used = 0;
+    double gemm_flops = 0.0;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(css_ctx* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(h, CSS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+int ensure(css_ctx* h, DevBuf& b, size_t bytes, bool zero = false) {
+    if (bytes <= b.cap) return CSS_OK;
+    if (b.p) HIPCHK(h, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIPCHK(h, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    if (zero) HIPCHK(h, hipMemsetAsync(b.p, 0, bytes, h->stream));
+    return CSS_OK;
+}
+
+// Walks the blob in the order documented in css_mi355.h; returns the number of floats consumed.
+int64_t bind_weights(const CssModelDesc& d, const float* base, Weights* w) {
+    const int64_t D = d.attention_dim, FF = d.linear_units, Kp = round_up(d.in_features, 32);
+    const int64_t dk = D / d.attention_heads, ks = d.kernel_size;
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        const float* p = base ? base + off : nullptr;
+        off += pad16(n);
+        return p;
+    };
+    Weights tmp;
+    Weights& W = w ? *w : tmp;
+    W.input_bias = take(Kp);
+    W.input_scale = take(Kp);
+    W.embed_w = take(D * Kp);
+    W.embed_b = take(D);
+    W.embed_ln_w = take(D);
+    W.embed_ln_b = take(D);
+    W.pe_k = take(2 * (int64_t)d.maxlen * dk);
+    W.blocks.resize(d.num_blocks);
+    for (int l = 0; l < d.num_blocks; ++l) {
+        BlockWeights& b = W.blocks[l];
+        b.ffi_ln_w = take(D); b.ffi_ln_b = take(D); b.ffi_w1 = take(FF * D); b.ffi_b1 = take(FF);
+        b.ffi_w2 = take(D * FF); b.ffi_b2 = take(D);
+        b.att_ln_w = take(D); b.att_ln_b = take(D); b.wqkv = take(3 * D * D); b.bqkv = take(3 * D);
+        b.wo = take(D * D); b.bo = take(D);
+        b.conv_ln_w = take(D); b.conv_ln_b = take(D); b.pw = take(8); b.dw_wt = take(ks * D); b.dw_b = take(D);
+        b.bn_alpha = take(D); b.bn_beta = take(D);
+        b.ffo_ln_w = take(D); b.ffo_ln_b = take(D); b.ffo_w1 = take(FF * D); b.ffo_b1 = take(FF);
+        b.ffo_w2 = take(D * FF); b.ffo_b2 = take(D);
+        b.fin_ln_w = take(D); b.fin_ln_b = take(D);
+    }
+    const int64_t nout = (int64_t)d.num_bins * (d.num_spks + d.num_nois);
+    W.head_w = take(nout * D);
+    W.head_b = take(nout);
+    return off;
+}
+
+const char* validate_desc(const CssModelDesc& d) {
+    if (d.num_mics != 1 && d.num_mics != 7) return "num_mics must be 1 or 7";
+    if (d.frame_len != 2 * d.frame_hop || d.frame_len % 32) return "frame_len must equal 2*frame_hop and be a multiple of 32";
+    if (d.num_bins != d.frame_len / 2 + 1) return "num_bins must be frame_len/2 + 1";
+    if (d.in_features != d.num_bins * d.num_mics) return "in_features must be num_bins * num_mics (magnitude + one IPD block per extra mic)";
+    if (d.attention_dim % 256 || d.attention_dim > 1024 || d.attention_dim <= 0) return "attention_dim must be a multiple of 256, at most 1024";
+    if (d.attention_heads <= 0 || d.attention_dim / d.attention_heads != 64 || d.attention_dim % d.attention_heads) return "head size (attention_dim / attention_heads) must be 64";
+    if (d.linear_units % 32 || d.linear_units <= 0) return "linear_units must be a multiple of 32";
+    if (d.kernel_size != 33 && d.kernel_size != 31 && d.kernel_size != 17) return "kernel_size must be 33, 31 or 17";
+    if (d.num_spks < 1 || d.num_spks > 3 || d.num_nois != 1) return "num_spks must be 1..3 and num_nois 1";
+    if (d.num_blocks < 1 || d.maxlen < 256) return "num_blocks >= 1 and maxlen >= 256 required";
+    return nullptr;
+}
+
+// cos/sin of 2 pi k / N with exact zeros / ones at the multiples of pi/2 (the DC and Nyquist sine rows
+// must be exactly zero: see frontend.hip, PHASE_NEG_REAL)
+void exact_cs(int64_t k, int N, double* c, double* s) {
+    k %= N;
+    const double ang = 2.0 * M_PI * (double)k / (double)N;
+    *c = cos(ang);
+    *s = sin(ang);
+    if ((2 * k) % N == 0) *s = 0.0;
+    if ((4 * k) % N == 0) *c = std::round(*c);
+}
+
+int plan_impl(const CssModelDesc& d, const CssRunCfg& cfg, int64_t n, CssPlan* p) {
+    const int T = cfg.segment_frames, hop = cfg.hop_frames;
+    if (T <= 0 || hop <= 0 || hop > T) return CSS_ERR_INVALID_ARG;
+    p->n_samples = n;
+    p->stft_frames = n < d.frame_len ? 0 : (n - d.frame_len) / d.frame_hop + 1;
+    p->mix_frames = std::max<int64_t>(p->stft_frames, T);
+    const int64_t ov = T - hop;
+    p->num_segments = (p->mix_frames - ov + hop - 1) / hop;  // ceil((mix - ov)/hop)
+    p->n_out = (p->mix_frames - 1) * d.frame_hop + d.frame_len;
+    const int64_t st = (p->num_segments - 1) * hop;
+    int64_t en = st + T;
+    if (en >= p->mix_frames) en = p->mix_frames;
+    p->last_valid = (int32_t)(en - st);
+    // css.py:297: every frame must collect a total weight > 1e-5
+    p->zero_weight = 0;
+    if (cfg.w_first && cfg.w_mid && cfg.w_last) {
+        for (int64_t t = 0; t < p->mix_frames && !p->zero_weight; ++t) {
+            float ws = 0.f;
+            for (int64_t seg = std::max<int64_t>(0, (t - T + hop) / hop); seg <= t / hop && seg < p->num_segments; ++seg) {
+                const int64_t tl = t - seg * hop;
+                if (tl < 0 || tl >= T) continue;
+                const float* w = seg == 0 ? cfg.w_first : (seg == p->num_segments - 1 ? cfg.w_last : cfg.w_mid);
+                ws += w[tl];
+            }
+            if (!(ws > 1e-5f)) p->zero_weight = 1;
+        }
+    }
+    return CSS_OK;
+}
+
+void gemm(css_ctx* h, const GemmArgs& g) {
+    if (h->profile_gemm) {
+        if (h->gemm_events_used == h->gemm_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            h->gemm_events.emplace_back(a, b);
+        }
+        auto& ev = h->gemm_events[h->gemm_events_used++];
+        hipEventRecord(ev.first, h->stream);
+        launch_gemm(g, h->stream);
+        hipEventRecord(ev.second, h->stream);
+        h->gemm_flops += 2.0 * g.M * (double)g.N * g.K * g.batch;
+    } else {
+        launch_gemm(g, h->stream);
+    }
+}
+
+GemmArgs linear(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                int M, int N, int K, int act) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.strideA = 0;
+    g.B = W; g.ldb = ldw; g.strideB = 0;
+    g.C = C; g.ldc = ldc; g.strideC = 0;
+    g.M = M; g.N = N; g.K = K; g.batch = 1;
+    g.bias = bias; g.bias_along_m = 0; g.act = act;
+    g.residual = nullptr; g.ldr = 0; g.alpha = 1.f;
+    return g;
+}
+
+StitchArgs stitch_args(css_ctx* h) {
+    StitchArgs a{};
+    const int T = h->cfg.segment_frames;
+    a.masks = (const float*)h->masks.p;
+    a.mask_ld = h->plan.num_segments * T;
+    a.sep = (const float*)h->sep.p;
+    a.S = h->d.num_spks; a.F = h->d.num_bins; a.T = T; a.hop = h->cfg.hop_frames;
+    a.num_segments = h->plan.num_segments; a.T_long = h->plan.mix_frames;
+    a.w_first = (const float*)h->segw.p; a.w_mid = a.w_first + T; a.w_last = a.w_mid + T;
+    a.perms = (const int32_t*)h->perms.p;
+    a.mask_st = (float*)h->mask_st.p; a.activity = (float*)h->activity.p;
+    a.act_b = (uint8_t*)h->act_b.p; a.act_tmp = (uint8_t*)h->act_tmp.p; a.act_final = (uint8_t*)h->act_final.p;
+    a.activity_th = h->cfg.activity_th; a.dilation = h->cfg.dilation_frames; a.erosion = h->cfg.erosion_frames;
+    a.Y = (float*)h->Y.p; a.KIp = h->KIp;
+    return a;
+}
+
+MvdrArgs mvdr_args(css_ctx* h, int64_t lo, int nseg) {
+    MvdrArgs a{};
+    const int T = h->cfg.segment_frames;
+    a.X = (const float*)h->X.p; a.T_ld = h->T_ld; a.stft_frames = h->plan.stft_frames;
+    a.C = h->n_ch; a.F = h->d.num_bins;
+    a.masks = (const float*)h->masks.p; a.mask_ld = h->plan.num_segments * T;
+    a.S = h->d.num_spks; a.T = T; a.hop = h->cfg.hop_frames;
+    a.seg_lo = lo; a.nseg = nseg;
+    a.wta_override = h->have_override ? (const uint8_t*)h->wta.p : nullptr;
+    a.scm = (double*)h->scm.p; a.bfw = (double*)h->bfw.p; a.sep = (float*)h->sep.p;
+    a.mask_floor = h->cfg.mask_floor;
+    a.use_mvdr = (h->n_ch > 1 && h->cfg.mc_mvdr) ? 1 : 0;
+    return a;
+}
+
+// activation workspace of the mask estimator for batches of up to `nb` segments of T frames
+int ensure_activations(css_ctx* h, int64_t nb, int T) {
+    const int64_t Mb = nb * T;
+    const int D = h->d.attention_dim, FF = h->d.linear_units;
+    int rc;
+    if ((rc = ensure(h, h->feat, (size_t)Mb * h->Kp * sizeof(float), true)) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->hx, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->hu, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->ht, (size_t)Mb * FF * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->qkv, (size_t)Mb * 3 * D * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->ctxb, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
+    return CSS_OK;
+}
+
+int check_session(css_ctx* h) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (!h->has_session) return fail(h, CSS_ERR_STATE, "no session: call css_begin first");
+    return CSS_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* css_version(void) { return "css_mi355 0.1 (gfx950)"; }
+
+const char* css_last_error(css_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int css_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t css_blob_num_floats(const CssModelDesc* desc) {
+    if (!desc || validate_desc(*desc)) return -1;
+    return bind_weights(*desc, nullptr, nullptr);
+}
+
+int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_floats, int device, void* stream,
+               int32_t max_batch_segments, css_handle_t* out) {
+    if (!desc || !blob_host || !out) return fail(nullptr, CSS_ERR_INVALID_ARG, "null argument");
+    if (const char* why = validate_desc(*desc)) return fail(nullptr, CSS_ERR_INVALID_ARG, why);
+    const int64_t need = bind_weights(*desc, nullptr, nullptr);
+    if (blob_floats != need)
+        return fail(nullptr, CSS_ERR_INVALID_ARG, "weight blob has " + std::to_string(blob_floats) + " floats, expected " + std::to_string(need));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, CSS_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, CSS_ERR_NO_DEVICE, "device index out of range");
+    css_ctx* h = new css_ctx();
+    h->d = *desc;
+    h->device = device;
+    h->max_batch = max_batch_segments > 0 ? max_batch_segments : 64;
+    h->Kp = round_up(desc->in_features, 32);
+    h->KIp = round_up(2 * desc->num_bins, 32);
+    auto bail = [&](int code, const std::string& msg) {
+        g_create_error = msg.empty() ? h->err : msg;
+        css_destroy(h);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(CSS_ERR_HIP, "hipSetDevice failed");
+    if (stream) {
+        h->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreate(&h->stream) != hipSuccess) return bail(CSS_ERR_HIP, "hipStreamCreate failed");
+        h->own_stream = true;
+    }
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(CSS_ERR_HIP, "hipEventCreate failed");
+    if (hipMalloc((void**)&h->blob, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(weights) failed");
+    if (hipMemcpy(h->blob, blob_host, need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(CSS_ERR_HIP, "weight upload failed");
+    bind_weights(*desc, h->blob, &h->w);
+
+    // transform matrices (feature.py:19-45): analysis = Hann * DFT, S = 1; synthesis = sqrt-Hann * DFT / 16
+    const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
+    std::vector<float> fwd((size_t)2 * F * N), inv((size_t)N * KI, 0.f);
+    const double S = 0.5 * std::sqrt((double)N * N / desc->frame_hop);
+    for (int n = 0; n < N; ++n) {
+        const double wn = 0.5 - 0.5 * cos(2.0 * M_PI * n / N);  // torch.hann_window (periodic)
+        const double wf = (double)(float)wn;                    // the reference holds the window in float32
+        const double ws = (double)(float)std::sqrt((float)wn);  // W ** 0.5 on the float32 window
+        for (int f = 0; f < F; ++f) {
+            double c, s;
+            exact_cs((int64_t)f * n, N, &c, &s);
+            fwd[(size_t)f * N + n] = (float)(c * wf);
+            fwd[(size_t)(F + f) * N + n] = (float)(0.0 - s * wf);
+            inv[(size_t)n * KI + f] = (float)(c * ws / S);
+            inv[(size_t)n * KI + F + f] = (float)(0.0 - s * ws / S);
+        }
+    }
+    if (hipMalloc((void**)&h->dft_fwd, fwd.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&h->dft_inv_t, inv.size() * sizeof(float)) != hipSuccess)
+        return bail(CSS_ERR_HIP, "hipMalloc(dft) failed");
+    if (hipMemcpy(h->dft_fwd, fwd.data(), fwd.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->dft_inv_t, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(CSS_ERR_HIP, "dft upload failed");
+    *out = h;
+    return CSS_OK;
+}
+
+int css_destroy(css_handle_t h) {
+    if (!h) return CSS_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->ctxb, &h->masks,
+                      &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
+                      &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    if (h->blob) hipFree(h->blob);
+    if (h->dft_fwd) hipFree(h->dft_fwd);
+    if (h->dft_inv_t) hipFree(h->dft_inv_t);
+    for (auto& e : h->ev)
+        if (e) hipEventDestroy(e);
+    for (auto& pr : h->gemm_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return CSS_OK;
+}
+
+int css_plan(const CssModelDesc* desc, const CssRunCfg* cfg, int64_t n_samples, CssPlan* out) {
+    if (!desc || !cfg || !out || n_samples < 0) return CSS_ERR_INVALID_ARG;
+    return plan_impl(*desc, *cfg, n_samples, out);
+}
+
+int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, int32_t* perms) {
+    if (!perms || n_boundaries < 0 || num_spks < 1 || num_spks > 4 || (n_boundaries > 0 && !costs)) return CSS_ERR_INVALID_ARG;
+    pit_scan_host(costs, n_boundaries, num_spks, perms);
+    return CSS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device) {
+    if (!h || !pcm || !cfg) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (n_ch != h->d.num_mics)
+        return fail(h, CSS_ERR_SHAPE, "input has " + std::to_string(n_ch) + " channels, the model expects " + std::to_string(h->d.num_mics));
+    if (!cfg->w_first || !cfg->w_mid || !cfg->w_last) return fail(h, CSS_ERR_INVALID_ARG, "segment weights missing");
+    if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
+    const int T = cfg->segment_frames, hop = cfg->hop_frames;
+    if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256]");
+    if (hop <= 0 || 2 * hop < T || hop > T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/2 <= hop <= T (at most two segments overlap)");
+    if (T - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "segment longer than the relative-position table");
+    HIPCHK(h, hipSetDevice(h->device));
+    CssPlan p{};
+    if (plan_impl(h->d, *cfg, n_samples, &p) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "bad segment configuration");
+    if (p.zero_weight) return fail(h, CSS_ERR_ZERO_WEIGHT, "zero weights found. check hop_size, segment_size or m0, m1");
+    h->cfg = *cfg;
+    h->w_host.assign(3 * (size_t)T, 0.f);
+    std::memcpy(h->w_host.data(), cfg->w_first, T * sizeof(float));
+    std::memcpy(h->w_host.data() + T, cfg->w_mid, T * sizeof(float));
+    std::memcpy(h->w_host.data() + 2 * T, cfg->w_last, T * sizeof(float));
+    h->cfg.w_first = h->w_host.data();
+    h->cfg.w_mid = h->w_host.data() + T;
+    h->cfg.w_last = h->w_host.data() + 2 * T;
+    h->plan = p;
+    h->n_ch = n_ch;
+    h->n_pad = (n_samples + 3) / 4 * 4;
+    h->T_ld = (p.mix_frames + 3) / 4 * 4;
+    h->stft_done = h->perms_done = h->have_override = false;
+    h->has_session = true;
+    h->tim = CssTimings{};
+    h->gemm_events_used = 0;
+    h->gemm_flops = 0.0;
+
+    const int F = h->d.num_bins, S = h->d.num_spks;
+    const int64_t nseg = p.num_segments, TL = p.mix_frames;
+    int rc;
+#define ENS(buf, bytes, ...)                                              \
+    if ((rc = ensure(h, h->buf, (size_t)(bytes), ##__VA_ARGS__)) != CSS_OK) return rc;
+    hipEventRecord(h->ev[0], h->stream);
+    ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
+    ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
+    if ((rc = ensure_activations(h, std::min<int64_t>(h->max_batch, nseg), T)) != CSS_OK) return rc;
+    ENS(masks, (size_t)(S + 1) * F * nseg * T * sizeof(float))
+    ENS(scm, (size_t)nseg * (S + 1) * F * 49 * sizeof(double))
+    ENS(bfw, (size_t)nseg * S * F * 7 * 2 * sizeof(double))
+    ENS(sep, (size_t)nseg * S * F * T * 2 * sizeof(float))
+    ENS(costs, (size_t)std::max<int64_t>(nseg - 1, 1) * S * S * sizeof(double))
+    ENS(perms, (size_t)nseg * S * sizeof(int32_t))
+    ENS(mask_st, (size_t)S * F * TL * sizeof(float))
+    ENS(activity, (size_t)S * TL * sizeof(float))
+    ENS(act_b, (size_t)S * TL)
+    ENS(act_tmp, (size_t)S * TL)
+    ENS(act_final, (size_t)S * TL)
+    ENS(Y, (size_t)S * TL * h->KIp * sizeof(float))
+    ENS(G, (size_t)S * TL * h->d.frame_len * sizeof(float))
+    ENS(wav, (size_t)S * p.n_out * sizeof(float))
+    ENS(pnorm, (size_t)nseg * sizeof(double))
+    ENS(segw, (size_t)3 * T * sizeof(float))
+    HIPCHK(h, hipMemcpyAsync(h->segw.p, h->w_host.data(), 3 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const float* pcm_dev = pcm;
+    if (!pcm_is_device) {
+        ENS(pcm_in, (size_t)n_samples * n_ch * sizeof(float))
+        HIPCHK(h, hipMemcpyAsync(h->pcm_in.p, pcm, (size_t)n_samples * n_ch * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        pcm_dev = (const float*)h->pcm_in.p;
+    }
+#undef ENS
+    launch_deinterleave(pcm_dev, (float*)h->pcm_cm.p, n_samples, n_ch, h->n_pad, h->stream);
+    hipEventRecord(h->ev[1], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_stft(css_handle_t h) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int F = h->d.num_bins, N = h->d.frame_len;
+    if (h->plan.stft_frames < h->plan.mix_frames)  // short input: zero-padded frames (css.py:159-164)
+        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+    if (h->plan.stft_frames > 0) {
+        GemmArgs g{};
+        g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
+        g.B = (const float*)h->pcm_cm.p; g.ldb = h->d.frame_hop; g.strideB = h->n_pad;
+        g.C = (float*)h->X.p; g.ldc = h->T_ld; g.strideC = (int64_t)2 * F * h->T_ld;
+        g.M = 2 * F; g.N = (int)h->plan.stft_frames; g.K = N; g.batch = h->n_ch;
+        g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
+        launch_gemm(g, h->stream);
+    }
+    hipEventRecord(h->ev[2], h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->stft_done = true;
+    return CSS_OK;
+}
+
+// Where one batched pass of the mask estimator reads its spectra and writes its masks.
+struct MaskIo {
+    const float* X; int64_t T_ld; int64_t stft_frames; int hop; int T;   // planes [C][2F][T_ld], segment s at s*hop
+    float* masks; int64_t mask_ld;                                       // [(S+1)F][mask_ld], segment s at column s*T
+};
+
+// One batched pass of the mask estimator over `nb` segments starting at `s0`.
+static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
+    const CssModelDesc& d = h->d;
+    const int T = io.T, D = d.attention_dim, FF = d.linear_units, F = d.num_bins;
+    const int M = nb * T;
+    hipStream_t st = h->stream;
+    float* feat = (float*)h->feat.p; float* x = (float*)h->hx.p; float* u = (float*)h->hu.p;
+    float* t1 = (float*)h->ht.p; float* qkv = (float*)h->qkv.p; float* cb = (float*)h->ctxb.p;
+    const Weights& W = h->w;
+    launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
+                    io.hop, st);
+    // embed: Linear -> LayerNorm -> ReLU (conformer.py:205-210)
+    gemm(h, linear(feat, h->Kp, W.embed_w, h->Kp, W.embed_b, u, D, M, D, h->Kp, ACT_NONE));
+    launch_layernorm(u, x, W.embed_ln_w, W.embed_ln_b, M, D, 1, st);
+    for (int l = 0; l < d.num_blocks; ++l) {
+        const BlockWeights& b = W.blocks[l];
+        auto ffn = [&](const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                       const float* b2) {
+            launch_layernorm(x, u, lnw, lnb, M, D, 0, st);
+            gemm(h, linear(u, D, w1, D, b1, t1, FF, M, FF, D, ACT_RELU));
+            GemmArgs g = linear(t1, FF, w2, FF, b2, x, D, M, D, FF, ACT_NONE);
+            g.residual = x; g.ldr = D; g.alpha = 0.5f;  // x + 0.5 * ff(x)  (conformer.py:179,182)
+            gemm(h, g);
+        };
+        ffn(b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
+        // self attention (conformer.py:65-92)
+        launch_layernorm(x, u, b.att_ln_w, b.att_ln_b, M, D, 0, st);
+        gemm(h, linear(u, D, b.wqkv, D, b.bqkv, qkv, 3 * D, M, 3 * D, D, ACT_NONE));
+        launch_relpos_attention(qkv, W.pe_k, cb, nb, T, D, d.attention_heads, d.maxlen, st);
+        {
+            GemmArgs g = linear(cb, D, b.wo, D, b.bo, x, D, M, D, D, ACT_NONE);
+            g.residual = x; g.ldr = D; g.alpha = 1.f;
+            gemm(h, g);
+        }
+        // conv module (conformer.py:113-127)
+        launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
+        launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
+        ffn(b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
+        launch_layernorm(x, x, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);  // conformer.py:184
+    }
+    // mask head (conformer.py:302-310), transposed so that time is the fastest axis of every mask:
+    // masks[(k*F + f)][segment*T + t] = sigmoid(head_w[k*F + f] . x[token] + head_b[k*F + f])
+    GemmArgs g{};
+    const int nout = F * (d.num_spks + d.num_nois);
+    g.A = W.head_w; g.lda = D; g.strideA = 0;
+    g.B = x; g.ldb = D; g.strideB = 0;
+    g.C = io.masks + s0 * T; g.ldc = io.mask_ld; g.strideC = 0;
+    g.M = nout; g.N = M; g.K = D; g.batch = 1;
+    g.bias = W.head_b; g.bias_along_m = 1; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
+    gemm(h, g);
+    h->last_batch_tokens = M;
+    return CSS_OK;
+}
+
+int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!h->stft_done) return fail(h, CSS_ERR_STATE, "css_stage_stft must run before css_stage_masknet");
+    if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int T = h->cfg.segment_frames;
+    const int64_t cap = std::min<int64_t>(h->max_batch, h->plan.num_segments);
+    MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, (float*)h->masks.p,
+              h->plan.num_segments * T};
+    for (int64_t s0 = seg_lo; s0 < seg_hi; s0 += cap) {
+        const int nb = (int)std::min<int64_t>(cap, seg_hi - s0);
+        if ((rc = masknet_batch(h, io, s0, nb)) != CSS_OK) return rc;
+    }
+    hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (seg_hi > seg_lo) {
+        MvdrArgs a = mvdr_args(h, seg_lo, (int)(seg_hi - seg_lo));
+        if (a.use_mvdr) {
+            launch_scm(a, h->stream);
+            launch_mvdr_solve(a, h->stream);
+        }
+        launch_beamform(a, h->stream);
+        if (h->cfg.normalize_segment_power) launch_segment_power_norm(a, (double*)h->pnorm.p, h->stream);
+    }
+    hipEventRecord(h->ev[4], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_pit_costs(css_handle_t h, int64_t b_lo, int64_t b_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (b_lo < 0 || b_hi > h->plan.num_segments - 1 || b_lo > b_hi) return fail(h, CSS_ERR_INVALID_ARG, "boundary range out of bounds");
+    if (h->cfg.stitching_loss < 0 || h->cfg.stitching_loss > 1 || h->cfg.stitching_input < 0 || h->cfg.stitching_input > 1)
+        return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->costs.p, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_pit_scan(css_handle_t h) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_pit_scan((const double*)h->costs.p, h->plan.num_segments - 1, h->d.num_spks, (int32_t*)h->perms.p, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->perms_done = true;
+    return CSS_OK;
+}
+
+int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
+    const int64_t TL = h->plan.mix_frames;
+    if (t_lo < 0 || t_hi > TL || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
+    HIPCHK(h, hipSetDevice(h->device));
+    StitchArgs a = stitch_args(h);
+    // the inverse transform of frame range [t_lo, t_hi) also needs frame t_lo - 1 (2-frame overlap-add),
+    // and the dilate/erode gate needs activity `dilation + erosion` frames to either side
+    const int64_t y_lo = std::max<int64_t>(t_lo - 1, 0);
+    const int64_t halo = a.dilation + a.erosion;
+    launch_ola_masks(a, std::max<int64_t>(y_lo - halo, 0), std::min<int64_t>(t_hi + halo, TL), h->stream);
+    launch_morphology(a, y_lo, t_hi, h->stream);
+    launch_ola_stft(a, y_lo, t_hi, h->stream);
+    hipEventRecord(h->ev[5], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    const int64_t TL = h->plan.mix_frames;
+    if (t_lo < 0 || t_hi > TL || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int S = h->d.num_spks, N = h->d.frame_len;
+    const int64_t y_lo = std::max<int64_t>(t_lo - 1, 0);
+    if (t_hi > y_lo) {
+        GemmArgs g{};
+        g.A = (const float*)h->Y.p + y_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
+        g.B = h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
+        g.C = (float*)h->G.p + y_lo * N; g.ldc = N; g.strideC = TL * N;
+        g.M = (int)(t_hi - y_lo); g.N = N; g.K = h->KIp; g.batch = S;
+        g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
+        launch_gemm(g, h->stream);
+        const int64_t q_hi = (t_hi == TL) ? TL + 1 : t_hi;  // the last rank also writes the tail half-frame
+        launch_wave_ola((const float*)h->G.p, (float*)h->wav.p, S, TL, h->d.frame_hop, t_lo, q_hi, h->plan.n_out, h->stream);
+    }
+    hipEventRecord(h->ev[6], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_sync(css_handle_t h) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CSS_OK;
+}
+
+static int run_impl(css_handle_t h, const float* pcm, int64_t n, int32_t n_ch, const CssRunCfg* cfg, float* wav,
+                    int64_t cap, int device_io) {
+    int rc;
+    if (!h || !wav) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if ((rc = css_begin(h, pcm, n, n_ch, cfg, device_io)) != CSS_OK) return rc;
+    if (cap < h->plan.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(h->plan.n_out) + " samples per stream");
+    const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
+    if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
+    if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
+    if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
+    if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
+    if ((rc = css_stage_pit_scan(h)) != CSS_OK) return rc;
+    if ((rc = css_stage_stitch(h, 0, TL)) != CSS_OK) return rc;
+    if ((rc = css_stage_istft(h, 0, TL)) != CSS_OK) return rc;
+    const int S = h->d.num_spks;
+    HIPCHK(h, hipMemcpy2DAsync(wav, (size_t)cap * sizeof(float), h->wav.p, (size_t)h->plan.n_out * sizeof(float),
+                               (size_t)h->plan.n_out * sizeof(float), S,
+                               device_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    hipEventRecord(h->ev[7], h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
+    CssTimings& t = h->tim;
+    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = ms(3, 4); t.stitch = ms(4, 5);
+    t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
+    t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
+    if (h->profile_gemm) {
+        for (size_t i = 0; i < h->gemm_events_used; ++i) {
+            float v = 0.f;
+            hipEventElapsedTime(&v, h->gemm_events[i].first, h->gemm_events[i].second);
+            t.gemm_ms += v;
+        }
+        t.gemm_launches = (int64_t)h->gemm_events_used;
+    }
+    return CSS_OK;
+}
+
+int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, float* wav_host,
+            int64_t cap) {
+    return run_impl(h, pcm_host, n_samples, n_ch, cfg, wav_host, cap, 0);
+}
+
+int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                   float* wav_dev, int64_t cap) {
+    return run_impl(h, pcm_dev, n_samples, n_ch, cfg, wav_dev, cap, 1);
+}
+
+int css_set_profile(css_handle_t h, int enable) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    h->profile_gemm = enable != 0;
+    return CSS_OK;
+}
+
+int css_get_timings(css_handle_t h, CssTimings* out) {
+    if (!h || !out) return CSS_ERR_INVALID_ARG;
+    *out = h->tim;
+    return CSS_OK;
+}
+
+int css_get_plan(css_handle_t h, CssPlan* out) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!out) return CSS_ERR_INVALID_ARG;
+    *out = h->plan;
+    return CSS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// separator-protocol helpers on caller data
+int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, float* x_planes, int64_t t_frames) {
+    if (!h || !pcm || !x_planes) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (n_ch < 1) return fail(h, CSS_ERR_SHAPE, "n_ch must be >= 1");
+    const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop;
+    const int64_t T = n_samples < N ? 0 : (n_samples - N) / hop + 1;
+    if (t_frames != T) return fail(h, CSS_ERR_SHAPE, "t_frames must be floor((n - frame_len)/hop) + 1 = " + std::to_string(T));
+    if (T == 0) return CSS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t n_pad = (n_samples + 3) / 4 * 4;
+    const size_t in_b = (size_t)n_samples * n_ch * sizeof(float), cm_b = (size_t)n_pad * n_ch * sizeof(float);
+    const size_t out_b = (size_t)n_ch * 2 * F * T * sizeof(float);
+    int rc;
+    if ((rc = ensure(h, h->stage, in_b + cm_b + out_b + 64)) != CSS_OK) return rc;
+    float* in = (float*)h->stage.p;
+    float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
+    float* out = cm + (size_t)n_pad * n_ch;
+    HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
+    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, h->stream);
+    GemmArgs g{};
+    g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
+    g.B = cm; g.ldb = hop; g.strideB = n_pad;
+    g.C = out; g.ldc = T; g.strideC = (int64_t)2 * F * T;
+    g.M = 2 * F; g.N = (int)T; g.K = N; g.batch = n_ch;
+    g.alpha = 1.f;
+    launch_gemm(g, h->stream);
+    HIPCHK(h, hipMemcpyAsync(x_planes, out, out_b, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CSS_OK;
+}
+
+int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks) {
+    if (!h || !x_planes || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    if (t_frames < 2 || t_frames > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 256] frames");
+    if (t_frames - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "segment longer than the relative-position table");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int F = h->d.num_bins, C = h->d.num_mics, T = t_frames, nm = h->d.num_spks + h->d.num_nois;
+    const int64_t TT = (int64_t)batch * T;
+    const size_t x_f = (size_t)C * 2 * F * TT, m_f = (size_t)nm * F * TT;
+    int rc;
+    if ((rc = ensure(h, h->stage, (x_f + m_f + 16) * sizeof(float))) != CSS_OK) return rc;
+    float* X = (float*)h->stage.p;
+    float* M = X + (x_f + 3) / 4 * 4;
+    HIPCHK(h, hipMemcpyAsync(X, x_planes, x_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const int64_t cap = std::min<int64_t>(h->max_batch, batch);
+    if ((rc = ensure_activations(h, cap, T)) != CSS_OK) return rc;
+    MaskIo io{X, TT, TT, T, T, M, TT};  // item b is the "segment" starting at frame b*T
+    for (int64_t s0 = 0; s0 < batch; s0 += cap)
+        if ((rc = masknet_batch(h, io, s0, (int)std::min<int64_t>(cap, batch - s0))) != CSS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(masks, M, m_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav) {
+    if (!h || !y_planes || !wav || batch < 1 || t_frames < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop, KI = h->KIp;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t n_out = (t_frames - 1) * hop + N;
+    const size_t in_f = (size_t)batch * 2 * F * t_frames, rows_f = (size_t)batch * t_frames * KI;
+    const size_t g_f = (size_t)batch * t_frames * N, w_f = (size_t)batch * n_out;
+    int rc;
+    if ((rc = ensure(h, h->stage, (in_f + rows_f + g_f + w_f + 16) * sizeof(float))) != CSS_OK) return rc;
+    float* in = (float*)h->stage.p;
+    float* rows = in + (in_f + 3) / 4 * 4;
+    float* G = rows + rows_f;
+    float* wv = G + g_f;
+    HIPCHK(h, hipMemcpyAsync(in, y_planes, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    launch_planes_to_rows(in, rows, batch, 2 * F, t_frames, KI, h->stream);
+    GemmArgs g{};
+    g.A = rows; g.lda = KI; g.strideA = t_frames * KI;
+    g.B = h->dft_inv_t; g.ldb = KI; g.strideB = 0;
+    g.C = G; g.ldc = N; g.strideC = t_frames * N;
+    g.M = (int)t_frames; g.N = N; g.K = KI; g.batch = batch;
+    g.alpha = 1.f;
+    launch_gemm(g, h->stream);
+    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, n_out, h->stream);
+    HIPCHK(h, hipMemcpyAsync(wav, wv, w_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CSS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+static int buffer_info(css_ctx* h, int which, DevBuf** buf, int64_t dims[4], int32_t* elem) {
+    const int F = h->d.num_bins, S = h->d.num_spks, T = h->cfg.segment_frames;
+    const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
+    dims[0] = dims[1] = dims[2] = dims[3] = 1;
+    *elem = 4;
+    switch (which) {
+        case CSS_BUF_X: *buf = &h->X; dims[0] = h->n_ch; dims[1] = 2 * F; dims[2] = h->T_ld; break;
+        case CSS_BUF_FEATURES: *buf = &h->feat; dims[0] = h->last_batch_tokens; dims[1] = h->Kp; break;
+        case CSS_BUF_MASKS: *buf = &h->masks; dims[0] = (int64_t)(S + 1) * F; dims[1] = nseg * T; break;
+        case CSS_BUF_SCM: *buf = &h->scm; dims[0] = nseg; dims[1] = S + 1; dims[2] = F; dims[3] = 49; *elem = 8; break;
+        case CSS_BUF_BFW: *buf = &h->bfw; dims[0] = nseg; dims[1] = S; dims[2] = F; dims[3] = 14; *elem = 8; break;
+        case CSS_BUF_SEP: *buf = &h->sep; dims[0] = nseg; dims[1] = S; dims[2] = F; dims[3] = (int64_t)T * 2; break;
+        case CSS_BUF_PIT_COST: *buf = &h->costs; dims[0] = std::max<int64_t>(nseg - 1, 0); dims[1] = S * S; *elem = 8; break;
+        case CSS_BUF_PERMS: *buf = &h->perms; dims[0] = nseg; dims[1] = S; break;
+        case CSS_BUF_MASK_ST: *buf = &h->mask_st; dims[0] = S; dims[1] = F; dims[2] = TL; break;
+        case CSS_BUF_ACTIVITY: *buf = &h->activity; dims[0] = S; dims[1] = TL; break;
+        case CSS_BUF_ACT_B: *buf = &h->act_b; dims[0] = S; dims[1] = TL; *elem = 1; break;
+        case CSS_BUF_ACT_FINAL: *buf = &h->act_final; dims[0] = S; dims[1] = TL; *elem = 1; break;
+        case CSS_BUF_Y: *buf = &h->Y; dims[0] = S; dims[1] = TL; dims[2] = h->KIp; break;
+        case CSS_BUF_WAV: *buf = &h->wav; dims[0] = S; dims[1] = h->plan.n_out; break;
+        case CSS_BUF_HIDDEN: *buf = &h->hx; dims[0] = h->last_batch_tokens; dims[1] = h->d.attention_dim; break;
+        case CSS_BUF_WTA_OVERRIDE: *buf = &h->wta; dims[0] = nseg; dims[1] = F; dims[2] = T; *elem = 1; break;
+        default: return CSS_ERR_INVALID_ARG;
+    }
+    return CSS_OK;
+}
+
+int css_buffer_dims(css_handle_t h, int which, int64_t dims[4], int32_t* elem_bytes) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    DevBuf* b;
+    if (!dims || !elem_bytes || buffer_info(h, which, &b, dims, elem_bytes) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    return CSS_OK;
+}
+
+int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    DevBuf* b;
+    int64_t dims[4];
+    int32_t el;
+    if (!host || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    const int64_t need = dims[0] * dims[1] * dims[2] * dims[3] * el;
+    if (nbytes != need || !b->p) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(host, b->p, (size_t)need, hipMemcpyDeviceToHost));
+    return CSS_OK;
+}
+
+int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    DevBuf* b;
+    int64_t dims[4];
+    int32_t el;
+    if (!host || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    const int64_t need = dims[0] * dims[1] * dims[2] * dims[3] * el;
+    if (nbytes != need) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = ensure(h, *b, (size_t)need)) != CSS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(b->p, host, (size_t)need, hipMemcpyHostToDevice));
+    if (which == CSS_BUF_WTA_OVERRIDE) h->have_override = true;
+    if (which == CSS_BUF_PERMS) h->perms_done = true;
+    return CSS_OK;
+}
+
+int css_buffer_devptr(css_handle_t h, int which, void** out) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    DevBuf* b;
+    int64_t dims[4];
+    int32_t el;
+    if (!out || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    *out = b->p;
+    return CSS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// Non-GEMM pieces of the Conformer mask estimator (css/css_with_conformer/nnet/conformer.py):
+// LayerNorm (+ReLU / +scalar GLU), the depthwise-conv module and relative-position attention.
+#include "kernels.hpp"
+
+namespace css {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows of D = 256*NV floats: one wave per row, NV float4 per lane, statistics by
+// wavefront shuffles.  (nn.LayerNorm, eps 1e-5: conformer.py:48,98,137,170,207)
+// MODE 0: y = LN(x)            MODE 1: y = relu(LN(x))   (embed: Linear->LN->ReLU, conformer.py:205-210)
+// MODE 2: u = LN(x); y = (pw0*u + pw1) * sigmoid(pw2*u + pw3)   (scalar Conv2d(1,2,1) + GLU,
+//         conformer.py:100,116-117)
+// ------------------------------------------------------------------------------------------------
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ pw, int rows) {
+    constexpr int D = 256 * NV;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    if (MODE == 2) { p0 = pw[0]; p1 = pw[1]; p2 = pw[2]; p3 = pw[3]; }
+    float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+        const float4 be = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+        float o[4] = {v[i].x * rstd * g.x + be.x, v[i].y * rstd * g.y + be.y, v[i].z * rstd * g.z + be.z,
+                      v[i].w * rstd * g.w + be.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (MODE == 1) o[e] = fmaxf(o[e], 0.f);
+            if (MODE == 2) o[e] = (p0 * o[e] + p1) * (1.0f / (1.0f + expf(-(p2 * o[e] + p3))));
+        }
+        yr[lane + 64 * i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int MODE>
+static void launch_ln_mode(const float* x, float* y, const float* w, const float* b, const float* pw, int rows,
+                           int D, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (D) {
+        case 256: hipLaunchKernelGGL((layernorm_kernel<1, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
+        case 512: hipLaunchKernelGGL((layernorm_kernel<2, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
+        case 768: hipLaunchKernelGGL((layernorm_kernel<3, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
+        case 1024: hipLaunchKernelGGL((layernorm_kernel<4, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
+        default: break;  // rejected at css_create (attention_dim must be a multiple of 256, <= 1024)
+    }
+}
+
+void launch_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int D, int relu,
+                      hipStream_t s) {
+    if (relu) launch_ln_mode<1>(x, y, w, b, nullptr, rows, D, s);
+    else launch_ln_mode<0>(x, y, w, b, nullptr, rows, D, s);
+}
+
+void launch_ln_glu(const float* x, float* z, const float* w, const float* b, const float* pw, int rows, int D,
+                   hipStream_t s) {
+    launch_ln_mode<2>(x, z, w, b, pw, rows, D, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise conv module, back half (conformer.py:119-126): 33-tap depthwise Conv1d over time with
+// zero padding at the SEGMENT edges (segments are independent sequences), eval-mode BatchNorm folded
+// to alpha/beta as ATen folds it, ReLU, scalar Conv2d(1,1,1), residual add into h.
+// One lane = one channel (coalesced across channels), one thread produces RUN consecutive frames
+// from RUN + TAPS - 1 loaded inputs (2x read amplification instead of 33x).
+// ------------------------------------------------------------------------------------------------
+template <int TAPS, int RUN>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ z, float* __restrict__ h,
+                                                     const float* __restrict__ wt, const float* __restrict__ dwb,
+                                                     const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                     const float* __restrict__ pw, int T, int D, int runs_per_seg) {
+    constexpr int PAD = (TAPS - 1) / 2;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= D) return;
+    const int seg = blockIdx.y / runs_per_seg, run = blockIdx.y % runs_per_seg;
+    const int t0 = run * RUN;
+    const float* zs = z + (int64_t)seg * T * D + ch;
+    float wk[TAPS];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < TAPS; ++k) wk[k] = wt[k * D + ch];
+    float acc[RUN];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < RUN; ++j) acc[j] = 0.f;
+#pragma clang loop unroll(full)
+    for (int p = 0; p < RUN + TAPS - 1; ++p) {
+        const int t = t0 + p - PAD;
+        const float v = (t >= 0 && t < T) ? zs[(int64_t)t * D] : 0.f;
+        // output j uses tap k = p - j; both indices are compile-time constants after full unrolling
+#pragma clang loop unroll(full)
+        for (int j = (p - (TAPS - 1) > 0 ? p - (TAPS - 1) : 0); j <= (p < RUN - 1 ? p : RUN - 1); ++j)
+            acc[j] = fmaf(wk[p - j], v, acc[j]);
+    }
+    const float bb = dwb[ch], al = alpha[ch], be = beta[ch], w2 = pw[4], c2 = pw[5];
+    float* hs = h + (int64_t)seg * T * D + ch;
+#pragma unroll
+    for (int j = 0; j < RUN; ++j) {
+        const int t = t0 + j;
+        if (t < T) {
+            const float y = fmaxf((acc[j] + bb) * al + be, 0.f);
+            hs[(int64_t)t * D] += w2 * y + c2;
+        }
+    }
+}
+
+void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
+                   const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s) {
+    constexpr int RUN = 31;
+    const int runs = (T + RUN - 1) / RUN;
+    const dim3 grid((D + 255) / 256, nseg * runs), block(256);
+    if (taps == 33)
+        hipLaunchKernelGGL((dwconv_kernel<33, RUN>), grid, block, 0, s, z, h, dw_wt, dw_b, bn_alpha, bn_beta, pw, T, D, runs);
+    else if (taps == 31)
+        hipLaunchKernelGGL((dwconv_kernel<31, RUN>), grid, block, 0, s, z, h, dw_wt, dw_b, bn_alpha, bn_beta, pw, T, D, runs);
+    else if (taps == 17)
+        hipLaunchKernelGGL((dwconv_kernel<17, RUN>), grid, block, 0, s, z, h, dw_wt, dw_b, bn_alpha, bn_beta, pw, T, D, runs);
+    // other tap counts are rejected at css_create
+}
+
+// ------------------------------------------------------------------------------------------------
+// Relative-position multi-head attention (conformer.py:65-92, 229-233):
+//   scores[i][j] = (q_i . k_j + q_i . pe[i - j + maxlen]) / sqrt(dk);  ctx = softmax_j(scores) v
+// One wave per (segment, head, 32-query tile); d_k = 64; T <= 32*NJT.
+// Everything is computed TRANSPOSED (keys/offsets on the MFMA row axis, queries on the column axis) so
+// that a lane owns one query column: the softmax row-reduction is 96 in-register values plus one
+// cross-half exchange, and the probabilities are already in the B-operand layout the P.V product
+// needs.  The position term uses the Toeplitz structure: R[i][r] = q_i . pe[r0 + r] over the 217
+// offsets a 32-query tile can see (never the reference's [T,T,64] gather), staged through LDS to
+// apply the per-row skew B[i][j] = R[i][i - j - r0].
+// ------------------------------------------------------------------------------------------------
+template <int NJT>
+__global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
+                                                         float* __restrict__ ctx, int T, int D, int maxlen) {
+    constexpr int DK = 64;
+    constexpr int NRT = NJT + 1;  // offset tiles: T - 1 + 32 <= 32 * (NJT + 1)
+    // LDS row stride of R (226 floats at NJT = 6): stride + 1 is odd, so the skewed reads of 32 lanes
+    // (address = c * (stride + 1) + const) hit 32 distinct banks
+    constexpr int ATT_LD = 32 * NJT + 34;
+    __shared__ float lds[32 * ATT_LD];
+    const int qt = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int ld = 3 * D;
+    const float* qb = qkv + (int64_t)seg * T * ld + head * DK;
+    const float* kb = qb + D;
+    const float* vb = qb + 2 * D;
+    const int i0 = qt * 32;
+    const int iq = min(i0 + c, T - 1);
+
+    float4 q[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) q[ch] = *reinterpret_cast<const float4*>(qb + (int64_t)iq * ld + 8 * ch + 4 * h);
+
+#define CSS_ATT_DOT(acc, rowptr)                                                          \
+    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                    \
+        const float4 a = *reinterpret_cast<const float4*>((rowptr) + 8 * ch + 4 * h);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[ch].x, acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[ch].y, acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[ch].z, acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[ch].w, acc, 0, 0, 0);           \
+    }
+
+    // ---- position term: R^T[r][i] for offsets rel = i0 - (T-1) + r, r in [0, 32*NRT) -> LDS[i][r]
+    const int rel0 = i0 - (T - 1);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        int prow = rel0 + rt * 32 + c;
+        prow = max(-maxlen, min(prow, maxlen - 1)) + maxlen;  // clamp_ of conformer.py:24
+        f32x16 acc = {0};
+        CSS_ATT_DOT(acc, pe + (int64_t)prow * DK)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr < ATT_LD) lds[c * ATT_LD + rr] = acc[r];
+        }
+    }
+    __syncthreads();
+
+    // ---- content term S^T[j][i] = k_j . q_i, plus skewed position term, scale, key mask
+    f32x16 S[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int jrow = min(jt * 32 + c, T - 1);
+        f32x16 acc = {0};
+        CSS_ATT_DOT(acc, kb + (int64_t)jrow * ld)
+        S[jt] = acc;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int rr = max(c + (T - 1) - j, 0);  // (i - j) - rel0 with i = i0 + c
+            float sc = (S[jt][r] + lds[c * ATT_LD + rr]) * 0.125f;  // 1/sqrt(64)
+            sc = j < T ? sc : -INFINITY;
+            S[jt][r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(S[jt][r] - mx);
+            S[jt][r] = p;
+            sum += p;
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    __syncthreads();  // all skewed reads done before the LDS region is reused for the output tile
+
+    // ---- O^T[d][i] = sum_j v[j][d] * P[i][j]; the MFMA k index of half h at step (jt, r) is the key
+    //      row this lane's S[jt][r] belongs to, so P feeds the B operand straight from registers.
+    constexpr int OLD = 65;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16 o = {0};
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = min(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, T - 1);
+                const float a = vb[(int64_t)j * ld + dt * 32 + c];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[jt][r], o, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            lds[c * OLD + d] = o[r] * inv;
+        }
+    }
+    __syncthreads();
+    float* ob = ctx + ((int64_t)seg * T + i0) * D + head * DK;
+    for (int il = 0; il < 32 && i0 + il < T; ++il) ob[(int64_t)il * D + lane] = lds[il * OLD + lane];
+}
+
+void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
+                             int maxlen, hipStream_t s) {
+    const int qtiles = (T + 31) / 32;
+    const dim3 grid(qtiles, H, nseg), block(64);
+    if (qtiles <= 4) hipLaunchKernelGGL((relpos_attn_kernel<4>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
+    else if (qtiles <= 6) hipLaunchKernelGGL((relpos_attn_kernel<6>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
+    else if (qtiles <= 8) hipLaunchKernelGGL((relpos_attn_kernel<8>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
+    // longer segments are rejected at css_begin (segment_frames <= 256)
+}
+
+}  // namespace css

@@ -1,0 +1,202 @@
+// Front/back end of the CSS path outside the GEMMs: PCM layout, network input features, and the
+// overlap-add that finishes the inverse transform.
+#include "kernels.hpp"
+
+namespace css {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// [n][C] sample-major PCM (css/helpers.py:40 load_audio layout) -> channel-major [C][n_pad], so that
+// every later read of the frame buffer is a contiguous run of one channel
+// (conformer_wrapper.py:119 does the same moveaxis on the host).
+// ------------------------------------------------------------------------------------------------
+__global__ void deinterleave_kernel(const float* __restrict__ pcm, float* __restrict__ out, int64_t n, int C,
+                                    int64_t n_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    for (int c = 0; c < C; ++c) out[(int64_t)c * n_pad + i] = i < n ? pcm[i * C + c] : 0.f;
+}
+
+void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, hipStream_t s) {
+    const int64_t blocks = (n_pad + 255) / 256;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Network input features of one segment (feature.py:478-508 compute_spectra, 198-249 IPDFeature,
+// then the global affine of conformer.py:298-299), written straight into the row-major
+// [token][K_pad] operand of the embed GEMM.
+//   m == 0 : mean/variance-normalised clamped magnitude of mic 0 (unbiased std over the T frames)
+//   m >= 1 : inter-channel phase difference of pair (m, 0), version-1 mean normalisation, raw angle
+// Zero-padded frames of the last segment take part in the statistics with X = 0 (css.py:185-190).
+// Block = (32-bin tile, m, segment); a wave owns 8 bins, lanes run over time so the plane reads are
+// contiguous; statistics by wavefront shuffles; the [bin][t] tile is transposed through LDS so the
+// stores are 128-byte runs along the feature axis.
+//
+// Phase of an exactly real negative bin (DC / Nyquist have Im == +0 by construction of the transform):
+// the reference reaches the features through polar() -> angle() (conformer_wrapper.py:124,94), which
+// maps such a bin to the float32 value just inside -pi, and the side of the atan2 branch cut of the
+// IPD feature depends on that (DESIGN.md "Numerical hazards").  PHASE_NEG_REAL is that value.
+// ------------------------------------------------------------------------------------------------
+constexpr int FEAT_TMAX = 256;
+constexpr int FEAT_LD = FEAT_TMAX + 1;
+#define CSS_PHASE_NEG_REAL (-3.14159250259399414f) /* 0xC0490FDA */
+#define CSS_EPS32 1.1920928955078125e-07f
+
+__device__ __forceinline__ float phase_of(float re, float im) {
+    return (im == 0.f && re < 0.f) ? CSS_PHASE_NEG_REAL : atan2f(im, re);
+}
+
+__global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, int64_t T_ld, int64_t stft_frames,
+                                                       int F, float* __restrict__ feat, int Kp,
+                                                       const float* __restrict__ in_bias,
+                                                       const float* __restrict__ in_scale, int64_t seg_lo, int T,
+                                                       int hop) {
+    __shared__ float tile[32 * FEAT_LD];
+    const int f0 = blockIdx.x * 32, m = blockIdx.y, segl = blockIdx.z;
+    const int64_t st = (seg_lo + segl) * (int64_t)hop;
+    const int64_t tv64 = stft_frames - st;
+    const int tv = (int)(tv64 < 0 ? 0 : (tv64 > T ? T : tv64));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float invT = 1.0f / (float)T;
+    constexpr int NT = FEAT_TMAX / 64;
+    for (int b = 0; b < 8; ++b) {
+        const int fl = wave * 8 + b, f = f0 + fl;
+        if (f >= F) break;
+        const float* re0 = X + (int64_t)(f)*T_ld + st;            // mic 0, Re row f
+        const float* im0 = X + (int64_t)(F + f) * T_ld + st;      // mic 0, Im row f
+        const float* rem = re0 + (int64_t)m * 2 * F * T_ld;       // mic m
+        const float* imm = im0 + (int64_t)m * 2 * F * T_ld;
+        float a[NT], bq[NT];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = lane + 64 * i;
+            a[i] = 0.f; bq[i] = 0.f;
+            if (t < T) {
+                const bool ok = t < tv;
+                const float r0 = ok ? re0[t] : 0.f, i0 = ok ? im0[t] : 0.f;
+                if (m == 0) {
+                    a[i] = fmaxf(sqrtf(r0 * r0 + i0 * i0), CSS_EPS32);
+                    s0 += a[i];
+                } else {
+                    const float rm = ok ? rem[t] : 0.f, imv = ok ? imm[t] : 0.f;
+                    const float d = phase_of(rm, imv) - phase_of(r0, i0);
+                    a[i] = cosf(d);
+                    bq[i] = sinf(d);
+                    s0 += a[i];
+                    s1 += bq[i];
+                }
+            }
+        }
+        s0 = wave_sum_f(s0);
+        s1 = wave_sum_f(s1);
+        if (m == 0) {
+            const float mean = s0 * invT;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = lane + 64 * i;
+                if (t < T) { a[i] -= mean; q += a[i] * a[i]; }
+            }
+            const float sd = sqrtf(wave_sum_f(q) / (float)(T - 1));
+            const float den = sd + CSS_EPS32;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = lane + 64 * i;
+                if (t < T) tile[fl * FEAT_LD + t] = a[i] / den;
+            }
+        } else {
+            const float yrm = s0 * invT, yim = s1 * invT;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = lane + 64 * i;
+                if (t < T) tile[fl * FEAT_LD + t] = atan2f(bq[i] - yim, a[i] - yrm);
+            }
+        }
+    }
+    __syncthreads();
+    // transposed store: lanes 0..31 -> consecutive feature columns (128 B), two frames per wave-instruction
+    const int fl = lane & 31, f = f0 + fl;
+    if (f < F) {
+        const int col = m * F + f;
+        const float bi = in_bias[col], sc = in_scale[col];
+        float* out = feat + (int64_t)segl * T * Kp + col;
+        for (int t = wave * 2 + (lane >> 5); t < T; t += 8) out[(int64_t)t * Kp] = (tile[fl * FEAT_LD + t] + bi) * sc;
+    }
+}
+
+void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
+                     const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
+                     hipStream_t s) {
+    const dim3 grid((F + 31) / 32, C, nseg), block(256);
+    hipLaunchKernelGGL(features_kernel, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
+                       seg_lo, T, hop);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Overlap-add that completes conv_transpose1d (feature.py:162) after the synthesis GEMM produced
+// G[b][q][0..2*hop): output sample hop*q + r receives frame q (first half) and frame q-1 (second half).
+// Gather form: one thread per output sample, no atomics, bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+__global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ wav, int64_t T_frames, int hop,
+                                int64_t q_lo, int64_t q_hi, int64_t n_out) {
+    const int b = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t q = q_lo + idx / hop;
+    const int r = (int)(idx % hop);
+    if (q >= q_hi) return;
+    const int64_t n = q * hop + r;
+    if (n >= n_out) return;
+    const float* g = G + (int64_t)b * T_frames * 2 * hop;
+    float v = 0.f;
+    if (q >= 1) v = g[(q - 1) * 2 * hop + hop + r];
+    if (q < T_frames) v += g[q * 2 * hop + r];
+    wav[(int64_t)b * n_out + n] = v;
+}
+
+void launch_wave_ola(const float* G, float* wav, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+                     int64_t n_out, hipStream_t s) {
+    const int64_t total = (q_hi - q_lo) * hop;
+    if (total <= 0) return;
+    const dim3 grid((unsigned)((total + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, wav, T_frames, hop, q_lo, q_hi, n_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// [B][rows][T] planes -> [B][T][KIp] rows (separator-protocol istft entry point only; the fused path
+// writes the row layout directly from the stitcher).  32x32 LDS transpose.
+// ------------------------------------------------------------------------------------------------
+__global__ void planes_to_rows_kernel(const float* __restrict__ planes, float* __restrict__ rows, int F2, int64_t T,
+                                      int KIp) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+    const float* src = planes + (int64_t)b * F2 * T;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k;
+        const int64_t t = t0 + tx;
+        tile[k][tx] = (r < F2 && t < T) ? src[(int64_t)r * T + t] : 0.f;
+    }
+    __syncthreads();
+    float* dst = rows + (int64_t)b * T * KIp;
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t t = t0 + k;
+        const int r = r0 + tx;
+        if (t < T && r < KIp) dst[t * KIp + r] = tile[tx][k];
+    }
+}
+
+void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s) {
+    const dim3 grid((unsigned)((T + 31) / 32), (KIp + 31) / 32, B), block(256);
+    hipLaunchKernelGGL(planes_to_rows_kernel, grid, block, 0, s, planes, rows, F2, T, KIp);
+}
+
+}  // namespace css

@@ -1,0 +1,151 @@
+// fp32 MFMA GEMM for gfx950:  C[m][n] = epilogue( sum_k A[m][k] * B[n][k] ).
+//
+// Used for every dense product on the CSS path: the Hann-DFT analysis transform (feature.py:116
+// conv1d, restated as DFT-matrix x overlapping frames), the Conformer's embed / FFN / QKV / output /
+// mask-head Linear layers (conformer.py:49-53,139-142,206,285) and the sqrt-Hann synthesis transform
+// (feature.py:162 conv_transpose1d).  Exact float32 (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf
+// chain), which the 1e-4 waveform parity and the winner-take-all mask decisions need.
+//
+// Shape: 128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32, K slab 32,
+// register-staged double-buffered LDS.  LDS rows are padded to 36 floats so that ds_read_b128 of 16
+// consecutive rows hits 16 distinct 16-byte slots (9*row mod 16 is a bijection).
+//
+// K permutation: within each group of 8 consecutive k the two lane halves of the MFMA take k = 4h+s
+// (h = lane>>5, s = MFMA step) instead of 2s+h, so each lane fetches its four A (and B) operands with
+// one 16-byte LDS read.  A and B use the same permutation, so the dot product is unchanged.
+#include "kernels.hpp"
+
+namespace css {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+    // ---- XCD-aware tile mapping: consecutive tiles (which share an A row panel) go to one XCD/L2 ----
+    const int n_tiles = tiles_m * tiles_n * g.batch;
+    const int L = blockIdx.x;
+    const int q = n_tiles >> 3, rem = n_tiles & 7, xcd = L & 7;
+    const int tile = xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
+    const int per_batch = tiles_m * tiles_n;
+    const int bz = tile / per_batch;
+    const int t2 = tile - bz * per_batch;
+    const int tn = t2 % tiles_n, tm = t2 / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const float* __restrict__ A = g.A + (int64_t)bz * g.strideA;
+    const float* __restrict__ B = g.B + (int64_t)bz * g.strideB;
+    float* __restrict__ C = g.C + (int64_t)bz * g.strideC;
+
+    const int tid = threadIdx.x;
+    const int lr = tid >> 3;          // 0..31 : row within a 32-row group
+    const int lc = (tid & 7) << 2;    // 0..28 : float offset within the K slab
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c = lane & 31, h = lane >> 5;
+
+    // rows past M / N read the last valid row (always in bounds) and are zeroed in registers
+    const float* a_base = A + lc;
+    const float* b_base = B + lc;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int M = g.M, N = g.N;
+    const int64_t lda = g.lda, ldb = g.ldb;
+#define CSS_GLOAD_ONE(dst, base, ld, row, lim, k0)                                                    \
+    {                                                                                                 \
+        const int r_ = (row);                                                                         \
+        const int rc_ = r_ < (lim) ? r_ : (lim) - 1;                                                  \
+        dst = *reinterpret_cast<const float4*>((base) + (int64_t)rc_ * (ld) + (k0));                  \
+        if (r_ >= (lim)) dst = zero4;                                                                 \
+    }
+#define CSS_GLOAD(k0)                                              \
+    CSS_GLOAD_ONE(ra0, a_base, lda, m0 + lr, M, k0)                \
+    CSS_GLOAD_ONE(ra1, a_base, lda, m0 + lr + 32, M, k0)           \
+    CSS_GLOAD_ONE(ra2, a_base, lda, m0 + lr + 64, M, k0)           \
+    CSS_GLOAD_ONE(ra3, a_base, lda, m0 + lr + 96, M, k0)           \
+    CSS_GLOAD_ONE(rb0, b_base, ldb, n0 + lr, N, k0)                \
+    CSS_GLOAD_ONE(rb1, b_base, ldb, n0 + lr + 32, N, k0)           \
+    CSS_GLOAD_ONE(rb2, b_base, ldb, n0 + lr + 64, N, k0)           \
+    CSS_GLOAD_ONE(rb3, b_base, ldb, n0 + lr + 96, N, k0)
+#define CSS_LSTORE(buf)                                                       \
+    {                                                                         \
+        float* as_ = lds + (buf) * (BM + BN) * LDS_LD + lr * LDS_LD + lc;     \
+        float* bs_ = as_ + BM * LDS_LD;                                       \
+        *reinterpret_cast<float4*>(as_) = ra0;                                \
+        *reinterpret_cast<float4*>(as_ + 32 * LDS_LD) = ra1;                  \
+        *reinterpret_cast<float4*>(as_ + 64 * LDS_LD) = ra2;                  \
+        *reinterpret_cast<float4*>(as_ + 96 * LDS_LD) = ra3;                  \
+        *reinterpret_cast<float4*>(bs_) = rb0;                                \
+        *reinterpret_cast<float4*>(bs_ + 32 * LDS_LD) = rb1;                  \
+        *reinterpret_cast<float4*>(bs_ + 64 * LDS_LD) = rb2;                  \
+        *reinterpret_cast<float4*>(bs_ + 96 * LDS_LD) = rb3;                  \
+    }
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nk = g.K / BK;
+    CSS_GLOAD(0)
+    CSS_LSTORE(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { CSS_GLOAD((kt + 1) * BK) }
+        const float* as = lds + buf * (BM + BN) * LDS_LD + (wm * 64 + c) * LDS_LD + 4 * h;
+        const float* bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * 64 + c) * LDS_LD + 4 * h;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const float4 a0 = *reinterpret_cast<const float4*>(as + ch * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_LD + ch * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(bs + ch * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * LDS_LD + ch * 8);
+#define CSS_MFMA4(e)                                                            \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc00, 0, 0, 0);   \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc01, 0, 0, 0);   \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc10, 0, 0, 0);   \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc11, 0, 0, 0);
+            CSS_MFMA4(x) CSS_MFMA4(y) CSS_MFMA4(z) CSS_MFMA4(w)
+        }
+        if (kt + 1 < nk) CSS_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, activation, scaled residual; 128-byte row segments per half wave ----
+    const float* bias = g.bias;
+    const float* res = g.residual;
+    const int act = g.act, bias_m = g.bias_along_m;
+    const int64_t ldc = g.ldc, ldr = g.ldr;
+    const float alpha = g.alpha;
+#define CSS_EMIT(acc, tm2, tn2)                                                              \
+    {                                                                                        \
+        const int n = n0 + wn * 64 + (tn2) * 32 + c;                                         \
+        if (n < N) {                                                                         \
+            const float bn = (bias && !bias_m) ? bias[n] : 0.f;                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                 \
+                const int m = m0 + wm * 64 + (tm2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;    \
+                if (m < M) {                                                                 \
+                    float v = acc[r] + bn;                                                   \
+                    if (bias && bias_m) v += bias[m];                                        \
+                    if (act == ACT_RELU) v = fmaxf(v, 0.f);                                  \
+                    else if (act == ACT_SIGMOID) v = sigmoidf_(v);                           \
+                    if (res) v = res[(int64_t)m * ldr + n] + alpha * v;                      \
+                    C[(int64_t)m * ldc + n] = v;                                             \
+                }                                                                            \
+            }                                                                                \
+        }                                                                                    \
+    }
+    CSS_EMIT(acc00, 0, 0)
+    CSS_EMIT(acc01, 0, 1)
+    CSS_EMIT(acc10, 1, 0)
+    CSS_EMIT(acc11, 1, 1)
+}
+
+void launch_gemm(const GemmArgs& g, hipStream_t s) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int blocks = tiles_m * tiles_n * g.batch;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+}
+
+}  // namespace css

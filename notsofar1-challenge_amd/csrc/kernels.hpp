@@ -1,0 +1,106 @@
+// Internal launch interface of the gfx950 kernels (one declaration per kernel family).
+// Everything here is device-pointer based and asynchronous on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace css {
+
+// ------------------------------------------------------------------------------------------------
+// gemm.hip -- fp32 MFMA GEMM  C[m][n] = epilogue( sum_k A[m*lda + k] * B[n*ldb + k] )
+// Both operands are K-contiguous ("NT"): A is an activation / DFT matrix, B a weight [out][in] or a
+// strided view of frames.  K must be a multiple of 32; M, N arbitrary.
+// ------------------------------------------------------------------------------------------------
+enum GemmAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+struct GemmArgs {
+    const float* A; int64_t lda; int64_t strideA;   // batch stride (0 = shared)
+    const float* B; int64_t ldb; int64_t strideB;
+    float* C; int64_t ldc; int64_t strideC;
+    int M, N, K, batch;
+    const float* bias;      // nullptr or [N] (bias_along_m == 0) / [M] (bias_along_m == 1)
+    int bias_along_m;
+    int act;                // GemmAct
+    const float* residual;  // nullptr or [M][ldr]: C = residual + alpha * (acc + bias)
+    int64_t ldr;
+    float alpha;            // only with residual
+};
+void launch_gemm(const GemmArgs& g, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// encoder.hip -- the non-GEMM pieces of the Conformer
+// ------------------------------------------------------------------------------------------------
+// y = LN(x) * w + b over rows of length D (D % 256 == 0, D <= 1024); optional ReLU.
+void launch_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int D, int relu,
+                      hipStream_t s);
+// conv-module front half: u = LN(x); z = (pw[0]*u + pw[1]) * sigmoid(pw[2]*u + pw[3])
+void launch_ln_glu(const float* x, float* z, const float* w, const float* b, const float* pw, int rows, int D,
+                   hipStream_t s);
+// conv-module back half: depthwise conv over time inside each segment (zero padded), eval-BatchNorm,
+// ReLU, scalar pointwise conv, residual:  h += pw[4] * relu((conv(z) + dw_b) * alpha + beta) + pw[5]
+void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
+                   const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s);
+// relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D]
+void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
+                             int maxlen, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// frontend.hip -- PCM layout, features, inverse-transform overlap-add
+// ------------------------------------------------------------------------------------------------
+void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, hipStream_t s);
+// features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded)
+void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
+                     const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
+                     hipStream_t s);
+// wav[b][hop*q + r] = G[b][q][r] + G[b][q-1][hop + r]   (frame_len == 2*hop)
+void launch_wave_ola(const float* G, float* wav, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+                     int64_t n_out, hipStream_t s);
+// [B][2F][T] planes -> [B][T][KIp] rows for the inverse GEMM
+void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// mvdr.hip -- WTA masks, spatial covariance, MVDR solve, beamform + mask
+// ------------------------------------------------------------------------------------------------
+struct MvdrArgs {
+    const float* X; int64_t T_ld; int64_t stft_frames; int C; int F;
+    const float* masks; int64_t mask_ld;   // [(S+1)F][mask_ld]; column = segment*T + t
+    int S; int T; int hop;
+    int64_t seg_lo; int nseg;
+    const uint8_t* wta_override;           // nullptr or [segments][F][T]
+    double* scm;                           // [segments][S+1][F][49]
+    double* bfw;                           // [segments][S][F][C][2]
+    float* sep;                            // [segments][S][F][T][2]
+    float mask_floor;
+    int use_mvdr;
+};
+void launch_scm(const MvdrArgs& a, hipStream_t s);
+void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s);
+void launch_beamform(const MvdrArgs& a, hipStream_t s);
+// optional power normalisation (css.py:233-247): scales sep of each segment in place
+void launch_segment_power_norm(const MvdrArgs& a, double* scratch, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// stitch.hip -- PIT costs, permutation scan, weighted overlap-add, activity gate
+// ------------------------------------------------------------------------------------------------
+struct StitchArgs {
+    const float* masks; int64_t mask_ld;
+    const float* sep;
+    int S; int F; int T; int hop;
+    int64_t num_segments; int64_t T_long;
+    const float* w_first; const float* w_mid; const float* w_last;  // device [T]
+    const int32_t* perms;      // [segments][S]
+    float* mask_st;            // [S][F][T_long]
+    float* activity;           // [S][T_long]
+    uint8_t* act_b; uint8_t* act_tmp; uint8_t* act_final;  // [S][T_long]
+    float activity_th; int dilation; int erosion;
+    float* Y; int KIp;         // [S][T_long][KIp]
+};
+void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* costs,
+                      hipStream_t s);
+void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s);
+void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms);
+void launch_ola_masks(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s);
+void launch_morphology(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s);
+void launch_ola_stft(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s);
+
+}  // namespace css

@@ -1,0 +1,324 @@
+// Mask-based MVDR beamformer of one segment (css/css_with_conformer/utils/mvdr_util.py):
+//   make_wta (:50) -> get_mask_scm (:58) -> calc_bfcoeffs (:69) -> get_bf (:78), then the floored mask
+//   multiplication of css/css.py:222-227.
+// The 7x7 spatial covariance matrices are accumulated and solved in float64 (the reference does
+// this in complex64, which leaves it ~2e-5 from the exact answer; float64 keeps our
+// own distance from the exact answer negligible, so the distance to the reference is the reference's).
+#include "kernels.hpp"
+
+namespace css {
+
+constexpr int NC = 7;        // microphones of the NOTSOFAR array (utils/mic_array_model.py:4)
+constexpr int NPACK = 49;    // Hermitian 7x7: 7 real diagonal + 21 complex upper-triangle entries
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ int valid_frames(int64_t stft_frames, int64_t seg, int hop, int T) {
+    const int64_t tv = stft_frames - seg * (int64_t)hop;
+    return (int)(tv < 0 ? 0 : (tv > T ? T : tv));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Winner-take-all masks + masked spatial covariance.
+//   w_k[f,t] = mask_k[f,t] if it is the maximum over the S speaker masks and the summed noise mask,
+//              else 1e-10                                            (mvdr_util.py:50-55)
+//   Phi_k[f] = sum_t w_k[f,t] x[f,t] x[f,t]^H  (+ 1e-15 I)            (mvdr_util.py:61-65)
+// Block = (bin f, segment); wave k accumulates mask k: lanes run over time (contiguous reads of the
+// seven Re/Im plane rows), 49 float64 accumulators per lane, wavefront-shuffle reduction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
+    const int f = blockIdx.x, segl = blockIdx.y;
+    const int64_t seg = a.seg_lo + segl;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nm = a.S + 1;
+    if (k >= nm) return;
+    const int F = a.F, T = a.T;
+    const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
+    const int64_t st = seg * (int64_t)a.hop;
+    double acc[NPACK];
+#pragma unroll
+    for (int i = 0; i < NPACK; ++i) acc[i] = 0.0;
+    const float* mrow = a.masks + (int64_t)f * a.mask_ld + seg * (int64_t)T;
+    const int64_t mstride = (int64_t)F * a.mask_ld;
+    const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
+    for (int t = lane; t < tv; t += 64) {
+        // masks of this TF point: S speakers, then the noise mask (sum over noise outputs; one here)
+        float mk = 0.f, mx = -INFINITY;
+        for (int j = 0; j < nm; ++j) {
+            const float v = mrow[j * mstride + t];
+            mx = fmaxf(mx, v);
+            if (j == k) mk = v;
+        }
+        const bool win = ov ? (ov[t] == k) : (mk == mx);  // ties keep every tied mask, like mask == mask_max
+        const double w = win ? (double)mk : 1e-10;
+        float xr[NC], xi[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            xr[c] = a.X[((int64_t)c * 2 * F + f) * a.T_ld + st + t];
+            xi[c] = a.X[((int64_t)c * 2 * F + F + f) * a.T_ld + st + t];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += w * ((double)xr[c] * xr[c] + (double)xi[c] * xi[c]);
+        int p = NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int d = c + 1; d < NC; ++d) {
+                acc[p] += w * ((double)xr[c] * xr[d] + (double)xi[c] * xi[d]);      // Re x_c conj(x_d)
+                acc[p + 1] += w * ((double)xi[c] * xr[d] - (double)xr[c] * xi[d]);  // Im
+                p += 2;
+            }
+        }
+    }
+    double* out = a.scm + ((seg * nm + k) * (int64_t)F + f) * NPACK;
+#pragma unroll
+    for (int i = 0; i < NPACK; ++i) {
+        double v = wave_sum_d(acc[i]);
+        if (i < NC) v += 1e-15;  // Ri += 1e-15 * I   (mvdr_util.py:63-65)
+        if (lane == 0) out[i] = v;
+    }
+}
+
+void launch_scm(const MvdrArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(scm_kernel, dim3(a.F, a.nseg), dim3(64 * (a.S + 1)), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Souden MVDR (mvdr_util.py:69-75): for speaker i, Phi_n = Phi_noise + sum_{j != i} Phi_j,
+//   Z = solve(Phi_n, Phi_i);  W = Z[:, 0] / (trace(Z) [+ 1e-15 at bin 0 only])
+// One thread per (segment, speaker, bin): complex LU with partial pivoting (the algorithm behind
+// numpy.linalg.solve / LAPACK gesv; pivot = max |re|+|im| like i?amax) held entirely in registers --
+// row exchanges are predicated swaps so every index is a compile-time constant -- then the seven
+// right-hand-side columns are pushed through one at a time (only column 0 and the trace are needed).
+// ------------------------------------------------------------------------------------------------
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx cinv(cplx a) {
+    const double d = a.re * a.re + a.im * a.im;
+    return {a.re / d, -a.im / d};
+}
+__device__ __forceinline__ void cswap_if(bool p, cplx& a, cplx& b) {
+    const cplx ta = a, tb = b;
+    a.re = p ? tb.re : ta.re; a.im = p ? tb.im : ta.im;
+    b.re = p ? ta.re : tb.re; b.im = p ? ta.im : tb.im;
+}
+// element (r, c) of a packed Hermitian matrix
+__device__ __forceinline__ cplx herm_at(const double* __restrict__ m, int r, int c) {
+    if (r == c) return {m[r], 0.0};
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int p = NC + 2 * (lo * NC - lo * (lo + 1) / 2 + (hi - lo - 1));
+    return {m[p], r < c ? m[p + 1] : -m[p + 1]};
+}
+
+__global__ __launch_bounds__(64) void mvdr_solve_kernel(MvdrArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int F = a.F, S = a.S, nm = S + 1;
+    const int64_t total = (int64_t)a.nseg * S * F;
+    if (gid >= total) return;
+    const int f = (int)(gid % F);
+    const int spk = (int)((gid / F) % S);
+    const int64_t seg = a.seg_lo + gid / ((int64_t)F * S);
+    const double* base = a.scm + seg * nm * (int64_t)F * NPACK + (int64_t)f * NPACK;
+    const int64_t kstride = (int64_t)F * NPACK;
+
+    // Phi_n = noise + other speakers, expanded to a full matrix
+    cplx A[NC][NC];
+#pragma unroll
+    for (int r = 0; r < NC; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) A[r][c] = {0.0, 0.0};
+    for (int j = 0; j < nm; ++j) {
+        if (j == spk) continue;
+        const double* m = base + j * kstride;
+#pragma unroll
+        for (int r = 0; r < NC; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const cplx v = herm_at(m, r, c);
+                A[r][c].re += v.re;
+                A[r][c].im += v.im;
+            }
+    }
+    // LU factorisation, partial pivoting
+    int piv[NC];
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+        int best = p;
+        double bv = fabs(A[p][p].re) + fabs(A[p][p].im);
+#pragma unroll
+        for (int r = p + 1; r < NC; ++r) {
+            const double v = fabs(A[r][p].re) + fabs(A[r][p].im);
+            if (v > bv) { bv = v; best = r; }
+        }
+        piv[p] = best;
+#pragma unroll
+        for (int r = p + 1; r < NC; ++r) {
+            const bool sw = (best == r);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cswap_if(sw, A[p][c], A[r][c]);
+        }
+        const cplx ip = cinv(A[p][p]);
+#pragma unroll
+        for (int r = p + 1; r < NC; ++r) {
+            const cplx l = cmul(A[r][p], ip);
+            A[r][p] = l;
+#pragma unroll
+            for (int c = p + 1; c < NC; ++c) A[r][c] = csub(A[r][c], cmul(l, A[p][c]));
+        }
+    }
+    // right-hand sides: the columns of Phi_spk
+    const double* ms = base + spk * kstride;
+    cplx w0[NC];
+    cplx tr = {0.0, 0.0};
+#pragma unroll
+    for (int col = 0; col < NC; ++col) {
+        cplx z[NC];
+#pragma unroll
+        for (int r = 0; r < NC; ++r) z[r] = herm_at(ms, r, col);
+#pragma unroll
+        for (int p = 0; p < NC; ++p)
+#pragma unroll
+            for (int r = p + 1; r < NC; ++r) cswap_if(piv[p] == r, z[p], z[r]);
+#pragma unroll
+        for (int r = 1; r < NC; ++r)
+#pragma unroll
+            for (int c = 0; c < r; ++c) z[r] = csub(z[r], cmul(A[r][c], z[c]));
+#pragma unroll
+        for (int r = NC - 1; r >= 0; --r) {
+#pragma unroll
+            for (int c = r + 1; c < NC; ++c) z[r] = csub(z[r], cmul(A[r][c], z[c]));
+            z[r] = cmul(z[r], cinv(A[r][r]));
+        }
+        tr.re += z[col].re;
+        tr.im += z[col].im;
+        if (col == 0) {
+#pragma unroll
+            for (int r = 0; r < NC; ++r) w0[r] = z[r];
+        }
+    }
+    if (f == 0) tr.re += 1e-15;  // den[0] += 1e-15 touches frequency bin 0 only (mvdr_util.py:73)
+    const cplx it = cinv(tr);
+    double* out = a.bfw + ((seg * S + spk) * (int64_t)F + f) * NC * 2;
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+        const cplx w = cmul(w0[r], it);
+        out[2 * r] = w.re;
+        out[2 * r + 1] = w.im;
+    }
+}
+
+void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s) {
+    const int64_t total = (int64_t)a.nseg * a.S * a.F;
+    hipLaunchKernelGGL(mvdr_solve_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_bf (mvdr_util.py:78-80): y[f,t] = sum_c conj(W[f,c]) x[c,f,t], then the floored mask
+// multiplication sep = y * clip(mask, min=floor) (css.py:226-227).  Without MVDR (single channel or
+// mc_mvdr = False) the masked signal is the reference microphone 0 (css.py:204,220).
+// Block = (bin, segment), threads run over time.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beamform_kernel(MvdrArgs a) {
+    const int f = blockIdx.x, segl = blockIdx.y;
+    const int64_t seg = a.seg_lo + segl;
+    const int F = a.F, T = a.T, S = a.S;
+    const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
+    const int64_t st = seg * (int64_t)a.hop;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const bool ok = t < tv;
+        float xr[NC], xi[NC];
+        const int nc = a.use_mvdr ? NC : 1;
+        for (int c = 0; c < nc; ++c) {
+            xr[c] = ok ? a.X[((int64_t)c * 2 * F + f) * a.T_ld + st + t] : 0.f;
+            xi[c] = ok ? a.X[((int64_t)c * 2 * F + F + f) * a.T_ld + st + t] : 0.f;
+        }
+        for (int k = 0; k < S; ++k) {
+            float yr, yi;
+            if (a.use_mvdr) {
+                const double* w = a.bfw + ((seg * S + k) * (int64_t)F + f) * NC * 2;
+                double sr = 0.0, si = 0.0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double wr = w[2 * c], wi = w[2 * c + 1];
+                    sr += wr * xr[c] + wi * xi[c];
+                    si += wr * xi[c] - wi * xr[c];
+                }
+                yr = (float)sr;
+                yi = (float)si;
+            } else {
+                yr = xr[0];
+                yi = xi[0];
+            }
+            const float m = fmaxf(a.masks[((int64_t)k * F + f) * a.mask_ld + seg * (int64_t)T + t], a.mask_floor);
+            float2* o = reinterpret_cast<float2*>(a.sep) + ((seg * S + k) * (int64_t)F + f) * T + t;
+            *o = make_float2(yr * m, yi * m);
+        }
+    }
+}
+
+void launch_beamform(const MvdrArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(beamform_kernel, dim3(a.F, a.nseg), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Optional power normalisation (css.py:233-247): scale the separated segment so that the energy of
+// the sum of its streams matches the reference microphone over the valid frames.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_energy_kernel(MvdrArgs a, double* __restrict__ scratch) {
+    __shared__ double red[2][4];
+    const int segl = blockIdx.x;
+    const int64_t seg = a.seg_lo + segl;
+    const int F = a.F, T = a.T, S = a.S;
+    const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
+    const int64_t st = seg * (int64_t)a.hop;
+    double em = 0.0, es = 0.0;
+    for (int idx = threadIdx.x; idx < F * tv; idx += 256) {
+        const int f = idx / tv, t = idx % tv;
+        const float xr = a.X[(int64_t)f * a.T_ld + st + t], xi = a.X[(int64_t)(F + f) * a.T_ld + st + t];
+        em += (double)xr * xr + (double)xi * xi;
+        float sr = 0.f, si = 0.f;
+        for (int k = 0; k < S; ++k) {
+            const float2 v = reinterpret_cast<const float2*>(a.sep)[((seg * S + k) * (int64_t)F + f) * T + t];
+            sr += v.x;
+            si += v.y;
+        }
+        es += (double)sr * sr + (double)si * si;
+    }
+    em = wave_sum_d(em);
+    es = wave_sum_d(es);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = em; red[1][wave] = es; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double s = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        scratch[segl] = sqrt(m) / sqrt(s);  // the 1/(F*tv) of both means cancels
+    }
+}
+
+__global__ void segment_scale_kernel(MvdrArgs a, const double* __restrict__ scratch) {
+    const int segl = blockIdx.y;
+    const int64_t seg = a.seg_lo + segl;
+    const int64_t n = (int64_t)a.S * a.F * a.T;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = (float)scratch[segl];
+    float2* p = reinterpret_cast<float2*>(a.sep) + seg * n + i;
+    float2 v = *p;
+    v.x *= g;
+    v.y *= g;
+    *p = v;
+}
+
+void launch_segment_power_norm(const MvdrArgs& a, double* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(segment_energy_kernel, dim3(a.nseg), dim3(256), 0, s, a, scratch);
+    const int64_t n = (int64_t)a.S * a.F * a.T;
+    hipLaunchKernelGGL(segment_scale_kernel, dim3((unsigned)((n + 255) / 256), a.nseg), dim3(256), 0, s, a, scratch);
+}
+
+}  // namespace css

@@ -1,0 +1,294 @@
+// Stitching of the separated segments (css/css.py:254-312): permutation alignment of adjacent
+// segments (training/losses.py PitWrapper), weighted overlap-add, activity gating with
+// dilate/erode (utils/numpy_utils.py), and the hand-off layout for the inverse transform.
+//
+// All kernels are in gather form: an output frame t receives at most the two segments
+// i = floor(t/hop) - 1 and floor(t/hop) (bit-exact segment indexing st = i * hop, css.py:183,287), so
+// nothing is accumulated with atomics and a frame range can be produced by any rank that holds the
+// segments covering it.
+#include "kernels.hpp"
+
+namespace css {
+
+__device__ __forceinline__ double wave_sum_dd(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Raw PIT cost of boundary b (segments b | b+1):  cost[a][c] = mean_{F, overlap} loss(L_a - R_c)
+// with L = last `overlap` frames of segment b, R = first `overlap` frames of segment b+1, both in
+// their RAW channel order (losses.py:50-71; css.py:267-276).  The cost of an already-permuted left
+// segment is a row permutation of this matrix, so all boundaries are computed in parallel and the
+// sequential dependence of css.py:266-285 is confined to the tiny scan below.
+//   input 0: masks   input 1: |separated spectrum|     loss 0: L1   loss 1: squared error
+// ------------------------------------------------------------------------------------------------
+constexpr int SMAX = 4;
+
+__global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, int input, int64_t b_lo,
+                                                       double* __restrict__ costs) {
+    __shared__ double red[4][SMAX * SMAX];
+    const int64_t b = b_lo + blockIdx.x;
+    const int S = a.S, F = a.F, T = a.T, ov = a.T - a.hop;
+    double acc[SMAX * SMAX];
+#pragma unroll
+    for (int i = 0; i < SMAX * SMAX; ++i) acc[i] = 0.0;
+    for (int idx = threadIdx.x; idx < F * ov; idx += 256) {
+        const int f = idx / ov, t = idx % ov;
+        float l[SMAX], r[SMAX];
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+            if (k < S) {
+                if (input == 0) {
+                    l[k] = a.masks[((int64_t)k * F + f) * a.mask_ld + b * T + (T - ov) + t];
+                    r[k] = a.masks[((int64_t)k * F + f) * a.mask_ld + (b + 1) * T + t];
+                } else {
+                    const float2 lv = reinterpret_cast<const float2*>(a.sep)[((b * S + k) * (int64_t)F + f) * T + (T - ov) + t];
+                    const float2 rv = reinterpret_cast<const float2*>(a.sep)[(((b + 1) * S + k) * (int64_t)F + f) * T + t];
+                    l[k] = sqrtf(lv.x * lv.x + lv.y * lv.y);
+                    r[k] = sqrtf(rv.x * rv.x + rv.y * rv.y);
+                }
+            } else { l[k] = 0.f; r[k] = 0.f; }
+        }
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i)
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j) {
+                const float d = l[i] - r[j];
+                acc[i * SMAX + j] += loss == 0 ? (double)fabsf(d) : (double)(d * d);
+            }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < SMAX * SMAX; ++i) {
+        const double v = wave_sum_dd(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < S * S) {
+        const int i = threadIdx.x / S, j = threadIdx.x % S, q = i * SMAX + j;
+        costs[b * S * S + threadIdx.x] = (red[0][q] + red[1][q] + red[2][q] + red[3][q]) / ((double)F * ov);
+    }
+}
+
+void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* costs,
+                      hipStream_t s) {
+    if (b_hi <= b_lo) return;
+    hipLaunchKernelGGL(pit_cost_kernel, dim3((unsigned)(b_hi - b_lo)), dim3(256), 0, s, a, loss, input, b_lo, costs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequential permutation scan (css.py:266-285 with losses.py:32-48): perm[0] = identity;
+// perm[i+1] = argmin over permutations sigma of sum_a cost_i[perm[i][a]][sigma[a]].
+// The reference minimises with scipy.optimize.linear_sum_assignment; for S <= 4 an exhaustive search
+// in lexicographic order (first minimum wins) is the same optimum.  Shared by host and device.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
+    for (int a = 0; a < S; ++a) perms[a] = a;
+    for (int64_t b = 0; b < n_boundaries; ++b) {
+        const double* c = costs + b * S * S;
+        const int32_t* lp = perms + b * S;
+        int32_t* rp = perms + (b + 1) * S;
+        int sig[SMAX] = {0, 1, 2, 3}, best_sig[SMAX] = {0, 1, 2, 3};
+        double best = 0.0;
+        bool first = true;
+        while (true) {
+            double tot = 0.0;
+            for (int a = 0; a < S; ++a) tot += c[lp[a] * S + sig[a]];
+            if (first || tot < best) {
+                best = tot;
+                first = false;
+                for (int a = 0; a < S; ++a) best_sig[a] = sig[a];
+            }
+            // next lexicographic permutation of sig[0..S)
+            int i = S - 2;
+            while (i >= 0 && sig[i] > sig[i + 1]) --i;
+            if (i < 0) break;
+            int j = S - 1;
+            while (sig[j] < sig[i]) --j;
+            int tmp = sig[i]; sig[i] = sig[j]; sig[j] = tmp;
+            for (int l = i + 1, r = S - 1; l < r; ++l, --r) { tmp = sig[l]; sig[l] = sig[r]; sig[r] = tmp; }
+        }
+        for (int a = 0; a < S; ++a) rp[a] = best_sig[a];
+    }
+}
+
+__global__ void pit_scan_kernel(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) pit_scan_impl(costs, n_boundaries, S, perms);
+}
+
+void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s) {
+    hipLaunchKernelGGL(pit_scan_kernel, dim3(1), dim3(64), 0, s, costs, n_boundaries, S, perms);
+}
+
+void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
+    pit_scan_impl(costs, n_boundaries, S, perms);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers shared by the two overlap-add kernels
+// ------------------------------------------------------------------------------------------------
+struct Contrib { int64_t seg; int tl; float w; };
+
+__device__ __forceinline__ float seg_weight(const StitchArgs& a, int64_t seg, int tl) {
+    // css.py:258,290: segment 0 is built with is_first_seg, the last one with is_last_seg
+    const float* w = seg == 0 ? a.w_first : (seg == a.num_segments - 1 ? a.w_last : a.w_mid);
+    return w[tl];
+}
+
+// the (at most two) segments covering frame t, in ascending segment order
+__device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Contrib c[2]) {
+    const int64_t i1 = t / a.hop;
+    int n = 0;
+    for (int64_t seg = i1 - 1; seg <= i1; ++seg) {
+        if (seg < 0 || seg >= a.num_segments) continue;
+        const int64_t tl = t - seg * a.hop;
+        if (tl < 0 || tl >= a.T) continue;
+        c[n].seg = seg;
+        c[n].tl = (int)tl;
+        c[n].w = seg_weight(a, seg, (int)tl);
+        ++n;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weighted overlap-add of the (permuted) masks + mean over frequency (css.py:254-299, 303-304):
+//   mask_st[s][f][t] = (sum_i w_i[t - st_i] * mask_i[perm_i[s]][f][t - st_i]) / (sum_i w_i[t - st_i])
+//   activity[s][t]   = mean_f mask_st[s][f][t];   act_b = activity >= th
+// The float32 operation order of the reference (multiply, add in ascending segment order, divide) is
+// reproduced with explicit round-to-nearest intrinsics so no FMA contraction changes a bit.
+// Block = 64 frames x 4 frequency groups; lanes run over time (contiguous mask reads).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_lo, int64_t t_hi) {
+    __shared__ double red[4][64];
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63, fg = threadIdx.x >> 6;
+    const int64_t t = t_lo + (int64_t)blockIdx.x * 64 + lane;
+    const bool active = t < t_hi;
+    Contrib c[2];
+    int n = 0;
+    float wsum = 0.f;
+    const float* m0 = nullptr;
+    const float* m1 = nullptr;
+    if (active) {
+        n = contributors(a, t, c);
+        for (int i = 0; i < n; ++i) wsum = __fadd_rn(wsum, c[i].w);
+        if (n > 0) m0 = a.masks + (int64_t)a.perms[c[0].seg * a.S + s] * a.F * a.mask_ld + c[0].seg * a.T + c[0].tl;
+        if (n > 1) m1 = a.masks + (int64_t)a.perms[c[1].seg * a.S + s] * a.F * a.mask_ld + c[1].seg * a.T + c[1].tl;
+    }
+    double sum = 0.0;
+    if (active && n > 0) {
+        float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
+        for (int f = fg; f < a.F; f += 4) {
+            float v = __fmul_rn(c[0].w, m0[(int64_t)f * a.mask_ld]);
+            if (n > 1) v = __fadd_rn(v, __fmul_rn(c[1].w, m1[(int64_t)f * a.mask_ld]));
+            v = __fdiv_rn(v, wsum);
+            out[(int64_t)f * a.T_long] = v;
+            sum += (double)v;
+        }
+    }
+    red[fg][lane] = sum;
+    __syncthreads();
+    if (fg == 0 && active) {
+        const float act = (float)((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (double)a.F);
+        a.activity[(int64_t)s * a.T_long + t] = act;
+        a.act_b[(int64_t)s * a.T_long + t] = act >= a.activity_th ? 1 : 0;
+    }
+}
+
+void launch_ola_masks(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
+    if (t_hi <= t_lo) return;
+    hipLaunchKernelGGL(ola_masks_kernel, dim3((unsigned)((t_hi - t_lo + 63) / 64), a.S), dim3(256), 0, s, a, t_lo, t_hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dilate (zero padding) then erode (one padding) of the per-speaker activity (css.py:305-308,
+// numpy_utils.py:4-13).  act_final over [t_lo, t_hi) needs act_b over [t_lo - E - Dl, t_hi + E + Dl).
+// ------------------------------------------------------------------------------------------------
+__global__ void morph_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t T_long, int radius,
+                             int erode, int64_t t_lo, int64_t t_hi) {
+    const int s = blockIdx.y;
+    const int64_t t = t_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= t_hi) return;
+    const uint8_t* row = in + (int64_t)s * T_long;
+    uint8_t v = erode ? 1 : 0;
+    for (int64_t u = t - radius; u <= t + radius; ++u) {
+        const uint8_t x = (u < 0 || u >= T_long) ? (erode ? 1 : 0) : row[u];
+        v = erode ? (v & x) : (v | x);
+    }
+    out[(int64_t)s * T_long + t] = v;
+}
+
+void launch_morphology(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
+    if (t_hi <= t_lo) return;
+    const int64_t d_lo = t_lo - a.erosion < 0 ? 0 : t_lo - a.erosion;
+    const int64_t d_hi = t_hi + a.erosion > a.T_long ? a.T_long : t_hi + a.erosion;
+    hipLaunchKernelGGL(morph_kernel, dim3((unsigned)((d_hi - d_lo + 255) / 256), a.S), dim3(256), 0, s, a.act_b,
+                       a.act_tmp, a.T_long, a.dilation, 0, d_lo, d_hi);
+    hipLaunchKernelGGL(morph_kernel, dim3((unsigned)((t_hi - t_lo + 255) / 256), a.S), dim3(256), 0, s, a.act_tmp,
+                       a.act_final, a.T_long, a.erosion, 1, t_lo, t_hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weighted overlap-add of the (permuted) separated spectra, activity gating (css.py:294,298,312) and
+// the hand-off layout of the synthesis GEMM: Y[s][t][0..F) = Re, [F..2F) = Im, zero padding to KIp.
+// Block = 16 frames of one stream; reads run over time (128-byte runs of float2), the tile is turned
+// through LDS so the writes run over the frequency axis.
+// ------------------------------------------------------------------------------------------------
+constexpr int OT = 16;
+
+__global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_lo, int64_t t_hi) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [OT][2F + 1] (odd stride: no bank conflicts)
+    const int TS = 2 * a.F + 1;
+    const int s = blockIdx.y;
+    const int64_t t0 = t_lo + (int64_t)blockIdx.x * OT;
+    const int tx = threadIdx.x & (OT - 1), fy = threadIdx.x >> 4;  // 16 frames x 16 bins per pass
+    const int64_t t = t0 + tx;
+    const bool active = t < t_hi;
+    Contrib c[2];
+    int n = 0;
+    float wsum = 0.f, gate = 0.f;
+    const float2* p0 = nullptr;
+    const float2* p1 = nullptr;
+    if (active) {
+        n = contributors(a, t, c);
+        for (int i = 0; i < n; ++i) wsum = __fadd_rn(wsum, c[i].w);
+        gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
+        const float2* sep = reinterpret_cast<const float2*>(a.sep);
+        if (n > 0) p0 = sep + (c[0].seg * a.S + a.perms[c[0].seg * a.S + s]) * (int64_t)a.F * a.T + c[0].tl;
+        if (n > 1) p1 = sep + (c[1].seg * a.S + a.perms[c[1].seg * a.S + s]) * (int64_t)a.F * a.T + c[1].tl;
+    }
+    for (int f = fy; f < a.F; f += 16) {
+        float re = 0.f, im = 0.f;
+        if (active && n > 0) {
+            const float2 v0 = p0[(int64_t)f * a.T];
+            re = __fmul_rn(c[0].w, v0.x);
+            im = __fmul_rn(c[0].w, v0.y);
+            if (n > 1) {
+                const float2 v1 = p1[(int64_t)f * a.T];
+                re = __fadd_rn(re, __fmul_rn(c[1].w, v1.x));
+                im = __fadd_rn(im, __fmul_rn(c[1].w, v1.y));
+            }
+            re = __fmul_rn(__fdiv_rn(re, wsum), gate);
+            im = __fmul_rn(__fdiv_rn(im, wsum), gate);
+        }
+        tile[tx * TS + f] = re;
+        tile[tx * TS + a.F + f] = im;
+    }
+    __syncthreads();
+    for (int r = 0; r < OT; ++r) {
+        if (t0 + r >= t_hi) break;
+        float* out = a.Y + ((int64_t)s * a.T_long + t0 + r) * a.KIp;
+        for (int j = threadIdx.x; j < a.KIp; j += 256) out[j] = j < 2 * a.F ? tile[r * TS + j] : 0.f;  // zero K padding
+    }
+}
+
+void launch_ola_stft(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
+    if (t_hi <= t_lo) return;
+    const size_t lds = (size_t)OT * (2 * a.F + 1) * sizeof(float);
+    hipLaunchKernelGGL(ola_stft_kernel, dim3((unsigned)((t_hi - t_lo + OT - 1) / OT), a.S), dim3(256), lds, s, a, t_lo, t_hi);
+}
+
+}  // namespace css

@@ -1,0 +1,204 @@
+"""Long-form continuous speech separation on the MI355X: the counterpart of the reference's ``css/css.py``.
+
+Same plug-in surface -- ``CssCfg``, ``css_inference``, ``separate_and_stitch``, ``calc_segment_weight``
+with the reference's argument names, return types and assertion behaviour -- so that the rest of the
+NOTSOFAR pipeline (Whisper ASR, diarization) consumes the ``sep_stream{i}.wav`` files unchanged.  The
+arithmetic of ``separate_and_stitch`` (css/css.py:110-338) runs in one fused pass of hand-written
+gfx950 kernels behind the C ABI of ``include/css_mi355.h``: one upload of the PCM, every segment of
+the meeting batched through the mask estimator, MVDR / stitching / gating / inverse transform on the
+device, one download of the separated waveforms.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _lib
+from .separator import HipSeparator, load_css_model
+from .wavio import load_audio, write_wav
+
+_LOG = logging.getLogger('css')
+
+
+# CSS inference configuration -- field-for-field the reference's CssCfg (css/css.py:24-48)
+@dataclass
+class CssCfg:
+    segment_size_sec: float = 3.  # in seconds
+    hop_size_sec: float = 1.5     # in seconds
+    normalize_segment_power: bool = False
+    stitching_loss: str = 'l1'  # loss function for stitching adjacent segments ('l1' or 'mse')
+    stitching_input: str = 'mask'  # type of input for stitching loss ('mask' or 'separation_result')
+    seg_weight_m0_sec: float = 0.15  # see calc_segment_weight
+    seg_weight_m1_sec: float = 0.3
+    activity_th: float = 0.4  # threshold for segmentation mask
+    activity_dilation_sec: float = 0.4  # dilation and erosion for segmentation mask
+    activity_erosion_sec: float = 0.2
+    device: Optional[str] = None
+    show_progressbar: bool = True
+    checkpoint_sc: str = 'notsofar/conformer1.0/sc'
+    checkpoint_mc: str = 'notsofar/conformer1.0/mc'
+    device_id: int = 0
+    num_spks: int = 3  # the number of streams the separation models outputs
+    mc_mvdr: bool = True  # if True, applies MVDR to the multi-channel input
+    mc_mask_floor_db: float = 0.  # mask floor in db. -inf means no floor. 0 means mask has no effect
+    sc_mask_floor_db: float = -np.inf
+    pass_through_ch0: bool = False  # if True, simply returns the first channel of the input and skips CSS
+    slice_audio_for_debug: bool = False  # if True, only processes 10 seconds of the input audio
+
+
+def _linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
+    """float32 linspace with ATen's evaluation order (symmetric halves, fused multiply-add), so that the
+    taper of calc_segment_weight is bit-identical to the reference's torch.linspace(0.1, 1, n)."""
+    start, end = np.float32(start), np.float32(end)
+    if steps == 1:
+        return np.array([start], dtype=np.float32)
+    step = np.float32((end - start) / np.float32(steps - 1))
+    out = np.empty(steps, dtype=np.float32)
+    for i in range(steps):
+        if i < steps // 2:
+            out[i] = np.float32(np.float64(start) + np.float64(step) * i)
+        else:
+            out[i] = np.float32(np.float64(end) - np.float64(step) * (steps - i - 1))
+    return out
+
+
+def calc_segment_weight(seg_frames: int, m0_frames: int, m1_frames: int,
+                        is_first_seg: bool = False, is_last_seg: bool = False) -> np.ndarray:
+    """Trapezoid weighting window of the overlap-add (css/css.py:341-390): 0 on the outer m0 frames,
+    linear 0.1 -> 1 between m0 and m1, 1 in the middle, mirrored on the right; the first (last) segment of
+    the recording keeps 0.1 instead of 0 on its left (right) edge because nothing else covers it."""
+    assert seg_frames > 2 * m1_frames, \
+        'not enough frames to fit weighting window. try modifying hop_size, segment_size or m0, m1'
+    w = np.ones(seg_frames, dtype=np.float32)
+    w[:m0_frames] = 0
+    w[seg_frames - m0_frames:] = 0
+    linear = _linspace_f32(0.1, 1, m1_frames - m0_frames)
+    w[m0_frames:m1_frames] = linear
+    w[seg_frames - m1_frames:seg_frames - m0_frames] = linear[::-1]
+    if is_first_seg:
+        w[:m0_frames] = 0.1
+    if is_last_seg:
+        w[seg_frames - m0_frames:] = 0.1
+    return w
+
+
+def make_run_cfg(cfg: CssCfg, fs: int, num_channels: int, frame_len: int = 512, frame_hop: int = 256) -> _lib.RunCfg:
+    """Seconds -> frames with the reference's own float expressions (css/css.py:144-152) and the
+    knobs the C ABI needs."""
+    seg_samples = int(cfg.segment_size_sec * fs)
+    segment_frames = (seg_samples - frame_len) // frame_hop + 1  # length of the dummy STFT, css.py:145-147
+    hop_frames = int(segment_frames * cfg.hop_size_sec / cfg.segment_size_sec)
+    m0_frames = int(segment_frames * cfg.seg_weight_m0_sec / cfg.segment_size_sec)
+    m1_frames = int(segment_frames * cfg.seg_weight_m1_sec / cfg.segment_size_sec)
+    dilation_frames = int(segment_frames * cfg.activity_dilation_sec / cfg.segment_size_sec)
+    erosion_frames = int(segment_frames * cfg.activity_erosion_sec / cfg.segment_size_sec)
+    mask_floor_db = cfg.mc_mask_floor_db if num_channels > 1 else cfg.sc_mask_floor_db   # css.py:223
+    assert mask_floor_db <= 0                                                            # css.py:224
+    mask_floor = 10. ** (mask_floor_db / 20.)
+    assert cfg.stitching_loss in ('l1', 'mse'), f'unexpected stitching_loss: {cfg.stitching_loss}'
+    assert cfg.stitching_input in ('mask', 'separation_result'), f'unexpected stitching_input: {cfg.stitching_input}'
+    return _lib.RunCfg(
+        segment_frames, hop_frames, dilation_frames, erosion_frames, cfg.mc_mvdr,
+        {'l1': 0, 'mse': 1}[cfg.stitching_loss], {'mask': 0, 'separation_result': 1}[cfg.stitching_input],
+        cfg.normalize_segment_power, mask_floor, cfg.activity_th,
+        calc_segment_weight(segment_frames, m0_frames, m1_frames, is_first_seg=True),
+        calc_segment_weight(segment_frames, m0_frames, m1_frames),
+        calc_segment_weight(segment_frames, m0_frames, m1_frames, is_last_seg=True))
+
+
+def _maybe_torch(arr: np.ndarray):
+    try:
+        import torch
+        return torch.from_numpy(arr)
+    except Exception:  # pragma: no cover
+        return arr
+
+
+def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg: CssCfg) -> (List[np.ndarray], Dict):
+    """Applies speech separation in block-online fashion (css/css.py:110-338).
+
+    Args:
+        speech_mix: long-form input [Batch, Nsamples, Channels] float32 (Channels == 1 or 7).
+        separator: a ``HipSeparator`` (see separator.py).
+        fs: sample rate.
+        device: GPU to run on (torch.device / 'cuda:N' / int).
+        cfg: CSS configuration.
+    Returns:
+        separated_wavs: list of ``cfg.num_spks`` float32 arrays [Nsamples_out].
+        side_info: dict with 'mask_stitched' [1, F, T_long, S], 'activity_b' [T_long, S],
+            'activity_final' [1, T_long, S] and 'segment_frames', as in the reference.
+    """
+    assert speech_mix.ndim == 3, f'expecting 3 dimensions, got {speech_mix.shape}'
+    assert speech_mix.shape[0] == 1, 'assuming 1 example in batch. easy to support more.'
+    if not isinstance(separator, HipSeparator):
+        raise TypeError("separate_and_stitch runs the fused HIP path and needs a HipSeparator; build one with "
+                        "HipSeparator(state_dict, cfg) or load_css_model(model_dir)")
+    assert not separator.training
+    separator.to(device)
+    desc = separator.desc
+    assert cfg.num_spks == desc.num_spks, f"cfg.num_spks={cfg.num_spks} but the model separates {desc.num_spks}"
+    n, c = speech_mix.shape[1], speech_mix.shape[2]
+    run_cfg = make_run_cfg(cfg, fs, c, desc.frame_len, desc.frame_hop)
+    h = separator.handle
+    wav = h.run(speech_mix[0], run_cfg)  # [S, n_out]
+    separated_wavs = [wav[k] for k in range(desc.num_spks)]
+
+    mask_st = h.read(_lib.BUF_MASK_ST)                       # [S, F, T_long]
+    act_b = h.read(_lib.BUF_ACT_B).astype(bool)              # [S, T_long]
+    act_final = h.read(_lib.BUF_ACT_FINAL).astype(bool)
+    side_info = {
+        'mask_stitched': _maybe_torch(np.ascontiguousarray(np.transpose(mask_st, (1, 2, 0)))[None]),
+        'activity_b': _maybe_torch(np.ascontiguousarray(act_b.T)),
+        'activity_final': _maybe_torch(np.ascontiguousarray(act_final.T)[None]),
+        'segment_frames': int(run_cfg.c.segment_frames),
+    }
+    return separated_wavs, side_info
+
+
+def css_inference(out_dir: str, models_dir: str, session, cfg: CssCfg, fetch_from_cache: bool):
+    """Applies CSS to one session row (css/css.py:51-107).
+
+    Writes ``out_dir/css_inference/<session_id>/{input_mixture,sep_stream0..}.wav`` and returns a copy of
+    the session with ``sep_wav_file_names`` added.
+    """
+    _LOG.info("Running CSS (Continuous Speech Separation)")
+    session_css = session.copy()
+
+    assert isinstance(session.wav_file_names, list)
+    if cfg.pass_through_ch0:
+        session_css['sep_wav_file_names'] = session.wav_file_names[0:1]
+        return session_css
+
+    css_out_dir = Path(out_dir) / "css_inference" / session.session_id
+    if fetch_from_cache and css_out_dir.exists():
+        sep_wav_file_names = sorted(css_out_dir.glob('sep*.wav'))
+        session_css['sep_wav_file_names'] = sep_wav_file_names
+        return session_css
+
+    separator, _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if session.is_mc else cfg.checkpoint_sc))
+    device = f"cuda:{cfg.device_id}"
+    separator.eval()
+    mixwav, sr = load_audio(session.wav_file_names, is_mc=session.is_mc)
+
+    if cfg.slice_audio_for_debug:
+        mixwav = mixwav[:, sr * 20:sr * 30, :]
+
+    separated_wavs, _ = separate_and_stitch(mixwav, separator, sr, device, cfg)
+    separator.close()
+
+    write_wav(css_out_dir / 'input_mixture.wav', samps=mixwav[0, :, 0], sr=sr)
+
+    sep_wav_file_names = []
+    for i, w in enumerate(separated_wavs):
+        filename = css_out_dir / f"sep_stream{i}.wav"
+        _LOG.info(f"CSS: saving separated wav to {filename}")
+        write_wav(filename, samps=w, sr=sr)
+        sep_wav_file_names.append(str(filename))
+
+    session_css['sep_wav_file_names'] = sep_wav_file_names
+    return session_css

@@ -10,7 +10,7 @@ SURVEY.md App. A.4).  This module
   seed, so no 237 MB checkpoint has to be committed or shipped,
 * packs a state dict into the flat float32 blob the C ABI consumes (``pack_blob``; layout documented
   in ``include/css_mi355.h``), applying the load-time transformations the HIP kernels expect
-  (K padded to a multiple of 16, fused QKV, BatchNorm folded to alpha/beta exactly like ATen's
+  (K padded to a multiple of 32, fused QKV, BatchNorm folded to alpha/beta exactly like ATen's
   eval-mode CPU kernel, depthwise-conv taps transposed to [tap][channel]).
 """
 from __future__ import annotations
@@ -44,7 +44,7 @@ class ModelDesc:
 
     @property
     def k_in_padded(self) -> int:
-        return (self.in_features + 15) // 16 * 16
+        return (self.in_features + 31) // 32 * 32
 
     @property
     def n_masks(self) -> int:
