@@ -186,6 +186,9 @@ int css_get_plan(css_handle_t h, CssPlan* out);
 int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device);
 /* ConformerCssWrapper.stft (conformer_wrapper.py:106, feature.py:88) over the whole recording. */
 int css_stage_stft(css_handle_t h);
+/* Same for frames [t_lo, t_hi) only (a rank that owns a slice of the meeting transforms just the
+ * frames its segments read). */
+int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi);
 /* ConformerCssWrapper.separate (conformer_wrapper.py:79): features + Conformer for segments [lo, hi). */
 int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi);
 /* make_mvdr (mvdr_util.py:5) + mask floor/multiply (css.py:222-227) for segments [lo, hi). */
@@ -199,6 +202,17 @@ int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi);
 /* ConformerCssWrapper.istft (conformer_wrapper.py:131, feature.py:138) for output frames
  * [t_lo, t_hi): samples [t_lo*hop, (t_hi)*hop) (+ the tail when t_hi == mix_frames). */
 int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi);
+/* The two halves of css_stage_stitch, for frame-sharded runs that exchange the activity bits in between:
+ * masks:  overlap-add of the masks, mean over frequency, threshold (css.py:295,299,303-304) on [t_lo, t_hi);
+ * gate:   dilate/erode (css.py:305-308; reads CSS_BUF_ACT_B `dilation+erosion` frames to either side),
+ *         overlap-add of the spectra, gating (css.py:294,298,312) on [t_lo, t_hi). */
+int css_stage_stitch_masks(css_handle_t h, int64_t t_lo, int64_t t_hi);
+int css_stage_stitch_gate(css_handle_t h, int64_t t_lo, int64_t t_hi);
+/* Inverse transform of frames [t_lo, t_hi) ONLY, written to a caller-owned device shard
+ * shard_dev [S][shard_ld]: column hop*(q - t_lo) + r for output blocks q in [t_lo, t_hi].  The first and
+ * last block hold one frame's contribution each; adding the overlapping blocks of adjacent shards
+ * reproduces css_stage_istft bit for bit (a two-term float sum commutes). */
+int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld);
 int css_sync(css_handle_t h);
 
 /* Separator-protocol helpers operating on caller data (host pointers):

@@ -83,6 +83,10 @@ SIGNATURES = {
     "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
     "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
     "css_stage_stft": (C.c_int, [_P]),
+    "css_stage_stft_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_stitch_masks": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_stitch_gate": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_istft_partial": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64]),
     "css_stage_masknet": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_mvdr": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_pit_costs": (C.c_int, [_P, C.c_int64, C.c_int64]),
@@ -244,6 +248,18 @@ class Handle:
     def stage_stft(self):
         check(self.h, self.lib.css_stage_stft(self.h))
 
+    def stage_stft_range(self, lo, hi):
+        check(self.h, self.lib.css_stage_stft_range(self.h, lo, hi))
+
+    def stage_stitch_masks(self, lo, hi):
+        check(self.h, self.lib.css_stage_stitch_masks(self.h, lo, hi))
+
+    def stage_stitch_gate(self, lo, hi):
+        check(self.h, self.lib.css_stage_stitch_gate(self.h, lo, hi))
+
+    def stage_istft_partial(self, lo, hi, shard_ptr: int, shard_ld: int):
+        check(self.h, self.lib.css_stage_istft_partial(self.h, lo, hi, C.c_void_p(shard_ptr), shard_ld))
+
     def stage_masknet(self, lo, hi):
         check(self.h, self.lib.css_stage_masknet(self.h, lo, hi))
 
@@ -297,7 +313,9 @@ class Handle:
         dims = (C.c_int64 * 4)()
         el = C.c_int32()
         check(self.h, self.lib.css_buffer_dims(self.h, which, dims, C.byref(el)))
-        return tuple(int(x) for x in dims), int(el.value)
+        shape = [int(x) for x in dims]
+        rank = {BUF_X: 3, BUF_SCM: 4, BUF_BFW: 4, BUF_SEP: 4, BUF_MASK_ST: 3, BUF_Y: 3, BUF_WTA_OVERRIDE: 3}.get(which, 2)
+        return tuple(shape[:rank]), int(el.value)
 
     def read(self, which: int) -> np.ndarray:
         dims, el = self.buffer_dims(which)

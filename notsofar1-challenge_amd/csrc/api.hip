@@ -63,6 +63,7 @@ struct css_ctx {
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
         act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage;
     int64_t last_batch_tokens = 0;
+    const float* pcm_src = nullptr;  // sample-major PCM on the device for the current session
 
     // timing
     hipEvent_t ev[10]{};
@@ -455,25 +456,30 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
         pcm_dev = (const float*)h->pcm_in.p;
     }
 #undef ENS
-    launch_deinterleave(pcm_dev, (float*)h->pcm_cm.p, n_samples, n_ch, h->n_pad, h->stream);
+    h->pcm_src = pcm_dev;
     hipEventRecord(h->ev[1], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
 
-int css_stage_stft(css_handle_t h) {
+int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     int rc = check_session(h);
     if (rc) return rc;
+    if (t_lo < 0 || t_hi > h->plan.mix_frames || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
-    const int F = h->d.num_bins, N = h->d.frame_len;
-    if (h->plan.stft_frames < h->plan.mix_frames)  // short input: zero-padded frames (css.py:159-164)
+    const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop;
+    if (h->plan.stft_frames < h->plan.mix_frames && !h->stft_done)  // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
-    if (h->plan.stft_frames > 0) {
+    const int64_t f_hi = std::min<int64_t>(t_hi, h->plan.stft_frames);
+    if (f_hi > t_lo) {
+        // channel-major copy of exactly the samples these frames read, then DFT-matrix x frames
+        const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
+        launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, h->stream);
         GemmArgs g{};
         g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
-        g.B = (const float*)h->pcm_cm.p; g.ldb = h->d.frame_hop; g.strideB = h->n_pad;
-        g.C = (float*)h->X.p; g.ldc = h->T_ld; g.strideC = (int64_t)2 * F * h->T_ld;
-        g.M = 2 * F; g.N = (int)h->plan.stft_frames; g.K = N; g.batch = h->n_ch;
+        g.B = (const float*)h->pcm_cm.p + t_lo * hop; g.ldb = hop; g.strideB = h->n_pad;
+        g.C = (float*)h->X.p + t_lo; g.ldc = h->T_ld; g.strideC = (int64_t)2 * F * h->T_ld;
+        g.M = 2 * F; g.N = (int)(f_hi - t_lo); g.K = N; g.batch = h->n_ch;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
         launch_gemm(g, h->stream);
     }
@@ -481,6 +487,12 @@ int css_stage_stft(css_handle_t h) {
     HIPCHK(h, hipGetLastError());
     h->stft_done = true;
     return CSS_OK;
+}
+
+int css_stage_stft(css_handle_t h) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    return css_stage_stft_range(h, 0, h->plan.mix_frames);
 }
 
 // Where one batched pass of the mask estimator reads its spectra and writes its masks.
@@ -603,48 +615,80 @@ int css_stage_pit_scan(css_handle_t h) {
     return CSS_OK;
 }
 
-int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+static int check_frames(css_ctx* h, int64_t t_lo, int64_t t_hi) {
     int rc = check_session(h);
     if (rc) return rc;
-    if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
-    const int64_t TL = h->plan.mix_frames;
-    if (t_lo < 0 || t_hi > TL || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
+    if (t_lo < 0 || t_hi > h->plan.mix_frames || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
+    return CSS_OK;
+}
+
+int css_stage_stitch_masks(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
+    launch_ola_masks(stitch_args(h), t_lo, t_hi, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_stitch_gate(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
     StitchArgs a = stitch_args(h);
-    // the inverse transform of frame range [t_lo, t_hi) also needs frame t_lo - 1 (2-frame overlap-add),
-    // and the dilate/erode gate needs activity `dilation + erosion` frames to either side
-    const int64_t y_lo = std::max<int64_t>(t_lo - 1, 0);
-    const int64_t halo = a.dilation + a.erosion;
-    launch_ola_masks(a, std::max<int64_t>(y_lo - halo, 0), std::min<int64_t>(t_hi + halo, TL), h->stream);
-    launch_morphology(a, y_lo, t_hi, h->stream);
-    launch_ola_stft(a, y_lo, t_hi, h->stream);
+    launch_morphology(a, t_lo, t_hi, h->stream);
+    launch_ola_stft(a, t_lo, t_hi, h->stream);
     hipEventRecord(h->ev[5], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
 
-int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi) {
-    int rc = check_session(h);
+int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
+    // the inverse transform of frame range [t_lo, t_hi) also needs frame t_lo - 1 (2-frame overlap-add),
+    // and the dilate/erode gate needs activity `dilation + erosion` frames to either side
     const int64_t TL = h->plan.mix_frames;
-    if (t_lo < 0 || t_hi > TL || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
-    HIPCHK(h, hipSetDevice(h->device));
-    const int S = h->d.num_spks, N = h->d.frame_len;
     const int64_t y_lo = std::max<int64_t>(t_lo - 1, 0);
-    if (t_hi > y_lo) {
+    const int64_t halo = h->cfg.dilation_frames + h->cfg.erosion_frames;
+    if ((rc = css_stage_stitch_masks(h, std::max<int64_t>(y_lo - halo, 0), std::min<int64_t>(t_hi + halo, TL))) != CSS_OK) return rc;
+    return css_stage_stitch_gate(h, y_lo, t_hi);
+}
+
+// synthesis GEMM over frames [f_lo, f_hi), then overlap-add of output blocks [q_lo, q_hi) using only those frames
+static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
+                      int64_t out_q0) {
+    const int S = h->d.num_spks, N = h->d.frame_len;
+    const int64_t TL = h->plan.mix_frames;
+    if (f_hi > f_lo) {
         GemmArgs g{};
-        g.A = (const float*)h->Y.p + y_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
+        g.A = (const float*)h->Y.p + f_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
         g.B = h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
-        g.C = (float*)h->G.p + y_lo * N; g.ldc = N; g.strideC = TL * N;
-        g.M = (int)(t_hi - y_lo); g.N = N; g.K = h->KIp; g.batch = S;
+        g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
+        g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
         launch_gemm(g, h->stream);
-        const int64_t q_hi = (t_hi == TL) ? TL + 1 : t_hi;  // the last rank also writes the tail half-frame
-        launch_wave_ola((const float*)h->G.p, (float*)h->wav.p, S, TL, h->d.frame_hop, t_lo, q_hi, h->plan.n_out, h->stream);
+        launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->stream);
     }
     hipEventRecord(h->ev[6], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
+}
+
+int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    const int64_t TL = h->plan.mix_frames;
+    const int64_t q_hi = (t_hi == TL) ? TL + 1 : t_hi;  // the last range also writes the tail half-frame
+    return istft_impl(h, std::max<int64_t>(t_lo - 1, 0), t_hi, t_lo, q_hi, (float*)h->wav.p, h->plan.n_out, 0);
+}
+
+int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    if (!shard_dev || shard_ld < (t_hi - t_lo + 1) * h->d.frame_hop) return fail(h, CSS_ERR_INVALID_ARG, "shard buffer too small");
+    return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo);
 }
 
 int css_sync(css_handle_t h) {
@@ -739,7 +783,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
-    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, h->stream);
+    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, h->stream);
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
     g.B = cm; g.ldb = hop; g.strideB = n_pad;
@@ -798,7 +842,7 @@ int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t
     g.M = (int)t_frames; g.N = N; g.K = KI; g.batch = batch;
     g.alpha = 1.f;
     launch_gemm(g, h->stream);
-    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, n_out, h->stream);
+    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, 0, t_frames, n_out, 0, h->stream);
     HIPCHK(h, hipMemcpyAsync(wav, wv, w_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CSS_OK;

@@ -16,15 +16,17 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // (conformer_wrapper.py:119 does the same moveaxis on the host).
 // ------------------------------------------------------------------------------------------------
 __global__ void deinterleave_kernel(const float* __restrict__ pcm, float* __restrict__ out, int64_t n, int C,
-                                    int64_t n_pad) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
+                                    int64_t n_pad, int64_t i_lo, int64_t i_hi) {
+    const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i_hi) return;
     for (int c = 0; c < C; ++c) out[(int64_t)c * n_pad + i] = i < n ? pcm[i * C + c] : 0.f;
 }
 
-void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, hipStream_t s) {
-    const int64_t blocks = (n_pad + 255) / 256;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad);
+void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
+                         hipStream_t s) {
+    if (i_hi <= i_lo) return;
+    const int64_t blocks = (i_hi - i_lo + 255) / 256;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad, i_lo, i_hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -144,28 +146,28 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
 // G[b][q][0..2*hop): output sample hop*q + r receives frame q (first half) and frame q-1 (second half).
 // Gather form: one thread per output sample, no atomics, bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-__global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ wav, int64_t T_frames, int hop,
-                                int64_t q_lo, int64_t q_hi, int64_t n_out) {
+__global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ out, int64_t T_frames, int hop,
+                                int64_t q_lo, int64_t q_hi, int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0) {
     const int b = blockIdx.y;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t q = q_lo + idx / hop;
     const int r = (int)(idx % hop);
     if (q >= q_hi) return;
-    const int64_t n = q * hop + r;
-    if (n >= n_out) return;
+    const int64_t n = (q - out_q0) * hop + r;
+    if (n >= out_ld) return;
     const float* g = G + (int64_t)b * T_frames * 2 * hop;
     float v = 0.f;
-    if (q >= 1) v = g[(q - 1) * 2 * hop + hop + r];
-    if (q < T_frames) v += g[q * 2 * hop + r];
-    wav[(int64_t)b * n_out + n] = v;
+    if (q - 1 >= f_lo && q - 1 < f_hi) v = g[(q - 1) * 2 * hop + hop + r];
+    if (q >= f_lo && q < f_hi) v += g[q * 2 * hop + r];
+    out[(int64_t)b * out_ld + n] = v;
 }
 
-void launch_wave_ola(const float* G, float* wav, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
-                     int64_t n_out, hipStream_t s) {
+void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, hipStream_t s) {
     const int64_t total = (q_hi - q_lo) * hop;
     if (total <= 0) return;
     const dim3 grid((unsigned)((total + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, wav, T_frames, hop, q_lo, q_hi, n_out);
+    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0);
 }
 
 // ------------------------------------------------------------------------------------------------

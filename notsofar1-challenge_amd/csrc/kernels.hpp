@@ -47,14 +47,17 @@ void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, in
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add
 // ------------------------------------------------------------------------------------------------
-void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, hipStream_t s);
+// samples [i_lo, i_hi) of every channel: pcm [n][C] -> pcm_cm [C][n_pad] (zeros past n)
+void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
+                         hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded)
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
                      hipStream_t s);
-// wav[b][hop*q + r] = G[b][q][r] + G[b][q-1][hop + r]   (frame_len == 2*hop)
-void launch_wave_ola(const float* G, float* wav, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
-                     int64_t n_out, hipStream_t s);
+// out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
+// only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
+void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, hipStream_t s);
 // [B][2F][T] planes -> [B][T][KIp] rows for the inverse GEMM
 void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s);
 

@@ -1,0 +1,170 @@
+"""Host-side checks of the C ABI that need no GPU: the library loads, exports every symbol the header
+declares, and its pure-host entry points (planning, permutation scan, validation) agree with the oracle."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+import css_oracle as O
+from conftest import ROOT, pkg
+
+
+@pytest.fixture(scope="module")
+def L():
+    return pkg("_lib")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "css_mi355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(css_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.load()
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libcss_mi355.so does not export {n}"
+    assert sorted(L.SIGNATURES) == names, "the ctypes binding and the header disagree"
+    assert lib.css_version().startswith(b"css_mi355")
+
+
+def test_struct_layouts_match_header(L):
+    assert C.sizeof(L.CssModelDesc) == 13 * 4
+    assert C.sizeof(L.CssRunCfg) == 8 * 4 + 2 * 4 + 3 * 8
+    assert C.sizeof(L.CssPlan) == 5 * 8 + 2 * 4
+    assert C.sizeof(L.CssTimings) == 10 * 4 + 8 + 8
+
+
+def test_blob_size_agrees_with_packer(L):
+    w = pkg("weights")
+    for desc in (w.ModelDesc.mc_v1(), w.ModelDesc.sc_v1(), w.ModelDesc(num_blocks=2)):
+        assert L.load().css_blob_num_floats(C.byref(L.make_desc(desc))) == w.blob_num_floats(desc)
+    bad = w.ModelDesc(attention_heads=4)  # head size 128: rejected
+    assert L.load().css_blob_num_floats(C.byref(L.make_desc(bad))) == -1
+
+
+def test_pack_blob_layout():
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=1)
+    st = w.portable_state_dict(desc, 7)
+    blob, d2 = w.pack_blob(st)
+    assert d2 == desc and blob.size == w.blob_num_floats(desc)
+    off = 0
+    secs = dict()
+    for name, n in w.blob_sections(desc):
+        secs[name] = (off, n)
+        off += (n + 15) // 16 * 16
+    o, n = secs["embed_w"]
+    e = blob[o:o + n].reshape(512, desc.k_in_padded)
+    assert np.array_equal(e[:, :1799], st[w.PREFIX + "conformer.embed.0.weight"]) and (e[:, 1799:] == 0).all()
+    o, n = secs["b0.wqkv"]
+    q = blob[o:o + n].reshape(1536, 512)
+    assert np.array_equal(q[512:1024], st[w.PREFIX + "conformer.encoders.0.self_attn.linear_k.weight"])
+    o, n = secs["b0.dw_wt"]
+    assert np.array_equal(blob[o:o + n].reshape(33, 512).T, st[w.PREFIX + "conformer.encoders.0.conv.dw_conv_1d.weight"][:, 0])
+    # a DDP checkpoint ("module." prefix, css/helpers.py:32-36) packs identically
+    blob2, _ = w.pack_blob({"module." + k: v for k, v in st.items()})
+    assert np.array_equal(blob, blob2)
+
+
+def test_plan_matches_oracle(L):
+    css = pkg("css")
+    w = pkg("weights")
+    desc = w.ModelDesc.mc_v1()
+    for kw in ({}, dict(hop_size_sec=2.0), dict(segment_size_sec=4.0, hop_size_sec=2.0)):
+        cfg = css.CssCfg(**kw)
+        ocfg = O.OracleCssCfg(**kw)
+        rc = css.make_run_cfg(cfg, 16000, 7)
+        for n in (0, 100, 511, 512, 48000, 48320, 50000, 64356, 160000, 960000, 960001, 28800000):
+            p = L.plan(desc, rc, n)
+            op = O.make_plan(n, 16000, ocfg)
+            assert (p.stft_frames, p.mix_frames, p.num_segments) == (op.stft_frames, op.mix_frames, op.num_segments), (kw, n)
+            assert p.last_valid == op.seg_range(op.num_segments - 1)[2]
+            assert p.n_out == (op.mix_frames - 1) * 256 + 512
+            assert (rc.c.segment_frames, rc.c.hop_frames, rc.c.dilation_frames, rc.c.erosion_frames) == \
+                (op.segment_frames, op.hop_frames, op.dilation_frames, op.erosion_frames)
+            assert bool(p.zero_weight) == (op.num_segments == 1), (kw, n)   # css.py:297 fires for single-segment inputs
+
+
+def test_segment_weight_bit_exact_vs_reference(golden):
+    css = pkg("css")
+    g = golden("segment_weight.npz")
+    assert np.array_equal(css.calc_segment_weight(186, 9, 18, is_first_seg=True), g["first"])
+    assert np.array_equal(css.calc_segment_weight(186, 9, 18), g["mid"])
+    assert np.array_equal(css.calc_segment_weight(186, 9, 18, is_last_seg=True), g["last"])
+    with pytest.raises(AssertionError, match="not enough frames"):
+        css.calc_segment_weight(30, 9, 18)
+
+
+def test_pit_scan_matches_bruteforce(L):
+    rs = np.random.RandomState(3)
+    costs = rs.rand(50, 3, 3)
+    perms = L.pit_scan(costs, 3)
+    assert tuple(perms[0]) == (0, 1, 2)
+    for b in range(50):
+        lp = perms[b]
+        best = min(itertools.permutations(range(3)), key=lambda s: sum(costs[b, lp[a], s[a]] for a in range(3)))
+        assert tuple(perms[b + 1]) == best
+    # the reference's known-answer test (losses.py:109-123): exact permutation, zero loss
+    t = rs.rand(100, 257, 4).astype(np.float32)
+    p = (3, 0, 2, 1)
+    _, _, c = O.pit_perm(t[..., p], t, "mse")
+    assert tuple(L.pit_scan(c[None], 4)[1]) == p
+
+
+def test_create_without_gpu_fails_loudly(L):
+    if L.load().css_device_count() > 0:
+        pytest.skip("a GPU is present")
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=1)
+    blob, _ = w.pack_blob(w.portable_state_dict(desc, 0), desc)
+    with pytest.raises(L.CssError) as e:
+        L.Handle(desc, blob)
+    assert e.value.code == L.CSS_ERR_NO_DEVICE
+    # and the Python driver has no fallback either
+    css, sep = pkg("css"), pkg("separator")
+    s = sep.HipSeparator(w.portable_state_dict(desc, 0))
+    with pytest.raises(L.CssError):
+        css.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), s, 16000, "cuda:0", css.CssCfg())
+    with pytest.raises(TypeError):
+        css.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), object(), 16000, "cuda:0", css.CssCfg())
+
+
+def test_wav_roundtrip_and_css_inference_plumbing(tmp_path):
+    """load_audio / write_wav counterparts (css/helpers.py:40, utils/audio_utils.py:37)."""
+    wavio = pkg("wavio")
+    rs = np.random.RandomState(0)
+    x = (rs.randn(7, 4000) * 0.1).astype(np.float32)
+    names = []
+    for c in range(7):
+        p = tmp_path / f"ch{c}.wav"
+        wavio.write_wav(p, x[c], 16000, max_norm=False)
+        names.append(str(p))
+    mix, sr = wavio.load_audio(names, is_mc=True)
+    assert mix.shape == (1, 4000, 7) and sr == 16000 and mix.dtype == np.float32
+    assert np.abs(mix[0].T - x).max() <= 1.0 / 32767 + 1e-7
+    import scipy.io.wavfile as wf   # the pipeline's other reader (utils/audio_utils.py:23-31) parses our files
+    sr2, y = wf.read(names[3])
+    assert sr2 == 16000 and y.dtype == np.int16 and np.array_equal(y, np.rint(x[3].astype(np.float64) * 32767).astype(np.int16))
+    wavio.write_wav(tmp_path / "n.wav", x[0] * 3.0)           # peak normalisation to 0.99
+    y, _ = wavio.read_wav(tmp_path / "n.wav")
+    assert abs(np.abs(y).max() - 0.99) < 1e-3
+    m1, _ = wavio.load_audio(names[:1], is_mc=False)
+    assert m1.shape == (1, 4000, 1)
+    # pass_through_ch0 / cache short-circuits of css_inference (css.py:73-82) need no GPU
+    import pandas as pd
+    css = pkg("css")
+    session = pd.Series({"wav_file_names": names, "session_id": "S1", "is_mc": True})
+    out = css.css_inference(str(tmp_path), "unused", session, css.CssCfg(pass_through_ch0=True), False)
+    assert out["sep_wav_file_names"] == names[:1] and "sep_wav_file_names" not in session
+    d = tmp_path / "css_inference" / "S1"
+    d.mkdir(parents=True)
+    for i in range(3):
+        wavio.write_wav(d / f"sep_stream{i}.wav", x[i])
+    out = css.css_inference(str(tmp_path), "unused", session, css.CssCfg(), True)
+    assert [os.path.basename(str(p)) for p in out["sep_wav_file_names"]] == [f"sep_stream{i}.wav" for i in range(3)]

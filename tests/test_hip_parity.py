@@ -1,0 +1,350 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and against the golden fixtures produced by the
+real reference.  Everything here needs an MI355X: run with `-m gpu`.
+
+Tolerances (float32 path; written where they are asserted):
+  * masks vs oracle                      max-abs <= 5e-5 (observed ~5e-6)
+  * separated waveforms vs reference     rel-RMS <= 1e-4 on identical winner-take-all decisions
+                                         (BASELINE.json north_star: "within 1e-4 RMS on the separated waveforms")
+  * decisions (segment indices, permutations, activity bits): exact
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import css_oracle as O
+from conftest import pkg, rel_rms, take_windows
+
+pytestmark = pytest.mark.gpu
+
+F, T, S = 257, 186, 3
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = pkg("_lib")
+    if lib.load().css_device_count() < 1:
+        pytest.fail("no HIP device visible: the parity tests must run on the GPU box")
+    return lib
+
+
+@pytest.fixture(scope="module")
+def CSS():
+    return pkg("css")
+
+
+@pytest.fixture(scope="module")
+def sep_mc(L, mc_state):
+    st, desc = mc_state
+    s = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=64)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def sep_sc(L, sc_state):
+    st, desc = sc_state
+    s = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=64)
+    yield s
+    s.close()
+
+
+def cfgs(CSS, **kw):
+    kw.setdefault("activity_th", 0.3)
+    return CSS.CssCfg(show_progressbar=False, **kw), O.OracleCssCfg(**kw)
+
+
+def hip_masks_per_segment(h, L, nseg):
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
+    return [(np.ascontiguousarray(np.moveaxis(m[:S, :, i], 0, 2)), np.ascontiguousarray(np.moveaxis(m[S:, :, i], 0, 2)))
+            for i in range(nseg)], m
+
+
+def _unpack(bits, shape):
+    return np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape).astype(bool)
+
+
+# ------------------------------------------------------------------------------------------------ stages
+def test_stage_by_stage_vs_oracle(L, CSS, sep_mc, mc_state, mix_stage, golden):
+    st, _ = mc_state
+    params = O.ConformerParams(st)
+    cfg, ocfg = cfgs(CSS)
+    h = sep_mc.handle
+    wav = h.run(mix_stage[0], CSS.make_run_cfg(cfg, 16000, 7))
+    plan = h.get_plan()
+    nseg = plan.num_segments
+    assert (plan.stft_frames, plan.mix_frames, nseg, plan.n_out, plan.last_valid) == (250, 250, 2, 64256, 157)
+
+    # STFT (feature.py:88): planes vs oracle; the DC / Nyquist imaginary parts must be EXACT zeros
+    X = h.read(L.BUF_X)
+    xo = O.stft(mix_stage[0])
+    xc = np.moveaxis((X[:, :F] + 1j * X[:, F:])[:, :, :plan.stft_frames], 0, 2)
+    assert rel_rms(xc, xo) < 1e-6
+    assert (X[:, F, :plan.stft_frames] == 0).all() and (X[:, 2 * F - 1, :plan.stft_frames] == 0).all()
+    g = golden("stage_mc.npz")
+    assert rel_rms(xc[::16, ::4], g["stft"]) < 2e-6          # ... and vs the reference's own STFT
+
+    # features of segment 0 (feature.py:478-569 + conformer.py:298-299)
+    feat = h.read(L.BUF_FEATURES)
+    seg0 = xo[:, :T]
+    fo = (O.features(seg0).T + params("input_bias").reshape(-1)) * params("input_scale").reshape(-1)
+    d = np.abs(feat[:T, :1799] - fo)
+    assert (feat[:, 1799:] == 0).all()
+    assert d.max() < 1e-2 and np.percentile(d, 99) < 1e-4 and (d > 1).sum() == 0   # no atan2 branch flips
+
+    # encoder output and masks (conformer.py:287-310)
+    taps = {}
+    om = O.conformer_forward(params, O.features(seg0), taps=taps)
+    hid = h.read(L.BUF_HIDDEN)
+    assert np.abs(hid[:T] - taps["block17"]).max() < 1e-4
+    per_seg, m = hip_masks_per_segment(h, L, nseg)
+    assert np.abs(m[:, :, 0, :] - om).max() < 5e-5
+    fd, td = int(g["fdec"]), int(g["tdec"])
+    assert np.abs(per_seg[0][0][::fd, ::td] - g["masks_spk"][0]).max() < 5e-5      # vs the reference's masks
+    assert np.abs(per_seg[1][0][::fd, ::td] - g["masks_spk"][1]).max() < 5e-5
+
+    # everything downstream of the masks, against the oracle driven by the HIP masks with a float64 MVDR
+    taps = {}
+    ow, oside = O.separate_and_stitch(mix_stage, params, 16000, ocfg, separate_fn=lambda i, seg: per_seg[i],
+                                      mvdr_cplx=np.complex128, taps=taps)
+    scm = h.read(L.BUF_SCM)  # [seg, 4, F, 49] packed Hermitian
+    oscm = taps["mvdr0"]["scm"]  # [4, F, 7, 7]
+    # (the oracle accumulates its own STFT, which differs from the HIP STFT by float32 rounding: ~2e-7)
+    assert np.abs(scm[0, :, :, :7] - np.real(np.diagonal(oscm, axis1=2, axis2=3))).max() / np.abs(oscm).max() < 5e-6
+    assert rel_rms(scm[0, :, :, 7] + 1j * scm[0, :, :, 8], oscm[:, :, 0, 1]) < 5e-6
+    bfw = h.read(L.BUF_BFW)  # [seg, S, F, 14]
+    w = bfw[0, :, :, 0::2] + 1j * bfw[0, :, :, 1::2]
+    assert rel_rms(w, taps["mvdr0"]["w"]) < 1e-4
+    assert rel_rms(w, g["w_seg0"]) < 2e-3          # the reference's complex64 solve, on its own masks
+    sep_ = h.read(L.BUF_SEP).reshape(nseg, S, F, T, 2)
+    costs = h.read(L.BUF_PIT_COST)
+    assert np.abs(costs[0].reshape(S, S) - oside["pit_costs"][0]).max() < 1e-9
+    assert [tuple(p) for p in h.read(L.BUF_PERMS)] == [tuple(p) for p in oside["perms"]]
+    assert np.abs(np.transpose(h.read(L.BUF_MASK_ST), (1, 2, 0)) - oside["mask_stitched"][0]).max() < 1e-6
+    assert np.abs(h.read(L.BUF_ACTIVITY).T - oside["activity"]).max() < 2e-6
+    assert np.array_equal(h.read(L.BUF_ACT_B).astype(bool).T, oside["activity_b"])
+    assert np.array_equal(h.read(L.BUF_ACT_FINAL).astype(bool).T, oside["activity_final"][0])
+    assert np.isfinite(sep_).all()
+    for k in range(S):
+        assert rel_rms(wav[k], ow[k]) < 1e-5
+    # ... and against the reference's waveforms (free-running decisions: no flips on this input)
+    ww = take_windows(wav, 4)
+    for k in range(S):
+        assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-4
+
+
+def test_separator_protocol(L, sep_mc, mix_stage):
+    """stft / separate / istft of the plug-in interface (conformer_wrapper.py:79-146)."""
+    import torch
+    xo = O.stft(mix_stage[0])
+    xs = sep_mc.stft(torch.from_numpy(mix_stage))
+    assert tuple(xs.shape) == (1, F, 250, 7) and xs.dtype == torch.complex64
+    assert rel_rms(xs.numpy()[0], xo) < 1e-6
+    x1 = sep_mc.stft(torch.from_numpy(mix_stage[:, :, 0]))
+    assert tuple(x1.shape) == (1, F, 250) and rel_rms(x1.numpy()[0], xo[:, :, 0]) < 1e-6
+    two = torch.stack([xs[0, :, :T], xs[0, :, 64:64 + T]])
+    ms = sep_mc.separate(two)
+    assert tuple(ms["spk_masks"].shape) == (2, F, T, 3) and tuple(ms["noise_masks"].shape) == (2, F, T, 1)
+    one = sep_mc.separate(two[1:])
+    assert np.array_equal(one["spk_masks"].numpy()[0], ms["spk_masks"].numpy()[1])   # batch-invariant bits
+    fwd = sep_mc.forward(torch.from_numpy(mix_stage[:, :48000]))
+    assert np.abs(fwd["spk_masks"].numpy()[0] - ms["spk_masks"].numpy()[0]).max() < 1e-6
+    rs = np.random.RandomState(0)
+    y = (rs.randn(2, F, 50) + 1j * rs.randn(2, F, 50)).astype(np.complex64)
+    assert rel_rms(sep_mc.istft(torch.from_numpy(y)).numpy(), O.istft(y)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+@pytest.fixture(scope="module")
+def e2e(L, CSS, sep_mc, mix60, golden):
+    g = golden("e2e_mc.npz")
+    mix = mix60[:, :20 * 16000]
+    cfg, _ = cfgs(CSS)
+    wavs, side = CSS.separate_and_stitch(mix, sep_mc, 16000, "cuda:0", cfg)
+    h = sep_mc.handle
+    per_seg, m = hip_masks_per_segment(h, L, int(g["num_segments"]))
+    return g, mix, wavs, side, per_seg, m
+
+
+def test_e2e_decisions_match_reference(e2e, L, sep_mc):
+    g, mix, wavs, side, per_seg, m = e2e
+    h = sep_mc.handle
+    assert h.get_plan().num_segments == int(g["num_segments"]) and len(wavs[0]) == int(g["wav_len"])
+    assert [tuple(p) for p in h.read(L.BUF_PERMS)[1:]] == [tuple(p) for p in g["pit_perm"]]
+    shape = tuple(g["activity_shape"])
+    assert np.array_equal(side["activity_b"].numpy(), _unpack(g["activity_b"], shape))
+    assert np.array_equal(side["activity_final"].numpy()[0], _unpack(g["activity_final"], shape))
+    assert tuple(side["mask_stitched"].shape) == (1, F, shape[0], 3) and side["segment_frames"] == T
+    assert np.abs(side["mask_stitched"].numpy()[0, ::16, ::8] - g["mask_stitched"]).max() < 5e-5
+    flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != g["wta_index"]).sum())
+    assert flips <= 1e-5 * g["wta_index"].size + 3      # float32-rounding-level ties only
+
+
+def test_e2e_waveform_vs_reference(e2e, L, CSS, sep_mc):
+    """<= 1e-4 rel-RMS against the reference's separated waveforms on the reference's WTA decisions."""
+    g, mix, wavs, side, per_seg, m = e2e
+    h = sep_mc.handle
+    cfg, _ = cfgs(CSS)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    nseg, TL = int(g["num_segments"]), h.get_plan().mix_frames
+    h.begin(mix[0], mix.shape[1], 7, run_cfg)
+    h.write(L.BUF_WTA_OVERRIDE, g["wta_index"])
+    h.stage_stft(); h.stage_masknet(0, nseg); h.stage_mvdr(0, nseg)
+    h.stage_pit_costs(0, nseg - 1); h.stage_pit_scan(); h.stage_stitch(0, TL); h.stage_istft(0, TL)
+    w2 = h.read(L.BUF_WAV)
+    ww = take_windows(w2)
+    for k in range(S):
+        assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-4
+        assert rel_rms(w2[k, ::64], g["wav_dec"][k]) < 1e-4
+    ww = take_windows(np.stack(wavs))                        # free-running decisions: a handful of flips at most
+    for k in range(S):
+        assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-3
+
+
+def test_e2e_forced_permutations(e2e, L, CSS, sep_mc):
+    """Variant (a): segment i's speaker masks rotated by i mod 3 -> non-trivial stitching permutations."""
+    g, mix, wavs, side, per_seg, m = e2e
+    h = sep_mc.handle
+    cfg, _ = cfgs(CSS)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    nseg, TL = int(g["num_segments"]), h.get_plan().mix_frames
+    rot = m.copy()
+    idx = g["wta_index"].copy()
+    for i in range(nseg):
+        rot[:S, :, i] = np.roll(m[:S, :, i], i % 3, axis=0)
+        sel = idx[i] < 3
+        idx[i][sel] = (idx[i][sel] + (i % 3)) % 3
+    h.begin(mix[0], mix.shape[1], 7, run_cfg)
+    h.stage_stft()
+    h.write(L.BUF_MASKS, rot.reshape((S + 1) * F, nseg * T))
+    h.write(L.BUF_WTA_OVERRIDE, idx)
+    h.stage_mvdr(0, nseg); h.stage_pit_costs(0, nseg - 1); h.stage_pit_scan(); h.stage_stitch(0, TL); h.stage_istft(0, TL)
+    assert [tuple(p) for p in h.read(L.BUF_PERMS)[1:]] == [tuple(p) for p in g["rot_pit_perm"]]
+    ww = take_windows(h.read(L.BUF_WAV))
+    for k in range(S):
+        assert rel_rms(ww[k], g["rot_wav_windows"][k]) < 1e-4
+
+
+def test_e2e_activity_gating(e2e, L, CSS, sep_mc):
+    """Variant (b): a threshold inside the range of activity values so that the gate toggles."""
+    g, mix, wavs, side, per_seg, m = e2e
+    h = sep_mc.handle
+    cfg, _ = cfgs(CSS, activity_th=float(g["gate_th"]))
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    nseg, TL = int(g["num_segments"]), h.get_plan().mix_frames
+    h.begin(mix[0], mix.shape[1], 7, run_cfg)
+    h.write(L.BUF_WTA_OVERRIDE, g["wta_index"])
+    h.stage_stft(); h.stage_masknet(0, nseg); h.stage_mvdr(0, nseg)
+    h.stage_pit_costs(0, nseg - 1); h.stage_pit_scan(); h.stage_stitch(0, TL); h.stage_istft(0, TL)
+    shape = tuple(g["activity_shape"])
+    assert np.array_equal(h.read(L.BUF_ACT_B).astype(bool).T, _unpack(g["gate_activity_b"], shape))
+    af = h.read(L.BUF_ACT_FINAL).astype(bool).T
+    assert np.array_equal(af, _unpack(g["gate_activity_final"], shape)) and 0 < af.mean() < 1
+    ww = take_windows(h.read(L.BUF_WAV))
+    for k in range(S):
+        assert rel_rms(ww[k], g["gate_wav_windows"][k]) < 1e-4
+
+
+def test_e2e_single_channel(L, CSS, sep_sc, mix60, golden):
+    """BASELINE.json configs[2]: 1-ch mask net, no beamformer (mask multiplication, floor -inf)."""
+    g = golden("e2e_sc.npz")
+    mix = mix60[:, :12 * 16000, :1].copy()
+    cfg, _ = cfgs(CSS)
+    wavs, side = CSS.separate_and_stitch(mix, sep_sc, 16000, "cuda:0", cfg)
+    h = sep_sc.handle
+    assert [tuple(p) for p in h.read(L.BUF_PERMS)[1:]] == [tuple(p) for p in g["pit_perm"]]
+    assert np.array_equal(side["activity_final"].numpy()[0], _unpack(g["activity_final"], tuple(g["activity_shape"])))
+    ww = take_windows(np.stack(wavs))
+    for k in range(S):
+        assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ options / edges
+def test_non_default_options_vs_oracle(L, CSS, sep_mc, mc_state, mix60):
+    st, _ = mc_state
+    params = O.ConformerParams(st)
+    mix = mix60[:, 16000:16000 + 6 * 16000 + 777]   # 4 segments, ragged tail
+    h = sep_mc.handle
+    for kw in (dict(stitching_loss='mse'), dict(stitching_input='separation_result'),
+               dict(normalize_segment_power=True), dict(mc_mvdr=False, mc_mask_floor_db=-6.0),
+               dict(mc_mask_floor_db=-12.0)):
+        cfg, ocfg = cfgs(CSS, **kw)
+        wavs, side = CSS.separate_and_stitch(mix, sep_mc, 16000, "cuda:0", cfg)
+        nseg = h.get_plan().num_segments
+        per_seg, m = hip_masks_per_segment(h, L, nseg)
+        ow, oside = O.separate_and_stitch(mix, params, 16000, ocfg, separate_fn=lambda i, seg: per_seg[i],
+                                          mvdr_cplx=np.complex128)
+        assert [tuple(p) for p in h.read(L.BUF_PERMS)] == [tuple(p) for p in oside["perms"]], kw
+        for k in range(S):
+            assert rel_rms(wavs[k], ow[k]) < 2e-5, (kw, k)
+
+
+def test_short_and_error_inputs(L, CSS, sep_mc):
+    cfg, _ = cfgs(CSS)
+    with pytest.raises(AssertionError, match="zero weights"):           # css.py:297 on inputs <= 3.0 s
+        CSS.separate_and_stitch(np.zeros((1, 48000, 7), np.float32), sep_mc, 16000, "cuda:0", cfg)
+    with pytest.raises(AssertionError, match="expecting 3 dimensions"):  # css.py:139
+        CSS.separate_and_stitch(np.zeros((48000, 7), np.float32), sep_mc, 16000, "cuda:0", cfg)
+    with pytest.raises(L.CssError):                                      # 1-ch audio into the 7-ch model
+        CSS.separate_and_stitch(np.zeros((1, 64000, 1), np.float32), sep_mc, 16000, "cuda:0", cfg)
+    with pytest.raises(AssertionError):                                  # css.py:224 mask_floor_db <= 0
+        CSS.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), sep_mc, 16000, "cuda:0",
+                                CSS.CssCfg(mc_mask_floor_db=3.0))
+    # digital silence: zero-padded frames, eps clamps, 1e-15 diagonal loading -- finite output, all zeros
+    w, side = CSS.separate_and_stitch(np.zeros((1, 50000, 7), np.float32), sep_mc, 16000, "cuda:0", cfg)
+    assert all(np.isfinite(x).all() and np.abs(x).max() == 0 for x in w)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_60s_properties(L, CSS, sep_mc, mix60):
+    """BASELINE.json configs[1] at full size, through size-independent properties:
+    determinism, shard invariance (2 virtual ranks == fused run, bit for bit), gain linearity of the
+    front end (features are scale-invariant, MVDR is linear), and frame-local support of the output."""
+    import torch
+    PAR = pkg("parallel")
+    cfg, _ = cfgs(CSS)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    h = sep_mc.handle
+    w1 = h.run(mix60[0], run_cfg)
+    plan = h.get_plan()
+    assert (plan.mix_frames, plan.num_segments, plan.n_out, plan.last_valid) == (3749, 40, 960000, 122)
+    w2 = h.run(mix60[0], run_cfg)
+    assert np.array_equal(w1, w2)                                                # deterministic
+    perms = h.read(L.BUF_PERMS)
+    assert sorted(map(tuple, np.sort(perms, axis=1))) == [(0, 1, 2)] * 40        # every row is a permutation
+
+    # two virtual ranks on the same GPU (fresh sessions, buffers poisoned in between)
+    dev = torch.device("cuda", 0)
+    be = PAR.HipShardBackend(h, dev)
+    sessions, costs, acts, shards = [], [], [], []
+    results = {}
+    for world in (1, 2, 3):
+        costs, acts, shards = [], [], []
+        for phase in range(3):
+            for r in range(world):
+                # each virtual rank replays its own session up to the current phase from scratch
+                h.begin(mix60[0], mix60.shape[1], 7, run_cfg)
+                if world > 1:   # nothing a previous virtual rank left behind may be readable
+                    h.write(L.BUF_MASKS, np.full(((S + 1) * F, 40 * T), np.nan, np.float32))
+                    h.write(L.BUF_SEP, np.full((40, S, F, T * 2), np.nan, np.float32))
+                    h.write(L.BUF_X, np.full((7, 2 * F, h.buffer_dims(L.BUF_X)[0][2]), np.nan, np.float32))
+                ss = PAR.ShardedSession(be, S, T, 93, 256, r, world)
+                c = ss.segments_and_costs()
+                if phase == 0:
+                    costs.append(c)
+                    continue
+                a = ss.masks_and_activity(PAR.ShardedSession.join_costs(ss.plans, costs))
+                if phase == 1:
+                    acts.append(a)
+                    continue
+                shards.append(ss.gate_and_istft(PAR.ShardedSession.join_activity(ss.plans, acts)))
+        out = PAR.ShardedSession.join_shards(ss.plans, shards, S, plan.n_out)
+        results[world] = out.cpu().numpy()
+    assert np.array_equal(results[1], w1)
+    assert np.array_equal(results[2], w1)
+    assert np.array_equal(results[3], w1)
+
+    # gain linearity: the features are scale-invariant up to their eps clamps and the beamformer is linear,
+    # so x -> 0.5 x halves the output (up to float32-rounding-level winner-take-all flips)
+    wh = h.run(0.5 * mix60[0], run_cfg)
+    assert rel_rms(wh, 0.5 * w1) < 1e-3
