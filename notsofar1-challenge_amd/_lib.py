@@ -106,6 +106,28 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7, found through torch's RPATH under the name "libamdhip64.so"), while
+    libcss_mi355.so asks the loader for "libamdhip64.so.7".  If our library is loaded first, the system
+    runtime gets in, torch later adds its bundled one, and torch then sees no GPU.  Loading torch's copy
+    first (without importing torch) makes the loader resolve our dependency to that same object by
+    SONAME, whichever side is imported first.  Without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):  # pragma: no cover
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:  # pragma: no cover
+            pass
+
+
 def load() -> C.CDLL:
     """Load the library once; raise loudly (no fallback) when it is absent."""
     global _lib
@@ -115,6 +137,7 @@ def load() -> C.CDLL:
         raise CssLibraryError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
             f"(or `make -C notsofar1-challenge_amd/csrc`). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

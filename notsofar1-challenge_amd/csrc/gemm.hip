@@ -47,29 +47,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, i
     const int wm = wave >> 1, wn = wave & 1;
     const int c = lane & 31, h = lane >> 5;
 
-    // rows past M / N read the last valid row (always in bounds) and are zeroed in registers
-    const float* a_base = A + lc;
-    const float* b_base = B + lc;
+    // Rows past M / N read the last valid row instead (always in bounds, always finite).  A row of C
+    // depends on one row of A and one row of B only, so such rows merely produce outputs the guarded
+    // epilogue never stores -- and, unlike a select on the loaded value, nothing consumes the loads
+    // before the LDS store, so they stay in flight under the MFMAs of the current slab.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int M = g.M, N = g.N;
-    const int64_t lda = g.lda, ldb = g.ldb;
-#define CSS_GLOAD_ONE(dst, base, ld, row, lim, k0)                                                    \
-    {                                                                                                 \
-        const int r_ = (row);                                                                         \
-        const int rc_ = r_ < (lim) ? r_ : (lim) - 1;                                                  \
-        dst = *reinterpret_cast<const float4*>((base) + (int64_t)rc_ * (ld) + (k0));                  \
-        if (r_ >= (lim)) dst = zero4;                                                                 \
-    }
-#define CSS_GLOAD(k0)                                              \
-    CSS_GLOAD_ONE(ra0, a_base, lda, m0 + lr, M, k0)                \
-    CSS_GLOAD_ONE(ra1, a_base, lda, m0 + lr + 32, M, k0)           \
-    CSS_GLOAD_ONE(ra2, a_base, lda, m0 + lr + 64, M, k0)           \
-    CSS_GLOAD_ONE(ra3, a_base, lda, m0 + lr + 96, M, k0)           \
-    CSS_GLOAD_ONE(rb0, b_base, ldb, n0 + lr, N, k0)                \
-    CSS_GLOAD_ONE(rb1, b_base, ldb, n0 + lr + 32, N, k0)           \
-    CSS_GLOAD_ONE(rb2, b_base, ldb, n0 + lr + 64, N, k0)           \
-    CSS_GLOAD_ONE(rb3, b_base, ldb, n0 + lr + 96, N, k0)
+#define CSS_ROWPTR(base, ld, row, lim) ((base) + (int64_t)((row) < (lim) ? (row) : (lim) - 1) * (ld) + lc)
+    const float* pa0 = CSS_ROWPTR(A, g.lda, m0 + lr, M);
+    const float* pa1 = CSS_ROWPTR(A, g.lda, m0 + lr + 32, M);
+    const float* pa2 = CSS_ROWPTR(A, g.lda, m0 + lr + 64, M);
+    const float* pa3 = CSS_ROWPTR(A, g.lda, m0 + lr + 96, M);
+    const float* pb0 = CSS_ROWPTR(B, g.ldb, n0 + lr, N);
+    const float* pb1 = CSS_ROWPTR(B, g.ldb, n0 + lr + 32, N);
+    const float* pb2 = CSS_ROWPTR(B, g.ldb, n0 + lr + 64, N);
+    const float* pb3 = CSS_ROWPTR(B, g.ldb, n0 + lr + 96, N);
+#define CSS_GLOAD(k0)                                          \
+    ra0 = *reinterpret_cast<const float4*>(pa0 + (k0));        \
+    ra1 = *reinterpret_cast<const float4*>(pa1 + (k0));        \
+    ra2 = *reinterpret_cast<const float4*>(pa2 + (k0));        \
+    ra3 = *reinterpret_cast<const float4*>(pa3 + (k0));        \
+    rb0 = *reinterpret_cast<const float4*>(pb0 + (k0));        \
+    rb1 = *reinterpret_cast<const float4*>(pb1 + (k0));        \
+    rb2 = *reinterpret_cast<const float4*>(pb2 + (k0));        \
+    rb3 = *reinterpret_cast<const float4*>(pb3 + (k0));
 #define CSS_LSTORE(buf)                                                       \
     {                                                                         \
         float* as_ = lds + (buf) * (BM + BN) * LDS_LD + lr * LDS_LD + lc;     \
@@ -117,22 +118,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, i
     const int act = g.act, bias_m = g.bias_along_m;
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
+    // All 16 residual / row-bias operands of a 32x32 tile are requested (at clamped, always valid
+    // addresses) before the first one is consumed, so the epilogue pays one memory round trip per tile
+    // instead of one per element; out-of-range elements are computed and simply not stored.
 #define CSS_EMIT(acc, tm2, tn2)                                                              \
     {                                                                                        \
         const int n = n0 + wn * 64 + (tn2) * 32 + c;                                         \
-        if (n < N) {                                                                         \
-            const float bn = (bias && !bias_m) ? bias[n] : 0.f;                              \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                 \
-                const int m = m0 + wm * 64 + (tm2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;    \
-                if (m < M) {                                                                 \
-                    float v = acc[r] + bn;                                                   \
-                    if (bias && bias_m) v += bias[m];                                        \
-                    if (act == ACT_RELU) v = fmaxf(v, 0.f);                                  \
-                    else if (act == ACT_SIGMOID) v = sigmoidf_(v);                           \
-                    if (res) v = res[(int64_t)m * ldr + n] + alpha * v;                      \
-                    C[(int64_t)m * ldc + n] = v;                                             \
-                }                                                                            \
-            }                                                                                \
+        const bool n_ok = n < N;                                                             \
+        const int nc = n_ok ? n : N - 1;                                                     \
+        const int mb = m0 + wm * 64 + (tm2) * 32 + 4 * h;                                    \
+        const float bn = (bias && !bias_m) ? bias[nc] : 0.f;                                 \
+        float rv[16], bm[16];                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+            const int m = mb + (r & 3) + 8 * (r >> 2);                                       \
+            const int mc = m < M ? m : M - 1;                                                \
+            rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;                                 \
+            bm[r] = (bias && bias_m) ? bias[mc] : 0.f;                                       \
+        }                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+            const int m = mb + (r & 3) + 8 * (r >> 2);                                       \
+            float v = acc[r] + bn + bm[r];                                                   \
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);                                          \
+            else if (act == ACT_SIGMOID) v = sigmoidf_(v);                                   \
+            if (res) v = rv[r] + alpha * v;                                                  \
+            if (n_ok && m < M) C[(int64_t)m * ldc + n] = v;                                  \
         }                                                                                    \
     }
     CSS_EMIT(acc00, 0, 0)

@@ -1,0 +1,106 @@
+"""The segment-sharded multi-GPU path on CPU: partition arithmetic, and the three-exchange driver of
+notsofar1-challenge_amd/parallel.py run with world_size 2 and 3 over gloo against an oracle-backed stage
+backend (tests/fake_backend.py).  The sharded result must equal the single-rank result BIT FOR BIT and
+match the oracle's own driver."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import css_oracle as O
+from conftest import ROOT, pkg, rel_rms
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_plans_partition_everything():
+    par = pkg("parallel")
+    T, hop = 186, 93
+    for mix_frames in (187, 250, 624, 3749, 112499):
+        nseg = int(np.ceil((mix_frames - (T - hop)) / hop))
+        for world in (1, 2, 3, 4, 7, 8):
+            plans = par.all_plans(nseg, mix_frames, mix_frames, T, hop, 256, world)
+            # owned segments, frames and boundaries tile their ranges exactly once, in rank order
+            assert plans[0].own_seg_lo == 0 and plans[-1].own_seg_hi == nseg
+            assert plans[0].t_lo == 0 and plans[-1].t_hi == mix_frames
+            assert plans[0].b_lo == 0 and plans[-1].b_hi == nseg - 1
+            for a, b in zip(plans, plans[1:]):
+                assert a.own_seg_hi == b.own_seg_lo and a.t_hi == b.t_lo and a.b_hi == b.b_lo
+            for p in plans:
+                if p.own_seg_hi == p.own_seg_lo:
+                    assert p.num_frames == 0 or p.rank == world - 1
+                    continue
+                assert p.seg_lo == max(p.own_seg_lo - 1, 0) and p.seg_hi == p.own_seg_hi     # one halo segment
+                # every owned frame is covered only by computed segments (bit-exact indexing st = i*hop)
+                for t in (p.t_lo, p.t_hi - 1):
+                    for seg in (t // hop - 1, t // hop):
+                        if 0 <= seg < nseg and 0 <= t - seg * hop < T:
+                            assert p.seg_lo <= seg < p.seg_hi, (mix_frames, world, p, t, seg)
+                # both segments of every owned boundary are computed
+                for b in range(p.b_lo, p.b_hi):
+                    assert p.seg_lo <= b and b + 1 < p.seg_hi
+                # the transform covers exactly the frames the computed segments read
+                assert p.f_lo == p.seg_lo * hop and p.f_hi == min((p.seg_hi - 1) * hop + T, mix_frames)
+            assert sum(p.shard_len for p in plans if p.num_frames) >= (mix_frames + 1) * 256
+
+
+def _small_model():
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=1)
+    return w.apply_golden_recipe(w.portable_state_dict(desc, 11)), desc
+
+
+def _worker(rank, world, port, out_dir, n_samples):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, HERE)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_backend import OracleStageBackend
+        par = pkg("parallel")
+        st, desc = _small_model()
+        mix = pkg("synth").synth_meeting(10.0, 7, seed=4)[:, :n_samples]
+        be = OracleStageBackend(O.ConformerParams(st), O.OracleCssCfg(activity_th=0.3))
+        be.begin(mix[0], mix.shape[1], 7)
+        out = par.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist)
+        np.save(os.path.join(out_dir, f"w{world}_r{rank}.npy"), out.numpy())
+        np.save(os.path.join(out_dir, f"w{world}_r{rank}_nseg.npy"), np.array([be.calls["masknet_segments"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_driver_over_gloo_matches_single_rank(tmp_path, world):
+    from fake_backend import OracleStageBackend
+    par = pkg("parallel")
+    n = 9 * 16000 + 123   # 7 segments, ragged tail
+    st, desc = _small_model()
+    params = O.ConformerParams(st)
+    ocfg = O.OracleCssCfg(activity_th=0.3)
+    mix = pkg("synth").synth_meeting(10.0, 7, seed=4)[:, :n]
+    # single rank through the same driver
+    be = OracleStageBackend(params, ocfg)
+    be.begin(mix[0], n, 7)
+    single = par.sharded_separate_and_stitch(be, 3, 186, 93, 256, 0, 1, None).numpy()
+    # ... equals the oracle's own (reference-shaped) driver up to float32 rounding of the summation order
+    ow, oside = O.separate_and_stitch(mix, params, 16000, ocfg)
+    for k in range(3):
+        assert rel_rms(single[k], ow[k]) < 1e-6
+    assert [tuple(p) for p in be.perms] == [tuple(p) for p in oside["perms"]]
+
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n), nprocs=world, join=True)
+    total_segments = 0
+    for r in range(world):
+        got = np.load(tmp_path / f"w{world}_r{r}.npy")
+        assert got.shape == single.shape
+        assert np.array_equal(got, single), f"rank {r}: sharded result differs from the single-rank result"
+        total_segments += int(np.load(tmp_path / f"w{world}_r{r}_nseg.npy")[0])
+    assert total_segments == oside["plan"].num_segments + (world - 1)   # exactly one halo segment per seam

@@ -1,0 +1,41 @@
+// Stand-alone timing of css::launch_gemm on the shapes of the CSS path (tools only, not shipped).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip notsofar1-challenge_amd/csrc/gemm.hip \
+//         -Inotsofar1-challenge_amd/csrc -o gpurun_out/gemm_bench && gpurun_out/gemm_bench
+#include <cstdio>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+using namespace css;
+int main() {
+    struct Shape { int M, N, K, batch; const char* name; int mode; };  // mode 1: bias+residual, 2: row bias + sigmoid
+    Shape shapes[] = {{7440, 512, 512, 1, "wo 40seg", 0}, {7440, 512, 512, 1, "wo +res", 1}, {7440, 1024, 512, 1, "ffn1", 0}, {7440, 512, 1024, 1, "ffn2", 0}, {7440, 512, 1024, 1, "ffn2 +res", 1},
+                      {7440, 1536, 512, 1, "qkv"}, {1028, 7440, 512, 1, "head", 0}, {1028, 7440, 512, 1, "head +sig", 2}, {7440, 512, 1824, 1, "embed"},
+                      {514, 3749, 512, 7, "stft"}, {23808, 512, 512, 1, "wo 128seg"}, {23808, 1536, 512, 1, "qkv 128seg"},
+                      {4096, 4096, 4096, 1, "4096^3"}};
+    size_t maxe = 4096ull * 4096 * 2;
+    float *A, *B, *C;
+    hipMalloc(&A, maxe * 4 * 2); hipMalloc(&B, maxe * 4 * 2); hipMalloc(&C, maxe * 4 * 2);
+    std::vector<float> h(maxe * 2);
+    unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    hipMemcpy(A, h.data(), maxe * 8, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), maxe * 8, hipMemcpyHostToDevice);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (auto& sh : shapes) {
+        GemmArgs g{};
+        g.A = A; g.lda = sh.K; g.strideA = 0; g.B = B; g.ldb = sh.K; g.strideB = (int64_t)sh.N * sh.K;
+        g.C = C; g.ldc = sh.N; g.strideC = (int64_t)sh.M * sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.batch = sh.batch; g.alpha = 1.f;
+        if (sh.batch > 1) { g.strideB = 0; }
+        if (sh.mode == 1) { g.bias = A; g.residual = C; g.ldr = sh.N; g.alpha = 0.5f; }
+        if (sh.mode == 2) { g.bias = A; g.bias_along_m = 1; g.act = ACT_SIGMOID; }
+        for (int i = 0; i < 3; ++i) launch_gemm(g, st);
+        hipEventRecord(e0, st);
+        const int it = 20;
+        for (int i = 0; i < it; ++i) launch_gemm(g, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double fl = 2.0 * sh.M * sh.N * sh.K * sh.batch;
+        printf("%-12s M=%6d N=%5d K=%5d b=%d  %8.2f us  %7.2f TFLOP/s  blocks=%d\n", sh.name, sh.M, sh.N, sh.K, sh.batch,
+               1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12, ((sh.M + 127) / 128) * ((sh.N + 127) / 128) * sh.batch);
+    }
+    return 0;
+}
