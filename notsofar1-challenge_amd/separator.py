@@ -89,6 +89,13 @@ def _torch():
     return torch
 
 
+def _like(out, ref):
+    """Return `out` on the device of the tensor the caller passed in (the reference driver mixes the
+    separator's outputs with tensors it moved to `device` itself, css.py:198,216,227)."""
+    dev = getattr(ref, "device", None)
+    return out.to(dev) if dev is not None and str(dev) != "cpu" else out
+
+
 def _device_index(device) -> int:
     if device is None:
         return 0
@@ -169,7 +176,7 @@ class HipSeparator:
         out = np.stack(outs)  # [B, F, T', C]
         if squeeze:
             out = out[..., 0]
-        return torch.from_numpy(out)
+        return _like(torch.from_numpy(out), s)
 
     def separate(self, stft):
         """complex [Batch, F, T, Mics] / [Batch, F, T] -> {'spk_masks': [B,F,T,S], 'noise_masks': [B,F,T,1]}
@@ -188,7 +195,7 @@ class HipSeparator:
         m = self.handle.separate_host(planes, b)  # [(S+1)F, B*T]
         nm = self.desc.num_spks + self.desc.num_nois
         m = m.reshape(nm, f, b, t).transpose(2, 1, 3, 0)  # [B, F, T, S+1]
-        m = torch.from_numpy(np.ascontiguousarray(m))
+        m = _like(torch.from_numpy(np.ascontiguousarray(m)), stft)
         return {'spk_masks': m[..., :self.desc.num_spks], 'noise_masks': m[..., self.desc.num_spks:]}
 
     def istft(self, stft):
@@ -197,7 +204,7 @@ class HipSeparator:
         x = stft.detach().cpu().numpy() if hasattr(stft, "detach") else np.asarray(stft)
         assert np.iscomplexobj(x) and x.ndim == 3
         planes = np.concatenate([x.real, x.imag], axis=1).astype(np.float32)
-        return torch.from_numpy(self.handle.istft_host(planes))
+        return _like(torch.from_numpy(self.handle.istft_host(planes)), stft)
 
     def forward(self, mix):
         """[Batch, T, Mics] time-domain mixture -> masks (conformer_wrapper.py:58-77)."""
