@@ -74,10 +74,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    # functional-test knobs (never used by the driver): CSS_BENCH_BACKEND=gloo exchanges through host memory,
+    # CSS_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (a 1-GPU box can then exercise the N > 1 code path)
+    backend = os.environ.get("CSS_BENCH_BACKEND", "nccl")
+    if os.environ.get("CSS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W = importlib.import_module("notsofar1_challenge_amd.weights")
     SYN = importlib.import_module("notsofar1_challenge_amd.synth")
@@ -105,7 +114,7 @@ def main():
     wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
-    be = PAR.HipShardBackend(h, dev)
+    be = PAR.HipShardBackend(h, dev, comm_dev)
 
     def step():
         if world == 1:
@@ -130,10 +139,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
+    if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
+        ref = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
+        h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, ref.data_ptr(), plan.n_out)
+        same = bool(torch.equal(ref.cpu(), out.cpu()))
+        log(f"[rank {rank}] sharded == fused single-GPU result: {same}")
+        assert same
 
     result = {
         "metric": "CSS real-time-factor (sep. audio sec/wall sec) on 7-ch 16 kHz",

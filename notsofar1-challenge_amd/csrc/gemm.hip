@@ -6,13 +6,19 @@
 // (feature.py:162 conv_transpose1d).  Exact float32 (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf
 // chain), which the 1e-4 waveform parity and the winner-take-all mask decisions need.
 //
-// Shape: 128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32, K slab 32,
-// register-staged double-buffered LDS.  LDS rows are padded to 36 floats so that ds_read_b128 of 16
-// consecutive rows hits 16 distinct 16-byte slots (9*row mod 16 is a bijection).
+// Shape: 128x128 block tile, K slab 32, register-staged double-buffered LDS, one barrier per slab.
+// Two wave layouts share the code (template WM = waves along M):
+//   WM = 2: 4 waves, each 64x64 = 2x2 MFMA tiles   (fewest LDS reads per MFMA)
+//   WM = 4: 8 waves, each 32x64 = 1x2 MFMA tiles   (two waves per SIMD from ONE block: when a launch
+//           has only ~1 block per CU, the second wave covers the other's barrier / LDS-latency bubbles)
+// LDS rows are padded to 36 floats so that ds_read_b128 of 16 consecutive rows hits 16 distinct 16-byte
+// slots (9*row mod 16 is a bijection).
 //
 // K permutation: within each group of 8 consecutive k the two lane halves of the MFMA take k = 4h+s
 // (h = lane>>5, s = MFMA step) instead of 2s+h, so each lane fetches its four A (and B) operands with
 // one 16-byte LDS read.  A and B use the same permutation, so the dot product is unchanged.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace css {
@@ -23,7 +29,40 @@ constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+// One 32x32 accumulator tile -> memory.  All 16 residual / row-bias operands are requested (at
+// clamped, always valid addresses) before the first one is consumed, so the epilogue pays one memory
+// round trip per tile instead of one per element; out-of-range elements are computed and not stored.
+__device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int M, int N, float* __restrict__ C,
+                                          int64_t ldc, const float* __restrict__ bias, int bias_m, int act,
+                                          const float* __restrict__ res, int64_t ldr, float alpha) {
+    const bool n_ok = n < N;
+    const int nc = n_ok ? n : N - 1;
+    const float bn = (bias && !bias_m) ? bias[nc] : 0.f;
+    float rv[16], bm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const int mc = m < M ? m : M - 1;
+        rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;
+        bm[r] = (bias && bias_m) ? bias[mc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + bn + bm[r];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+        if (res) v = rv[r] + alpha * v;
+        if (n_ok && m < M) C[(int64_t)m * ldc + n] = v;
+    }
+}
+
+template <int WM>
+__global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int THREADS = WM * 128;          // WM x 2 waves
+    constexpr int TM = (BM / WM) / 32;         // MFMA tiles along M per wave (2 or 1)
+    constexpr int LROWS = THREADS / 8;         // rows covered by one staging pass (32 or 64)
+    constexpr int NLD = BM / LROWS;            // staging passes per operand (4 or 2)
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
     // ---- XCD-aware tile mapping: consecutive tiles (which share an A row panel) go to one XCD/L2 ----
     const int n_tiles = tiles_m * tiles_n * g.batch;
@@ -41,51 +80,56 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, i
     float* __restrict__ C = g.C + (int64_t)bz * g.strideC;
 
     const int tid = threadIdx.x;
-    const int lr = tid >> 3;          // 0..31 : row within a 32-row group
+    const int lr = tid >> 3;          // row within a staging pass
     const int lc = (tid & 7) << 2;    // 0..28 : float offset within the K slab
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int c = lane & 31, h = lane >> 5;
+    const int M = g.M, N = g.N;
 
     // Rows past M / N read the last valid row instead (always in bounds, always finite).  A row of C
     // depends on one row of A and one row of B only, so such rows merely produce outputs the guarded
     // epilogue never stores -- and, unlike a select on the loaded value, nothing consumes the loads
     // before the LDS store, so they stay in flight under the MFMAs of the current slab.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int M = g.M, N = g.N;
 #define CSS_ROWPTR(base, ld, row, lim) ((base) + (int64_t)((row) < (lim) ? (row) : (lim) - 1) * (ld) + lc)
     const float* pa0 = CSS_ROWPTR(A, g.lda, m0 + lr, M);
-    const float* pa1 = CSS_ROWPTR(A, g.lda, m0 + lr + 32, M);
-    const float* pa2 = CSS_ROWPTR(A, g.lda, m0 + lr + 64, M);
-    const float* pa3 = CSS_ROWPTR(A, g.lda, m0 + lr + 96, M);
+    const float* pa1 = CSS_ROWPTR(A, g.lda, m0 + lr + LROWS, M);
+    const float* pa2 = CSS_ROWPTR(A, g.lda, m0 + lr + 2 * LROWS, M);   // passes 2, 3 only exist when NLD == 4
+    const float* pa3 = CSS_ROWPTR(A, g.lda, m0 + lr + 3 * LROWS, M);
     const float* pb0 = CSS_ROWPTR(B, g.ldb, n0 + lr, N);
-    const float* pb1 = CSS_ROWPTR(B, g.ldb, n0 + lr + 32, N);
-    const float* pb2 = CSS_ROWPTR(B, g.ldb, n0 + lr + 64, N);
-    const float* pb3 = CSS_ROWPTR(B, g.ldb, n0 + lr + 96, N);
-#define CSS_GLOAD(k0)                                          \
-    ra0 = *reinterpret_cast<const float4*>(pa0 + (k0));        \
-    ra1 = *reinterpret_cast<const float4*>(pa1 + (k0));        \
-    ra2 = *reinterpret_cast<const float4*>(pa2 + (k0));        \
-    ra3 = *reinterpret_cast<const float4*>(pa3 + (k0));        \
-    rb0 = *reinterpret_cast<const float4*>(pb0 + (k0));        \
-    rb1 = *reinterpret_cast<const float4*>(pb1 + (k0));        \
-    rb2 = *reinterpret_cast<const float4*>(pb2 + (k0));        \
-    rb3 = *reinterpret_cast<const float4*>(pb3 + (k0));
-#define CSS_LSTORE(buf)                                                       \
-    {                                                                         \
-        float* as_ = lds + (buf) * (BM + BN) * LDS_LD + lr * LDS_LD + lc;     \
-        float* bs_ = as_ + BM * LDS_LD;                                       \
-        *reinterpret_cast<float4*>(as_) = ra0;                                \
-        *reinterpret_cast<float4*>(as_ + 32 * LDS_LD) = ra1;                  \
-        *reinterpret_cast<float4*>(as_ + 64 * LDS_LD) = ra2;                  \
-        *reinterpret_cast<float4*>(as_ + 96 * LDS_LD) = ra3;                  \
-        *reinterpret_cast<float4*>(bs_) = rb0;                                \
-        *reinterpret_cast<float4*>(bs_ + 32 * LDS_LD) = rb1;                  \
-        *reinterpret_cast<float4*>(bs_ + 64 * LDS_LD) = rb2;                  \
-        *reinterpret_cast<float4*>(bs_ + 96 * LDS_LD) = rb3;                  \
+    const float* pb1 = CSS_ROWPTR(B, g.ldb, n0 + lr + LROWS, N);
+    const float* pb2 = CSS_ROWPTR(B, g.ldb, n0 + lr + 2 * LROWS, N);
+    const float* pb3 = CSS_ROWPTR(B, g.ldb, n0 + lr + 3 * LROWS, N);
+#undef CSS_ROWPTR
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define CSS_GLOAD(k0)                                              \
+    ra0 = *reinterpret_cast<const float4*>(pa0 + (k0));            \
+    ra1 = *reinterpret_cast<const float4*>(pa1 + (k0));            \
+    rb0 = *reinterpret_cast<const float4*>(pb0 + (k0));            \
+    rb1 = *reinterpret_cast<const float4*>(pb1 + (k0));            \
+    if constexpr (NLD == 4) {                                      \
+        ra2 = *reinterpret_cast<const float4*>(pa2 + (k0));        \
+        ra3 = *reinterpret_cast<const float4*>(pa3 + (k0));        \
+        rb2 = *reinterpret_cast<const float4*>(pb2 + (k0));        \
+        rb3 = *reinterpret_cast<const float4*>(pb3 + (k0));        \
+    }
+#define CSS_LSTORE(buf)                                                         \
+    {                                                                           \
+        float* as_ = lds + (buf) * (BM + BN) * LDS_LD + lr * LDS_LD + lc;       \
+        float* bs_ = as_ + BM * LDS_LD;                                         \
+        *reinterpret_cast<float4*>(as_) = ra0;                                  \
+        *reinterpret_cast<float4*>(as_ + LROWS * LDS_LD) = ra1;                 \
+        *reinterpret_cast<float4*>(bs_) = rb0;                                  \
+        *reinterpret_cast<float4*>(bs_ + LROWS * LDS_LD) = rb1;                 \
+        if constexpr (NLD == 4) {                                               \
+            *reinterpret_cast<float4*>(as_ + 2 * LROWS * LDS_LD) = ra2;         \
+            *reinterpret_cast<float4*>(as_ + 3 * LROWS * LDS_LD) = ra3;         \
+            *reinterpret_cast<float4*>(bs_ + 2 * LROWS * LDS_LD) = rb2;         \
+            *reinterpret_cast<float4*>(bs_ + 3 * LROWS * LDS_LD) = rb3;         \
+        }                                                                       \
     }
 
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // acc1x only used when TM == 2
     const int nk = g.K / BK;
     CSS_GLOAD(0)
     CSS_LSTORE(0)
@@ -93,24 +137,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, i
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { CSS_GLOAD((kt + 1) * BK) }
-        const float* as = lds + buf * (BM + BN) * LDS_LD + (wm * 64 + c) * LDS_LD + 4 * h;
+        const float* as = lds + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + c) * LDS_LD + 4 * h;
         const float* bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * 64 + c) * LDS_LD + 4 * h;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const float4 a0 = *reinterpret_cast<const float4*>(as + ch * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_LD + ch * 8);
             const float4 b0 = *reinterpret_cast<const float4*>(bs + ch * 8);
             const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * LDS_LD + ch * 8);
-#define CSS_MFMA4(e)                                                            \
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc00, 0, 0, 0);   \
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc01, 0, 0, 0);   \
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc10, 0, 0, 0);   \
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc11, 0, 0, 0);
-            CSS_MFMA4(x) CSS_MFMA4(y) CSS_MFMA4(z) CSS_MFMA4(w)
+            float4 a1 = a0;
+            if constexpr (TM == 2) a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_LD + ch * 8);
+#define CSS_MFMA_STEP(e)                                                                 \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc00, 0, 0, 0);            \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc01, 0, 0, 0);            \
+    if constexpr (TM == 2) {                                                             \
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc10, 0, 0, 0);        \
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc11, 0, 0, 0);        \
+    }
+            CSS_MFMA_STEP(x) CSS_MFMA_STEP(y) CSS_MFMA_STEP(z) CSS_MFMA_STEP(w)
+#undef CSS_MFMA_STEP
         }
         if (kt + 1 < nk) CSS_LSTORE(buf ^ 1)
         __syncthreads();
     }
+#undef CSS_GLOAD
+#undef CSS_LSTORE
 
     // ---- epilogue: bias, activation, scaled residual; 128-byte row segments per half wave ----
     const float* bias = g.bias;
@@ -118,43 +168,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, int tiles_m, i
     const int act = g.act, bias_m = g.bias_along_m;
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
-    // All 16 residual / row-bias operands of a 32x32 tile are requested (at clamped, always valid
-    // addresses) before the first one is consumed, so the epilogue pays one memory round trip per tile
-    // instead of one per element; out-of-range elements are computed and simply not stored.
-#define CSS_EMIT(acc, tm2, tn2)                                                              \
-    {                                                                                        \
-        const int n = n0 + wn * 64 + (tn2) * 32 + c;                                         \
-        const bool n_ok = n < N;                                                             \
-        const int nc = n_ok ? n : N - 1;                                                     \
-        const int mb = m0 + wm * 64 + (tm2) * 32 + 4 * h;                                    \
-        const float bn = (bias && !bias_m) ? bias[nc] : 0.f;                                 \
-        float rv[16], bm[16];                                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
-            const int m = mb + (r & 3) + 8 * (r >> 2);                                       \
-            const int mc = m < M ? m : M - 1;                                                \
-            rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;                                 \
-            bm[r] = (bias && bias_m) ? bias[mc] : 0.f;                                       \
-        }                                                                                    \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
-            const int m = mb + (r & 3) + 8 * (r >> 2);                                       \
-            float v = acc[r] + bn + bm[r];                                                   \
-            if (act == ACT_RELU) v = fmaxf(v, 0.f);                                          \
-            else if (act == ACT_SIGMOID) v = sigmoidf_(v);                                   \
-            if (res) v = rv[r] + alpha * v;                                                  \
-            if (n_ok && m < M) C[(int64_t)m * ldc + n] = v;                                  \
-        }                                                                                    \
+    const int mrow = m0 + wm * (BM / WM) + 4 * h, ncol = n0 + wn * 64 + c;
+    emit_tile(acc00, mrow, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
+    emit_tile(acc01, mrow, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
+    if constexpr (TM == 2) {
+        emit_tile(acc10, mrow + 32, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
+        emit_tile(acc11, mrow + 32, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
     }
-    CSS_EMIT(acc00, 0, 0)
-    CSS_EMIT(acc01, 0, 1)
-    CSS_EMIT(acc10, 1, 0)
-    CSS_EMIT(acc11, 1, 1)
 }
 
+// Wave layout per launch: 8 waves when the grid gives each CU about one block (the second wave per
+// SIMD hides the barrier / LDS bubbles), 4 waves when at least two blocks per CU are resident anyway.
+// CSS_GEMM_WAVES=4|8 forces a layout (experiments).
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int blocks = tiles_m * tiles_n * g.batch;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WAVES"); return e ? std::atoi(e) : 0; }();
+    // measured on MI355X (tools/gemm_bench.hip): 8 waves win on every shape of the 60 s meeting (wo 79 -> 86,
+    // qkv 77 -> 96, ffn2 91 -> 97 TFLOP/s); with >= 4 blocks per CU the 4-wave layout is ~3 % ahead
+    const bool eight = forced ? forced == 8 : blocks < 1000;
+    if (eight) hipLaunchKernelGGL((gemm_kernel<4>), dim3(blocks), dim3(512), 0, s, g, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_kernel<2>), dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
 }
 
 }  // namespace css

@@ -83,10 +83,13 @@ def all_plans(num_segments, mix_frames, stft_frames, seg_frames, hop_frames, hop
 class HipShardBackend:
     """Stage calls of one rank on its GPU (the C ABI's css_stage_* entry points)."""
 
-    def __init__(self, handle, torch_device):
+    def __init__(self, handle, torch_device, comm_device=None):
+        """`comm_device`: where the process group exchanges tensors -- the GPU itself for "nccl" (RCCL over
+        xGMI, the default), torch.device("cpu") for "gloo" (functional testing of the multi-process path)."""
         import torch
         self.h = handle
         self.dev = torch_device
+        self.comm_dev = comm_device if comm_device is not None else torch_device
         self.torch = torch
 
     def begin(self, pcm, n, c, run_cfg):
@@ -127,7 +130,7 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.dev)  # zeros are written on torch's stream, the kernels on the handle's
         self.h.stage_istft_partial(lo, hi, out.data_ptr(), shard_len)
         self.h.sync()
-        return out
+        return out.to(self.comm_dev)
 
     def pit_scan(self, costs, num_spks):
         from . import _lib
@@ -135,7 +138,7 @@ class HipShardBackend:
 
     def to_comm(self, arr):
         """numpy -> tensor on the device the process group communicates from"""
-        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.comm_dev)
 
 
 def _all_gather(dist, tensor, world):
