@@ -114,12 +114,79 @@ __host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_bou
     }
 }
 
-__global__ void pit_scan_kernel(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) pit_scan_impl(costs, n_boundaries, S, perms);
+// Device form of the scan.  A permutation is a state (its lexicographic index, S! <= 24 states), and
+// boundary b is a transition table next[b][state_in] -> state_out that depends only on the raw cost
+// matrix of b.  All tables are built in parallel (one thread per (boundary, incoming state), in LDS);
+// what remains sequential is one LDS lookup per boundary by a single lane, instead of a chain of
+// dependent global-memory reads (180 us for 39 boundaries became a few us; 1208 boundaries of a 30-min
+// meeting stay under 0.1 ms).  Chunked so that any meeting length fits the LDS.
+constexpr int SCAN_CHUNK = 4096;
+constexpr int NPMAX = 24;
+
+__device__ __forceinline__ void perm_from_index(int idx, int S, int* p) {
+    // idx-th permutation of 0..S-1 in lexicographic order (factorial number system)
+    int avail[SMAX] = {0, 1, 2, 3};
+    int f = 1;
+    for (int i = 2; i < S; ++i) f *= i;  // (S-1)!
+    int n = S;
+    for (int a = 0; a < S; ++a) {
+        const int d = idx / f;
+        idx -= d * f;
+        p[a] = avail[d];
+        for (int i = d; i + 1 < n; ++i) avail[i] = avail[i + 1];
+        --n;
+        if (n > 1) f /= (n);
+    }
+}
+
+__global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict__ costs, int64_t n_boundaries, int S,
+                                                       int32_t* __restrict__ perms) {
+    __shared__ uint8_t next[SCAN_CHUNK * NPMAX];
+    __shared__ uint8_t state_of[SCAN_CHUNK];
+    __shared__ int carry;
+    int np = 1;
+    for (int i = 2; i <= S; ++i) np *= i;
+    if (threadIdx.x == 0) carry = 0;  // identity = lexicographic index 0
+    if (threadIdx.x < S) perms[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n_boundaries; b0 += SCAN_CHUNK) {
+        const int nb = (int)(n_boundaries - b0 < SCAN_CHUNK ? n_boundaries - b0 : SCAN_CHUNK);
+        for (int e = threadIdx.x; e < nb * np; e += blockDim.x) {
+            const int b = e / np, pin = e - b * np;
+            const double* c = costs + (b0 + b) * S * S;
+            int lp[SMAX], sig[SMAX];
+            perm_from_index(pin, S, lp);
+            double best = 0.0;
+            int arg = 0;
+            for (int k = 0; k < np; ++k) {  // ascending lexicographic order, strict '<': first minimum wins
+                perm_from_index(k, S, sig);
+                double tot = 0.0;
+                for (int a = 0; a < S; ++a) tot += c[lp[a] * S + sig[a]];
+                if (k == 0 || tot < best) { best = tot; arg = k; }
+            }
+            next[b * np + pin] = (uint8_t)arg;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int st = carry;
+            for (int b = 0; b < nb; ++b) {
+                st = next[b * np + st];
+                state_of[b] = (uint8_t)st;
+            }
+            carry = st;
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+            int p[SMAX];
+            perm_from_index(state_of[b], S, p);
+            for (int a = 0; a < S; ++a) perms[(b0 + b + 1) * S + a] = p[a];
+        }
+        __syncthreads();
+    }
 }
 
 void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s) {
-    hipLaunchKernelGGL(pit_scan_kernel, dim3(1), dim3(64), 0, s, costs, n_boundaries, S, perms);
+    hipLaunchKernelGGL(pit_scan_kernel, dim3(1), dim3(256), 0, s, costs, n_boundaries, S, perms);
 }
 
 void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
