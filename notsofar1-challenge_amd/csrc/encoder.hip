@@ -177,23 +177,39 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) q[ch] = *reinterpret_cast<const float4*>(qb + (int64_t)iq * ld + 8 * ch + 4 * h);
 
-#define CSS_ATT_DOT(acc, rowptr)                                                          \
-    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                    \
-        const float4 a = *reinterpret_cast<const float4*>((rowptr) + 8 * ch + 4 * h);     \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[ch].x, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[ch].y, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[ch].z, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[ch].w, acc, 0, 0, 0);           \
+    // Operand tiles are prefetched a whole tile (8 x 16 B per lane) ahead of the 32 MFMAs that consume
+    // them: the compiler's own schedule kept one load in flight (vmcnt(1) every 4 MFMAs) and exposed the
+    // L2 latency 8 times per tile.
+#define CSS_ATT_LOAD8(dst, rowptr)                                                                      \
+    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) dst[ch] = *reinterpret_cast<const float4*>((rowptr) + 8 * ch + 4 * h);
+#define CSS_ATT_MFMA32(acc, src)                                                              \
+    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].x, q[ch].x, acc, 0, 0, 0);         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].y, q[ch].y, acc, 0, 0, 0);         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].z, q[ch].z, acc, 0, 0, 0);         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].w, q[ch].w, acc, 0, 0, 0);         \
     }
-
-    // ---- position term: R^T[r][i] for offsets rel = i0 - (T-1) + r, r in [0, 32*NRT) -> LDS[i][r]
     const int rel0 = i0 - (T - 1);
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
+    auto pe_row = [&](int rt) {
         int prow = rel0 + rt * 32 + c;
         prow = max(-maxlen, min(prow, maxlen - 1)) + maxlen;  // clamp_ of conformer.py:24
+        return pe + (int64_t)prow * DK;
+    };
+    auto k_row = [&](int jt) { return kb + (int64_t)min(jt * 32 + c, T - 1) * ld; };
+
+    // ---- position term: R^T[r][i] for offsets rel = i0 - (T-1) + r, r in [0, 32*NRT) -> LDS[i][r]
+    float4 nxt[8], cur[8];
+    CSS_ATT_LOAD8(nxt, pe_row(0))
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch];
+        if (rt + 1 < NRT) { CSS_ATT_LOAD8(nxt, pe_row(rt + 1)) }
+        else { CSS_ATT_LOAD8(nxt, k_row(0)) }                 // chain straight into the content term
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sinks it back)
         f32x16 acc = {0};
-        CSS_ATT_DOT(acc, pe + (int64_t)prow * DK)
+        CSS_ATT_MFMA32(acc, cur)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -206,9 +222,13 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     f32x16 S[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
-        const int jrow = min(jt * 32 + c, T - 1);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch];
+        if (jt + 1 < NJT) { CSS_ATT_LOAD8(nxt, k_row(jt + 1)) }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = {0};
-        CSS_ATT_DOT(acc, kb + (int64_t)jrow * ld)
+        CSS_ATT_MFMA32(acc, cur)
+        __builtin_amdgcn_sched_barrier(0);
         S[jt] = acc;
     }
     float mx = -INFINITY;
@@ -242,17 +262,26 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // ---- O^T[d][i] = sum_j v[j][d] * P[i][j]; the MFMA k index of half h at step (jt, r) is the key
     //      row this lane's S[jt][r] belongs to, so P feeds the B operand straight from registers.
     constexpr int OLD = 65;
+    float vn[16], vc[16];
+#define CSS_ATT_LOADV(dst, dt, jt)                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+        const int j = min((jt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, T - 1);                 \
+        dst[r] = vb[(int64_t)j * ld + (dt) * 32 + c];                                         \
+    }
+    CSS_ATT_LOADV(vn, 0, 0)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         f32x16 o = {0};
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = min(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, T - 1);
-                const float a = vb[(int64_t)j * ld + dt * 32 + c];
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[jt][r], o, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) vc[r] = vn[r];
+            if (jt + 1 < NJT) { CSS_ATT_LOADV(vn, dt, jt + 1) }
+            else if (dt == 0) { CSS_ATT_LOADV(vn, 1, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], S[jt][r], o, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
