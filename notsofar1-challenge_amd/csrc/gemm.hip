@@ -25,7 +25,7 @@ namespace css {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
+constexpr int BN = 128, BK = 32, LDS_LD = 36;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -57,12 +57,14 @@ __device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int 
     }
 }
 
-template <int WM>
+template <int BM, int WM>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WM * 128;          // WM x 2 waves
     constexpr int TM = (BM / WM) / 32;         // MFMA tiles along M per wave (2 or 1)
     constexpr int LROWS = THREADS / 8;         // rows covered by one staging pass (32 or 64)
-    constexpr int NLD = BM / LROWS;            // staging passes per operand (4 or 2)
+    constexpr int NLA = BM / LROWS;            // staging passes of the A tile (2 or 4)
+    constexpr int NLB = BN / LROWS;            // staging passes of the B tile (2 or 4)
+    static_assert((NLA == 2 || NLA == 4) && (NLB == 2 || NLB == 4) && (TM == 1 || TM == 2), "unsupported tile layout");
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
     // ---- XCD-aware tile mapping: consecutive tiles (which share an A row panel) go to one XCD/L2 ----
     const int n_tiles = tiles_m * tiles_n * g.batch;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 #define CSS_ROWPTR(base, ld, row, lim) ((base) + (int64_t)((row) < (lim) ? (row) : (lim) - 1) * (ld) + lc)
     const float* pa0 = CSS_ROWPTR(A, g.lda, m0 + lr, M);
     const float* pa1 = CSS_ROWPTR(A, g.lda, m0 + lr + LROWS, M);
-    const float* pa2 = CSS_ROWPTR(A, g.lda, m0 + lr + 2 * LROWS, M);   // passes 2, 3 only exist when NLD == 4
+    const float* pa2 = CSS_ROWPTR(A, g.lda, m0 + lr + 2 * LROWS, M);   // passes 2, 3 only exist when NLA / NLB == 4
     const float* pa3 = CSS_ROWPTR(A, g.lda, m0 + lr + 3 * LROWS, M);
     const float* pb0 = CSS_ROWPTR(B, g.ldb, n0 + lr, N);
     const float* pb1 = CSS_ROWPTR(B, g.ldb, n0 + lr + LROWS, N);
@@ -107,9 +109,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     ra1 = *reinterpret_cast<const float4*>(pa1 + (k0));            \
     rb0 = *reinterpret_cast<const float4*>(pb0 + (k0));            \
     rb1 = *reinterpret_cast<const float4*>(pb1 + (k0));            \
-    if constexpr (NLD == 4) {                                      \
+    if constexpr (NLA == 4) {                                      \
         ra2 = *reinterpret_cast<const float4*>(pa2 + (k0));        \
         ra3 = *reinterpret_cast<const float4*>(pa3 + (k0));        \
+    }                                                              \
+    if constexpr (NLB == 4) {                                      \
         rb2 = *reinterpret_cast<const float4*>(pb2 + (k0));        \
         rb3 = *reinterpret_cast<const float4*>(pb3 + (k0));        \
     }
@@ -121,9 +125,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
         *reinterpret_cast<float4*>(as_ + LROWS * LDS_LD) = ra1;                 \
         *reinterpret_cast<float4*>(bs_) = rb0;                                  \
         *reinterpret_cast<float4*>(bs_ + LROWS * LDS_LD) = rb1;                 \
-        if constexpr (NLD == 4) {                                               \
+        if constexpr (NLA == 4) {                                               \
             *reinterpret_cast<float4*>(as_ + 2 * LROWS * LDS_LD) = ra2;         \
             *reinterpret_cast<float4*>(as_ + 3 * LROWS * LDS_LD) = ra3;         \
+        }                                                                       \
+        if constexpr (NLB == 4) {                                               \
             *reinterpret_cast<float4*>(bs_ + 2 * LROWS * LDS_LD) = rb2;         \
             *reinterpret_cast<float4*>(bs_ + 3 * LROWS * LDS_LD) = rb3;         \
         }                                                                       \
@@ -136,7 +142,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#ifndef CSS_ABL_NO_GLOAD
         if (kt + 1 < nk) { CSS_GLOAD((kt + 1) * BK) }
+#endif
         const float* as = lds + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + c) * LDS_LD + 4 * h;
         const float* bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * 64 + c) * LDS_LD + 4 * h;
 #pragma unroll
@@ -156,8 +164,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
             CSS_MFMA_STEP(x) CSS_MFMA_STEP(y) CSS_MFMA_STEP(z) CSS_MFMA_STEP(w)
 #undef CSS_MFMA_STEP
         }
+#ifndef CSS_ABL_NO_LSTORE
         if (kt + 1 < nk) CSS_LSTORE(buf ^ 1)
+#endif
+#ifndef CSS_ABL_NO_BARRIER
         __syncthreads();
+#endif
     }
 #undef CSS_GLOAD
 #undef CSS_LSTORE
@@ -177,19 +189,36 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     }
 }
 
-// Wave layout per launch: 8 waves when the grid gives each CU about one block (the second wave per
-// SIMD hides the barrier / LDS bubbles), 4 waves when at least two blocks per CU are resident anyway.
-// CSS_GEMM_WAVES=4|8 forces a layout (experiments).
+// Tile layouts (block tile M x 128, waves):
+//   128 x 128, 8 waves (each 32x64)  default: two waves per SIMD from one block cover each other's barrier /
+//                                    LDS bubbles when a launch has about one block per CU
+//   128 x 128, 4 waves (each 64x64)  fewest LDS reads per MFMA; ~3 % ahead once >= 4 blocks per CU are queued
+//    64 x 128, 4 waves (each 32x64)  twice the blocks: independent 4-wave blocks drift out of phase
+// CSS_GEMM_LAYOUT=8|4|64 forces one (experiments; tools/gemm_bench.hip).
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int blocks = tiles_m * tiles_n * g.batch;
-    if (blocks <= 0) return;
-    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WAVES"); return e ? std::atoi(e) : 0; }();
-    // measured on MI355X (tools/gemm_bench.hip): 8 waves win on every shape of the 60 s meeting (wo 79 -> 86,
-    // qkv 77 -> 96, ffn2 91 -> 97 TFLOP/s); with >= 4 blocks per CU the 4-wave layout is ~3 % ahead
-    const bool eight = forced ? forced == 8 : blocks < 1000;
-    if (eight) hipLaunchKernelGGL((gemm_kernel<4>), dim3(blocks), dim3(512), 0, s, g, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm_kernel<2>), dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
+    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_LAYOUT"); return e ? std::atoi(e) : 0; }();
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;
+    int layout = forced ? forced : (blocks128 < 1000 ? 8 : 4);
+    if (!forced) {
+        // short M (mask head: 1028 rows, analysis transform: 514): 128-row tiles would leave the last tile
+        // nearly empty (12 % / 25 % padded work); 64-row tiles halve that (measured: head 119 -> 86 us,
+        // STFT 192 -> 156 us)
+        const double waste128 = (double)(((g.M + 127) / 128) * 128 - g.M) / g.M;
+        const double waste64 = (double)(((g.M + 63) / 64) * 64 - g.M) / g.M;
+        if (waste128 - waste64 > 0.03) layout = 64;
+    }
+    if (layout == 64) {
+        const int tiles_m = (g.M + 63) / 64;
+        hipLaunchKernelGGL((gemm_kernel<64, 2>), dim3(tiles_m * tiles_n * g.batch), dim3(256), 0, s, g, tiles_m, tiles_n);
+    } else if (layout == 8) {
+        const int tiles_m = (g.M + 127) / 128;
+        hipLaunchKernelGGL((gemm_kernel<128, 4>), dim3(blocks128), dim3(512), 0, s, g, tiles_m, tiles_n);
+    } else {
+        const int tiles_m = (g.M + 127) / 128;
+        hipLaunchKernelGGL((gemm_kernel<128, 2>), dim3(blocks128), dim3(256), 0, s, g, tiles_m, tiles_n);
+    }
 }
 
 }  // namespace css

@@ -36,6 +36,7 @@ int main() {
         double fl = 2.0 * sh.M * sh.N * sh.K * sh.batch;
         printf("%-12s M=%6d N=%5d K=%5d b=%d  %8.2f us  %7.2f TFLOP/s  blocks=%d\n", sh.name, sh.M, sh.N, sh.K, sh.batch,
                1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12, ((sh.M + 127) / 128) * ((sh.N + 127) / 128) * sh.batch);
+        hipMemcpy(h.data(), C, 64 * 4, hipMemcpyDeviceToHost); double cs = 0; for (int i = 0; i < 64; ++i) cs += h[i] * (i + 1); printf("      checksum %.9g\n", cs);
     }
     return 0;
 }
