@@ -399,7 +399,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
     if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256]");
-    if (hop <= 0 || 2 * hop < T || hop > T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/2 <= hop <= T (at most two segments overlap)");
+    if (hop <= 0 || 4 * hop < T || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/4 <= hop < T (at most four segments overlap; at least one frame of overlap for the stitching cost)");
     if (T - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "segment longer than the relative-position table");
     HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};

@@ -159,11 +159,12 @@ template <int NJT>
 __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen) {
     constexpr int DK = 64;
-    constexpr int NRT = NJT + 1;  // offset tiles: T - 1 + 32 <= 32 * (NJT + 1)
-    // LDS row stride of R (226 floats at NJT = 6): stride + 1 is odd, so the skewed reads of 32 lanes
-    // (address = c * (stride + 1) + const) hit 32 distinct banks
-    constexpr int ATT_LD = 32 * NJT + 34;
-    __shared__ float lds[32 * ATT_LD];
+    // The position term lives in an LDS ring of three 32-offset tiles per query row (row stride 98 floats:
+    // the skewed reads of 32 lanes land on addresses 3c + const (mod 32), i.e. 32 distinct banks).  A key tile
+    // only ever needs three consecutive offset tiles, and the window slides down by one tile per key tile, so
+    // the ring replaces the full [32][217] table (29 KB, 5 waves per CU) by 12.5 KB (register-limited 8 per CU).
+    constexpr int LDR = 98;
+    __shared__ float lds[32 * LDR];
     const int qt = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const int ld = 3 * D;
@@ -197,51 +198,57 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     };
     auto k_row = [&](int jt) { return kb + (int64_t)min(jt * 32 + c, T - 1) * ld; };
 
-    // ---- position term: R^T[r][i] for offsets rel = i0 - (T-1) + r, r in [0, 32*NRT) -> LDS[i][r]
+    // ---- position term R^T[r][i] = pe[rel0 + r] . q_i (offset tiles, descending) interleaved with the
+    //      content term S^T[j][i] = k_j . q_i (key tiles, ascending); skew B[i][j] = R[i][i - j - rel0]
+    const int RT0 = (T - 1 + 31) >> 5;  // highest offset tile a 32-query tile can see
     float4 nxt[8], cur[8];
-    CSS_ATT_LOAD8(nxt, pe_row(0))
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch];
-        if (rt + 1 < NRT) { CSS_ATT_LOAD8(nxt, pe_row(rt + 1)) }
-        else { CSS_ATT_LOAD8(nxt, k_row(0)) }                 // chain straight into the content term
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sinks it back)
-        f32x16 acc = {0};
-        CSS_ATT_MFMA32(acc, cur)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (rr < ATT_LD) lds[c * ATT_LD + rr] = acc[r];
-        }
-    }
-    __syncthreads();
-
-    // ---- content term S^T[j][i] = k_j . q_i, plus skewed position term, scale, key mask
     f32x16 S[NJT];
+#define CSS_ATT_STEP(acc, LOADNEXT)                                         \
+    {                                                                       \
+        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch]; \
+        LOADNEXT                                                            \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the MFMAs (the scheduler sinks it) */ \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;        \
+        CSS_ATT_MFMA32(acc, cur)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#define CSS_ATT_RING_WRITE(acc, rt)                                                          \
+    {                                                                                        \
+        const int slot_ = (((rt) % 3) + 3) % 3;                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
+            lds[c * LDR + slot_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];             \
+    }
+    CSS_ATT_LOAD8(nxt, pe_row(RT0))
 #pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch];
-        if (jt + 1 < NJT) { CSS_ATT_LOAD8(nxt, k_row(jt + 1)) }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc = {0};
-        CSS_ATT_MFMA32(acc, cur)
-        __builtin_amdgcn_sched_barrier(0);
-        S[jt] = acc;
+    for (int u = 0; u < 3; ++u) {
+        const int rt = RT0 - u;
+        f32x16 acc;
+        if (u < 2) CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, pe_row(max(rt - 1, 0))))
+        else CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, k_row(0)))
+        CSS_ATT_RING_WRITE(acc, rt)
     }
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
+        const int rt_new = RT0 - 3 - jt;  // the offset tile key tile jt + 1 adds to the window
+        if (rt_new >= 0) CSS_ATT_STEP(S[jt], CSS_ATT_LOAD8(nxt, pe_row(rt_new)))
+        else if (jt + 1 < NJT) CSS_ATT_STEP(S[jt], CSS_ATT_LOAD8(nxt, k_row(jt + 1)))
+        else CSS_ATT_STEP(S[jt], ;)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int rr = max(c + (T - 1) - j, 0);  // (i - j) - rel0 with i = i0 + c
-            float sc = (S[jt][r] + lds[c * ATT_LD + rr]) * 0.125f;  // 1/sqrt(64)
+            const float bpos = lds[c * LDR + ((rr >> 5) % 3) * 32 + (rr & 31)];
+            float sc = (S[jt][r] + bpos) * 0.125f;  // 1/sqrt(64)
             sc = j < T ? sc : -INFINITY;
             S[jt][r] = sc;
             mx = fmaxf(mx, sc);
+        }
+        if (rt_new >= 0) {
+            f32x16 acc;
+            if (jt + 1 < NJT) CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, k_row(jt + 1)))
+            else CSS_ATT_STEP(acc, ;)
+            CSS_ATT_RING_WRITE(acc, rt_new)  // overwrites tile RT0 - jt, which key tile jt was the last to read
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));

@@ -2,8 +2,8 @@
 // segments (training/losses.py PitWrapper), weighted overlap-add, activity gating with
 // dilate/erode (utils/numpy_utils.py), and the hand-off layout for the inverse transform.
 //
-// All kernels are in gather form: an output frame t receives at most the two segments
-// i = floor(t/hop) - 1 and floor(t/hop) (bit-exact segment indexing st = i * hop, css.py:183,287), so
+// All kernels are in gather form: an output frame t collects the segments i with i*hop <= t < i*hop + T
+// (two with the shipped configuration; bit-exact segment indexing st = i * hop, css.py:183,287), so
 // nothing is accumulated with atomics and a frame range can be produced by any rank that holds the
 // segments covering it.
 #include "kernels.hpp"
@@ -204,11 +204,13 @@ __device__ __forceinline__ float seg_weight(const StitchArgs& a, int64_t seg, in
     return w[tl];
 }
 
-// the (at most two) segments covering frame t, in ascending segment order
-__device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Contrib c[2]) {
+// the segments covering frame t (at most MAXC: css_begin enforces hop >= T / MAXC; two with the shipped
+// 3 s / 1.5 s configuration), in ascending segment order
+constexpr int MAXC = 4;
+__device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Contrib c[MAXC]) {
     const int64_t i1 = t / a.hop;
     int n = 0;
-    for (int64_t seg = i1 - 1; seg <= i1; ++seg) {
+    for (int64_t seg = i1 - (MAXC - 1); seg <= i1; ++seg) {
         if (seg < 0 || seg >= a.num_segments) continue;
         const int64_t tl = t - seg * a.hop;
         if (tl < 0 || tl >= a.T) continue;
@@ -234,23 +236,27 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
     const int lane = threadIdx.x & 63, fg = threadIdx.x >> 6;
     const int64_t t = t_lo + (int64_t)blockIdx.x * 64 + lane;
     const bool active = t < t_hi;
-    Contrib c[2];
+    Contrib c[MAXC];
     int n = 0;
     float wsum = 0.f;
-    const float* m0 = nullptr;
-    const float* m1 = nullptr;
+    const float* mp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
     if (active) {
         n = contributors(a, t, c);
-        for (int i = 0; i < n; ++i) wsum = __fadd_rn(wsum, c[i].w);
-        if (n > 0) m0 = a.masks + (int64_t)a.perms[c[0].seg * a.S + s] * a.F * a.mask_ld + c[0].seg * a.T + c[0].tl;
-        if (n > 1) m1 = a.masks + (int64_t)a.perms[c[1].seg * a.S + s] * a.F * a.mask_ld + c[1].seg * a.T + c[1].tl;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (i < n) {
+                wsum = __fadd_rn(wsum, c[i].w);
+                mp[i] = a.masks + (int64_t)a.perms[c[i].seg * a.S + s] * a.F * a.mask_ld + c[i].seg * a.T + c[i].tl;
+            }
     }
     double sum = 0.0;
     if (active && n > 0) {
         float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
         for (int f = fg; f < a.F; f += 4) {
-            float v = __fmul_rn(c[0].w, m0[(int64_t)f * a.mask_ld]);
-            if (n > 1) v = __fadd_rn(v, __fmul_rn(c[1].w, m1[(int64_t)f * a.mask_ld]));
+            float v = __fmul_rn(c[0].w, mp[0][(int64_t)f * a.mask_ld]);
+#pragma unroll
+            for (int i = 1; i < MAXC; ++i)
+                if (i < n) v = __fadd_rn(v, __fmul_rn(c[i].w, mp[i][(int64_t)f * a.mask_ld]));
             v = __fdiv_rn(v, wsum);
             out[(int64_t)f * a.T_long] = v;
             sum += (double)v;
@@ -314,30 +320,34 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
     const int tx = threadIdx.x & (OT - 1), fy = threadIdx.x >> 4;  // 16 frames x 16 bins per pass
     const int64_t t = t0 + tx;
     const bool active = t < t_hi;
-    Contrib c[2];
+    Contrib c[MAXC];
     int n = 0;
     float wsum = 0.f, gate = 0.f;
-    const float2* p0 = nullptr;
-    const float2* p1 = nullptr;
+    const float2* pp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
     if (active) {
         n = contributors(a, t, c);
-        for (int i = 0; i < n; ++i) wsum = __fadd_rn(wsum, c[i].w);
         gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
         const float2* sep = reinterpret_cast<const float2*>(a.sep);
-        if (n > 0) p0 = sep + (c[0].seg * a.S + a.perms[c[0].seg * a.S + s]) * (int64_t)a.F * a.T + c[0].tl;
-        if (n > 1) p1 = sep + (c[1].seg * a.S + a.perms[c[1].seg * a.S + s]) * (int64_t)a.F * a.T + c[1].tl;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (i < n) {
+                wsum = __fadd_rn(wsum, c[i].w);
+                pp[i] = sep + (c[i].seg * a.S + a.perms[c[i].seg * a.S + s]) * (int64_t)a.F * a.T + c[i].tl;
+            }
     }
     for (int f = fy; f < a.F; f += 16) {
         float re = 0.f, im = 0.f;
         if (active && n > 0) {
-            const float2 v0 = p0[(int64_t)f * a.T];
+            const float2 v0 = pp[0][(int64_t)f * a.T];
             re = __fmul_rn(c[0].w, v0.x);
             im = __fmul_rn(c[0].w, v0.y);
-            if (n > 1) {
-                const float2 v1 = p1[(int64_t)f * a.T];
-                re = __fadd_rn(re, __fmul_rn(c[1].w, v1.x));
-                im = __fadd_rn(im, __fmul_rn(c[1].w, v1.y));
-            }
+#pragma unroll
+            for (int i = 1; i < MAXC; ++i)
+                if (i < n) {
+                    const float2 v1 = pp[i][(int64_t)f * a.T];
+                    re = __fadd_rn(re, __fmul_rn(c[i].w, v1.x));
+                    im = __fadd_rn(im, __fmul_rn(c[i].w, v1.y));
+                }
             re = __fmul_rn(__fdiv_rn(re, wsum), gate);
             im = __fmul_rn(__fdiv_rn(im, wsum), gate);
         }

@@ -7,8 +7,9 @@ global segment indices (segment i always covers frames [i*hop, i*hop + T), css.p
 not depend on the number of ranks:
 
   rank r owns segments [S_r, S_r+1) with S_r = floor(r * num_segments / world) and the frames
-  [S_r*hop, S_r+1*hop) (first rank from 0, last rank to T_long).  It computes its own segments plus ONE
-  halo segment S_r - 1, whose second half overlaps the rank's first frames.
+  [S_r*hop, S_r+1*hop) (first rank from 0, last rank to T_long).  It computes its own segments plus the
+  ceil(T/hop) - 1 halo segments before S_r that still cover the rank's first frames (ONE segment with the
+  shipped 3 s / 1.5 s configuration).
 
 Exchanges (all tiny except the last; `torch.distributed`, backend "nccl" = RCCL on ROCm, "gloo" in CPU tests):
   1. raw 3x3 PIT cost matrices of the boundaries each rank owns (all-gather, 72 B per boundary); every
@@ -66,7 +67,8 @@ def make_shard_plan(num_segments: int, mix_frames: int, stft_frames: int, seg_fr
     t_hi = mix_frames if rank == world - 1 else s_hi * hop_frames
     if s_hi == s_lo and rank != world - 1:   # a rank without segments owns no frames
         t_lo = t_hi = s_lo * hop_frames if rank else 0
-    seg_lo = max(s_lo - 1, 0) if s_hi > s_lo else s_lo
+    halo = -(-seg_frames // hop_frames) - 1   # earlier segments that still cover the first owned frame (1 at 3 s / 1.5 s)
+    seg_lo = max(s_lo - max(halo, 1), 0) if s_hi > s_lo else s_lo
     f_lo = seg_lo * hop_frames
     f_hi = min((s_hi - 1) * hop_frames + seg_frames, stft_frames) if s_hi > s_lo else f_lo
     f_hi = max(f_hi, f_lo)

@@ -107,7 +107,7 @@ class OracleStageBackend:
 
     def _contrib(self, t):
         out = []
-        for seg in (t // self.hop - 1, t // self.hop):
+        for seg in range(t // self.hop - 3, t // self.hop + 1):
             tl = t - seg * self.hop
             if 0 <= seg < self.nseg and 0 <= tl < self.T:
                 w = self.w[0] if seg == 0 else (self.w[2] if seg == self.nseg - 1 else self.w[1])

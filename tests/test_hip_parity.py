@@ -279,6 +279,37 @@ def test_non_default_options_vs_oracle(L, CSS, sep_mc, mc_state, mix60):
             assert rel_rms(wavs[k], ow[k]) < 2e-5, (kw, k)
 
 
+@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0)])
+def test_other_segmentations_vs_oracle(L, CSS, sep_mc, mc_state, mix60, seg_hop):
+    """Segment / hop sizes other than the shipped 3 s / 1.5 s: different frame counts per segment (186, 249,
+    124 -> different attention tile counts, conv runs, weight windows) and different overlaps."""
+    st, _ = mc_state
+    params = O.ConformerParams(st)
+    kw = dict(segment_size_sec=seg_hop[0], hop_size_sec=seg_hop[1])
+    cfg, ocfg = cfgs(CSS, **kw)
+    mix = mix60[:, 32000:32000 + 11 * 16000 + 300]
+    wavs, side = CSS.separate_and_stitch(mix, sep_mc, 16000, "cuda:0", cfg)
+    h = sep_mc.handle
+    plan = h.get_plan()
+    oplan = O.make_plan(mix.shape[1], 16000, ocfg)
+    assert (plan.mix_frames, plan.num_segments, plan.last_valid) == \
+        (oplan.mix_frames, oplan.num_segments, oplan.seg_range(oplan.num_segments - 1)[2])
+    Ts, nseg = oplan.segment_frames, oplan.num_segments
+    assert side["segment_frames"] == Ts
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, Ts)
+    xo = O.stft(mix[0])
+    om = O.conformer_forward(params, O.features(xo[:, :Ts]))
+    assert np.abs(m[:, :, 0, :] - om).max() < 5e-5
+    per_seg = [(np.ascontiguousarray(np.moveaxis(m[:S, :, i], 0, 2)), np.ascontiguousarray(np.moveaxis(m[S:, :, i], 0, 2)))
+               for i in range(nseg)]
+    ow, oside = O.separate_and_stitch(mix, params, 16000, ocfg, separate_fn=lambda i, seg: per_seg[i],
+                                      mvdr_cplx=np.complex128)
+    assert [tuple(p) for p in h.read(L.BUF_PERMS)] == [tuple(p) for p in oside["perms"]]
+    assert np.array_equal(side["activity_final"].numpy()[0], oside["activity_final"][0])
+    for k in range(S):
+        assert len(wavs[k]) == len(ow[k]) and rel_rms(wavs[k], ow[k]) < 2e-5
+
+
 def test_short_and_error_inputs(L, CSS, sep_mc):
     cfg, _ = cfgs(CSS)
     with pytest.raises(AssertionError, match="zero weights"):           # css.py:297 on inputs <= 3.0 s

@@ -37,7 +37,7 @@ def test_shard_plans_partition_everything():
                 assert p.seg_lo == max(p.own_seg_lo - 1, 0) and p.seg_hi == p.own_seg_hi     # one halo segment
                 # every owned frame is covered only by computed segments (bit-exact indexing st = i*hop)
                 for t in (p.t_lo, p.t_hi - 1):
-                    for seg in (t // hop - 1, t // hop):
+                    for seg in range(t // hop - 3, t // hop + 1):
                         if 0 <= seg < nseg and 0 <= t - seg * hop < T:
                             assert p.seg_lo <= seg < p.seg_hi, (mix_frames, world, p, t, seg)
                 # both segments of every owned boundary are computed
@@ -46,6 +46,21 @@ def test_shard_plans_partition_everything():
                 # the transform covers exactly the frames the computed segments read
                 assert p.f_lo == p.seg_lo * hop and p.f_hi == min((p.seg_hi - 1) * hop + T, mix_frames)
             assert sum(p.shard_len for p in plans if p.num_frames) >= (mix_frames + 1) * 256
+
+
+def test_shard_plan_halo_grows_with_overlap():
+    """segment 4 s / hop 2 s: 249-frame segments, hop 124 -> a frame can sit in three segments, two halo segments"""
+    par = pkg("parallel")
+    T, hop, mix_frames = 249, 124, 1000
+    nseg = int(np.ceil((mix_frames - (T - hop)) / hop))
+    for world in (2, 3):
+        for p in par.all_plans(nseg, mix_frames, mix_frames, T, hop, 256, world):
+            if p.own_seg_hi > p.own_seg_lo:
+                assert p.seg_lo == max(p.own_seg_lo - 2, 0)
+                for t in (p.t_lo, p.t_hi - 1):
+                    for seg in range(t // hop - 3, t // hop + 1):
+                        if 0 <= seg < nseg and 0 <= t - seg * hop < T:
+                            assert p.seg_lo <= seg < p.seg_hi
 
 
 def _small_model():
