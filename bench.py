@@ -184,6 +184,15 @@ def main():
         h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
         result["stage_ms"] = {k: round(v, 3) for k, v in h.timings().items()
                               if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total")}
+        # the same pass through the host-buffer entry point (css_run: PCIe upload of the PCM, download of the
+        # waveforms) -- reported beside `value`, never as `value`
+        h.run(mix[0], run_cfg)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            h.run(mix[0], run_cfg)
+        host_ms = 1e3 * (time.perf_counter() - t0) / 5
+        result["host_buffers"] = {"ms_per_step": round(host_ms, 3), "value": round(total_seconds / (host_ms * 1e-3), 2),
+                                  "note": "css_run from/to pageable host memory (PCIe-inclusive)"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, total_seconds),
                                                   {"activity_th": 0.3})

@@ -1,0 +1,106 @@
+"""Module-level drop-in on the GPU: css_inference (css/css.py:51-107) and the session loop, from wav files
+and a checkpoint directory (one *.yaml + one *.pt, keys prefixed `module.`, css/helpers.py:14-37) to
+`css_inference/<session_id>/sep_stream{i}.wav` and the `sep_wav_file_names` column."""
+import os
+
+import numpy as np
+import pytest
+
+import css_oracle as O
+from conftest import pkg, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_models(tmp_path_factory):
+    """A 2-block MC model and a 1-block SC model saved the way the reference's training loop saves them."""
+    import torch
+    import yaml
+    w = pkg("weights")
+    root = tmp_path_factory.mktemp("css_models")
+    out = {}
+    for kind, desc, blocks in (("mc", w.ModelDesc(num_blocks=2), 2), ("sc", w.ModelDesc(num_mics=1, in_features=257, num_blocks=1), 1)):
+        d = root / "notsofar" / "conformer1.0" / kind
+        d.mkdir(parents=True)
+        st = w.apply_golden_recipe(w.portable_state_dict(desc, 21)) if kind == "mc" else w.portable_state_dict(desc, 22)
+        ckpt = {"model": {"module." + k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}}
+        torch.save(ckpt, d / "model.pt")
+        cfg = {"train_dir": "x", "val_dir": "x", "out_dir": "x",
+               "conformer_css_cfg": {"nnet_conf": {"conformer_conf": {"attention_dim": 512, "attention_heads": 8,
+                                                                      "num_blocks": blocks, "dropout_rate": 0.0}}}}
+        if kind == "sc":
+            cfg["conformer_css_cfg"]["extractor_conf"] = {"ipd_index": ""}
+            cfg["conformer_css_cfg"]["nnet_conf"]["in_features"] = 257
+        with open(d / "train_cfg.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        out[kind] = (st, desc)
+    return str(root), out
+
+
+def _write_session(tmp_path, wavio, mix, sid, is_mc):
+    names = []
+    for c in range(mix.shape[2]):
+        p = tmp_path / f"{sid}_ch{c}.wav"
+        wavio.write_wav(p, mix[0, :, c], 16000, max_norm=False)
+        names.append(str(p))
+    return {"wav_file_names": names, "session_id": sid, "is_mc": is_mc}
+
+
+def test_css_inference_from_files(tmp_path, tiny_models):
+    import pandas as pd
+    css, wavio, sep_mod, L = pkg("css"), pkg("wavio"), pkg("separator"), pkg("_lib")
+    models_dir, models = tiny_models
+    mix = (pkg("synth").synth_meeting(6.0, 7, seed=9) * 0.05).astype(np.float32)   # inside [-1, 1] for PCM16
+    session = pd.Series(_write_session(tmp_path, wavio, mix, "MTG_1_plaza_0", True))
+    cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
+    out = css.css_inference(str(tmp_path / "out"), models_dir, session, cfg, fetch_from_cache=False)
+    names = out["sep_wav_file_names"]
+    d = tmp_path / "out" / "css_inference" / "MTG_1_plaza_0"
+    assert names == [str(d / f"sep_stream{i}.wav") for i in range(3)] and (d / "input_mixture.wav").exists()
+    assert "sep_wav_file_names" not in session                       # the input Series is copied (css.py:70)
+
+    # the files hold what separate_and_stitch returns for the PCM16-quantised input, peak-normalised to 0.99
+    mixq, sr = wavio.load_audio(session.wav_file_names, is_mc=True)
+    assert sr == 16000 and mixq.shape == mix.shape and np.abs(mixq - mix).max() <= 1.0 / 32768 + 1e-7
+    st, desc = models["mc"]
+    sep = sep_mod.HipSeparator(st, None, device=0)
+    wavs, _ = css.separate_and_stitch(mixq, sep, 16000, "cuda:0", cfg)
+    sep.close()
+    for i in range(3):
+        y, sr_i = wavio.read_wav(names[i])
+        ref = wavs[i] * 0.99 / (np.max(np.abs(wavs[i])) + 1e-7)
+        assert sr_i == 16000 and len(y) == len(ref)
+        # PCM16 only: half an LSB of rounding plus the 32767 (write) vs 32768 (read) scale conventions
+        assert np.abs(y - ref).max() <= 1.6 / 32768
+    # ... and the oracle agrees with that model loaded from the checkpoint directory (masks injected from HIP
+    # are not needed here: 2 blocks, benign MVDR)
+    ow, _ = O.separate_and_stitch(mixq, O.ConformerParams(st), 16000, O.OracleCssCfg(activity_th=0.3),
+                                  mvdr_cplx=np.complex128)
+    assert max(rel_rms(wavs[k], ow[k]) for k in range(3)) < 5e-3    # free-running WTA decisions: flips allowed
+
+    # cache hit returns the existing files (css.py:79-82); pass-through returns channel 0 (css.py:73-75)
+    again = css.css_inference(str(tmp_path / "out"), models_dir, session, cfg, fetch_from_cache=True)
+    assert [str(p) for p in again["sep_wav_file_names"]] == names
+    pt = css.css_inference(str(tmp_path / "out"), models_dir, session, css.CssCfg(pass_through_ch0=True), False)
+    assert pt["sep_wav_file_names"] == session.wav_file_names[:1]
+    with pytest.raises(FileNotFoundError):
+        css.css_inference(str(tmp_path / "out2"), str(tmp_path / "nope"), session, cfg, False)
+
+
+def test_session_loop_shards_by_session(tmp_path, tiny_models):
+    import pandas as pd
+    css, wavio, pipe = pkg("css"), pkg("wavio"), pkg("pipeline")
+    models_dir, models = tiny_models
+    mix = (pkg("synth").synth_meeting(5.0, 7, seed=10) * 0.05).astype(np.float32)
+    rows = [_write_session(tmp_path, wavio, mix[:, : 70000 + 1000 * i], f"S{i}_mc", True) for i in range(2)]
+    rows.append(_write_session(tmp_path, wavio, mix[:, :72000, :1], "S2_sc", False))
+    df = pd.DataFrame(rows)
+    cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
+    parts = [pipe.css_sessions(str(tmp_path / "o"), models_dir, df, cfg, rank=r, world=2, device="cuda:0") for r in range(2)]
+    assert [list(p.session_id) for p in parts] == [["S0_mc", "S2_sc"], ["S1_mc"]]
+    for p in parts:
+        for _, row in p.iterrows():
+            assert len(row.sep_wav_file_names) == 3 and all(os.path.exists(f) for f in row.sep_wav_file_names)
+            y, sr = wavio.read_wav(row.sep_wav_file_names[0])
+            assert sr == 16000 and np.isfinite(y).all() and abs(np.abs(y).max() - 0.99) < 1e-3
