@@ -200,7 +200,10 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
 
     // ---- position term R^T[r][i] = pe[rel0 + r] . q_i (offset tiles, descending) interleaved with the
     //      content term S^T[j][i] = k_j . q_i (key tiles, ascending); skew B[i][j] = R[i][i - j - rel0]
-    const int RT0 = (T - 1 + 31) >> 5;  // highest offset tile a 32-query tile can see
+    // highest offset tile a 32-query tile can see: (T - 1 + 31) >> 5 = NJT for every T of this instantiation
+    // except T = 32 (NJT - 1) + 1, where tile NJT is computed but never read.  A compile-time constant keeps the
+    // whole tile schedule static (a run-time RT0 tripled the code size through duplicated branches).
+    constexpr int RT0 = NJT;
     float4 nxt[8], cur[8];
     f32x16 S[NJT];
 #define CSS_ATT_STEP(acc, LOADNEXT)                                         \
@@ -305,10 +308,15 @@ void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, in
                              int maxlen, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
     const dim3 grid(qtiles, H, nseg), block(64);
-    if (qtiles <= 4) hipLaunchKernelGGL((relpos_attn_kernel<4>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
-    else if (qtiles <= 6) hipLaunchKernelGGL((relpos_attn_kernel<6>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
-    else if (qtiles <= 8) hipLaunchKernelGGL((relpos_attn_kernel<8>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen);
-    // longer segments are rejected at css_begin (segment_frames <= 256)
+    // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
+#define CSS_ATT_CASE(n) \
+    case n: hipLaunchKernelGGL((relpos_attn_kernel<n>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen); break;
+    switch (qtiles) {
+        CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)
+        CSS_ATT_CASE(5) CSS_ATT_CASE(6) CSS_ATT_CASE(7) CSS_ATT_CASE(8)
+        default: break;  // longer segments are rejected at css_begin (segment_frames <= 256)
+    }
+#undef CSS_ATT_CASE
 }
 
 }  // namespace css
