@@ -1,0 +1,28 @@
+// Stand-alone timing of css::launch_relpos_attention (tools only).
+#include <cstdio>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+using namespace css;
+int main() {
+    const int nseg = 40, T = 186, D = 512, H = 8, maxlen = 1000;
+    const size_t nq = (size_t)nseg * T * 3 * D, npe = 2 * maxlen * 64, nc = (size_t)nseg * T * D;
+    float *qkv, *pe, *ctx;
+    hipMalloc(&qkv, nq * 4); hipMalloc(&pe, npe * 4); hipMalloc(&ctx, nc * 4);
+    std::vector<float> h(nq);
+    unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xFFFF) / 32768.0f - 1.0f) * 0.5f; }
+    hipMemcpy(qkv, h.data(), nq * 4, hipMemcpyHostToDevice); hipMemcpy(pe, h.data(), npe * 4, hipMemcpyHostToDevice);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, st);
+    hipEventRecord(e0, st);
+    const int it = 50;
+    for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, st);
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<float> o(64); hipMemcpy(o.data(), ctx + 12345, 64 * 4, hipMemcpyDeviceToHost);
+    double cs = 0; for (int i = 0; i < 64; ++i) cs += o[i] * (i + 1);
+    const double mfma = (double)nseg * H * 6 * 608 * 4096.0;
+    printf("attention %d seg: %.2f us per launch, %.1f TFLOP/s MFMA-issued, checksum %.9g\n", nseg, 1e3 * ms / it, mfma / (ms / it * 1e-3) / 1e12, cs);
+    return 0;
+}
