@@ -35,20 +35,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(mix, state, seconds, cfg_kwargs):
+def cpu_baseline(mix, state, seconds, cfg_kwargs, threads=16):
     """The oracle (numpy restatement of the reference's path, kind = "port") timed on the host cores on a
-    bounded slice of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    bounded slice of the same workload.  This is the ONLY place bench.py touches oracle/.
+
+    BLAS threads are limited to `threads`: on the 256-thread host of the GPU box OpenBLAS' default (64
+    threads) runs this workload 3.5x SLOWER than 8-16 threads (measured: 1.5x vs 5.5x real time), and the
+    reference's own measurement (5.3x on 8 cores) is an 8-thread figure."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import css_oracle as O
     n = int(seconds * 16000)
     sample = np.ascontiguousarray(mix[:, :n])
     params = O.ConformerParams(state)
-    t0 = time.time()
-    O.separate_and_stitch(sample, params, 16000, O.OracleCssCfg(**cfg_kwargs))
-    dt = time.time() - t0
-    return {"value": round(seconds / dt, 3), "unit": "x real-time (audio s / wall s)", "cores": os.cpu_count(),
-            "kind": "port", "sample": f"first {seconds:g} s of the same 7-ch meeting, numpy/BLAS float32 oracle, "
-                                      f"{dt:.1f} s wall"}
+    threads = min(threads, os.cpu_count() or threads)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:  # pragma: no cover
+        import contextlib
+        limiter, threads = contextlib.nullcontext(), os.cpu_count()
+    with limiter:
+        t0 = time.time()
+        O.separate_and_stitch(sample, params, 16000, O.OracleCssCfg(**cfg_kwargs))
+        dt = time.time() - t0
+    return {"value": round(seconds / dt, 3), "unit": "x real-time (audio s / wall s)", "cores": threads,
+            "kind": "port", "sample": f"first {seconds:g} s of the same 7-ch meeting, numpy/OpenBLAS float32 oracle on "
+                                      f"{threads} threads, {dt:.1f} s wall"}
 
 
 def main():
@@ -58,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=60.0, help="meeting seconds per GPU")
     ap.add_argument("--max-batch", type=int, default=128, help="segments per batched mask-estimator pass")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=24.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
