@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -49,6 +50,10 @@ struct css_ctx {
     int Kp = 0, KIp = 0;
     float* blob = nullptr;
     Weights w;
+    // Linear-layer arithmetic: split-f16 operands on the f16 matrix cores (float32-grade accuracy, gemm_split.hip) or,
+    // with CSS_EXACT_F32=1 in the environment at css_create, the exact float32 MFMA chain of gemm.hip (A/B tests).
+    bool split = true;
+    float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_fwd = nullptr;    // [2F][frame_len]
     float* dft_inv_t = nullptr;  // [frame_len][KIp]
 
@@ -331,6 +336,23 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     if (hipMemcpy(h->blob, blob_host, need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "weight upload failed");
     bind_weights(*desc, h->blob, &h->w);
+    if (const char* e = std::getenv("CSS_EXACT_F32")) h->split = !(e[0] == '1');
+    if (h->split) {
+        if (hipMalloc((void**)&h->wsplit, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(split weights) failed");
+        const int D = desc->attention_dim, FF = desc->linear_units;
+        auto conv = [&](const float* w, int64_t rows, int K) {
+            launch_split_convert(w, K, h->wsplit + (w - h->blob), rows, K, K, h->stream);
+        };
+        conv(h->w.embed_w, D, h->Kp);
+        for (const BlockWeights& b : h->w.blocks) {
+            conv(b.ffi_w1, FF, D); conv(b.ffi_w2, D, FF);
+            conv(b.wqkv, 3 * D, D); conv(b.wo, D, D);
+            conv(b.ffo_w1, FF, D); conv(b.ffo_w2, D, FF);
+        }
+        conv(h->w.head_w, (int64_t)desc->num_bins * (desc->num_spks + desc->num_nois), D);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+            return bail(CSS_ERR_HIP, "split-f16 weight conversion failed");
+    }
 
     // transform matrices (feature.py:19-45): analysis = Hann * DFT, S = 1; synthesis = sqrt-Hann * DFT / 16
     const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
@@ -369,6 +391,7 @@ int css_destroy(css_handle_t h) {
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
+    if (h->wsplit) hipFree(h->wsplit);
     if (h->dft_fwd) hipFree(h->dft_fwd);
     if (h->dft_inv_t) hipFree(h->dft_inv_t);
     for (auto& e : h->ev)
@@ -510,28 +533,39 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
     float* feat = (float*)h->feat.p; float* x = (float*)h->hx.p; float* u = (float*)h->hu.p;
     float* t1 = (float*)h->ht.p; float* qkv = (float*)h->qkv.p; float* cb = (float*)h->ctxb.p;
     const Weights& W = h->w;
+    // Linear layers: split-f16 operands (h->split) -- every producer of a GEMM input writes the split format
+    // directly (features, LayerNorm, the FFN's first GEMM, attention), the residual stream x stays float32.
+    const int sp = h->split ? 1 : 0;
+    auto WS = [&](const float* w) { return sp ? h->wsplit + (w - h->blob) : w; };
+    auto lin = [&](const float* A, int64_t lda, const float* Wt, const float* bias, float* C, int64_t ldc, int n, int k,
+                   int act, int split_out) {
+        GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
+        g.split_in = sp; g.split_out = sp ? split_out : 0;
+        return g;
+    };
     launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
-                    io.hop, st);
+                    io.hop, sp, st);
     // embed: Linear -> LayerNorm -> ReLU (conformer.py:205-210)
-    gemm(h, linear(feat, h->Kp, W.embed_w, h->Kp, W.embed_b, u, D, M, D, h->Kp, ACT_NONE));
-    launch_layernorm(u, x, W.embed_ln_w, W.embed_ln_b, M, D, 1, st);
+    gemm(h, lin(feat, h->Kp, W.embed_w, W.embed_b, u, D, D, h->Kp, ACT_NONE, 0));
+    launch_layernorm(u, x, nullptr, W.embed_ln_w, W.embed_ln_b, M, D, 1, st);
     for (int l = 0; l < d.num_blocks; ++l) {
         const BlockWeights& b = W.blocks[l];
+        const bool last = l + 1 == d.num_blocks;
         auto ffn = [&](const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2) {
-            launch_layernorm(x, u, lnw, lnb, M, D, 0, st);
-            gemm(h, linear(u, D, w1, D, b1, t1, FF, M, FF, D, ACT_RELU));
-            GemmArgs g = linear(t1, FF, w2, FF, b2, x, D, M, D, FF, ACT_NONE);
+            launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
+            gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, 1));
+            GemmArgs g = lin(t1, FF, w2, b2, x, D, D, FF, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 0.5f;  // x + 0.5 * ff(x)  (conformer.py:179,182)
             gemm(h, g);
         };
         ffn(b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
-        launch_layernorm(x, u, b.att_ln_w, b.att_ln_b, M, D, 0, st);
-        gemm(h, linear(u, D, b.wqkv, D, b.bqkv, qkv, 3 * D, M, 3 * D, D, ACT_NONE));
-        launch_relpos_attention(qkv, W.pe_k, cb, nb, T, D, d.attention_heads, d.maxlen, st);
+        launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
+        gemm(h, lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 0));
+        launch_relpos_attention(qkv, W.pe_k, cb, nb, T, D, d.attention_heads, d.maxlen, sp, st);
         {
-            GemmArgs g = linear(cb, D, b.wo, D, b.bo, x, D, M, D, D, ACT_NONE);
+            GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;
             gemm(h, g);
         }
@@ -539,17 +573,19 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
         launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
         launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
         ffn(b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
-        launch_layernorm(x, x, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);  // conformer.py:184
+        // conformer.py:184; the last block's output also feeds the mask head, as a split operand in u
+        launch_layernorm(x, x, (sp && last) ? u : nullptr, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);
     }
     // mask head (conformer.py:302-310), transposed so that time is the fastest axis of every mask:
     // masks[(k*F + f)][segment*T + t] = sigmoid(head_w[k*F + f] . x[token] + head_b[k*F + f])
     GemmArgs g{};
     const int nout = F * (d.num_spks + d.num_nois);
-    g.A = W.head_w; g.lda = D; g.strideA = 0;
-    g.B = x; g.ldb = D; g.strideB = 0;
+    g.A = WS(W.head_w); g.lda = D; g.strideA = 0;
+    g.B = sp ? u : x; g.ldb = D; g.strideB = 0;
     g.C = io.masks + s0 * T; g.ldc = io.mask_ld; g.strideC = 0;
     g.M = nout; g.N = M; g.K = D; g.batch = 1;
     g.bias = W.head_b; g.bias_along_m = 1; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
+    g.split_in = sp;
     gemm(h, g);
     h->last_batch_tokens = M;
     return CSS_OK;
@@ -896,6 +932,20 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(host, b->p, (size_t)need, hipMemcpyDeviceToHost));
+    if (which == CSS_BUF_FEATURES && h->split) {
+        // the device holds the rows as split-f16 GEMM operands (split_f16.hpp); hand out float32 = hi + lo * 2^-11
+        const int64_t rows = dims[0], K = dims[1];
+        std::vector<float> row((size_t)K);
+        for (int64_t r = 0; r < rows; ++r) {
+            float* dst = (float*)host + r * K;
+            const _Float16* src = (const _Float16*)dst;
+            for (int64_t k = 0; k < K; ++k) {
+                const int64_t i = ((k >> 5) << 6) | (k & 31);
+                row[(size_t)k] = (float)src[i] + (float)src[i + 32] * (1.0f / 2048.0f);
+            }
+            std::memcpy(dst, row.data(), (size_t)K * sizeof(float));
+        }
+    }
     return CSS_OK;
 }
 

@@ -1,6 +1,7 @@
 // Non-GEMM pieces of the Conformer mask estimator (css/css_with_conformer/nnet/conformer.py):
 // LayerNorm (+ReLU / +scalar GLU), the depthwise-conv module and relative-position attention.
 #include "kernels.hpp"
+#include "split_f16.hpp"
 
 namespace css {
 
@@ -21,8 +22,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 template <int NV, int MODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                        const float* __restrict__ pw, int rows) {
+                                                        float* __restrict__ ys, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ pw,
+                                                        int rows) {
     constexpr int D = 256 * NV;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
     if (MODE == 2) { p0 = pw[0]; p1 = pw[1]; p2 = pw[2]; p3 = pw[3]; }
+    // y: float32 rows (may be null); ys: the same rows in the split-f16 GEMM operand format (may be null)
     float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * D);
+    _Float16* ysr = reinterpret_cast<_Float16*>(ys + (int64_t)row * D);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float4 g = reinterpret_cast<const float4*>(w)[lane + 64 * i];
@@ -57,32 +61,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (MODE == 1) o[e] = fmaxf(o[e], 0.f);
             if (MODE == 2) o[e] = (p0 * o[e] + p1) * (1.0f / (1.0f + expf(-(p2 * o[e] + p3))));
         }
-        yr[lane + 64 * i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (y) yr[lane + 64 * i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (ys) split_store4(ysr, 4 * (lane + 64 * i), o[0], o[1], o[2], o[3]);
     }
 }
 
 template <int MODE>
-static void launch_ln_mode(const float* x, float* y, const float* w, const float* b, const float* pw, int rows,
-                           int D, hipStream_t s) {
+static void launch_ln_mode(const float* x, float* y, float* ys, const float* w, const float* b, const float* pw,
+                           int rows, int D, hipStream_t s) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (D) {
-        case 256: hipLaunchKernelGGL((layernorm_kernel<1, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
-        case 512: hipLaunchKernelGGL((layernorm_kernel<2, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
-        case 768: hipLaunchKernelGGL((layernorm_kernel<3, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
-        case 1024: hipLaunchKernelGGL((layernorm_kernel<4, MODE>), grid, block, 0, s, x, y, w, b, pw, rows); break;
+        case 256: hipLaunchKernelGGL((layernorm_kernel<1, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
+        case 512: hipLaunchKernelGGL((layernorm_kernel<2, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
+        case 768: hipLaunchKernelGGL((layernorm_kernel<3, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
+        case 1024: hipLaunchKernelGGL((layernorm_kernel<4, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
         default: break;  // rejected at css_create (attention_dim must be a multiple of 256, <= 1024)
     }
 }
 
-void launch_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int D, int relu,
-                      hipStream_t s) {
-    if (relu) launch_ln_mode<1>(x, y, w, b, nullptr, rows, D, s);
-    else launch_ln_mode<0>(x, y, w, b, nullptr, rows, D, s);
+void launch_layernorm(const float* x, float* y, float* y_split, const float* w, const float* b, int rows, int D,
+                      int relu, hipStream_t s) {
+    if (relu) launch_ln_mode<1>(x, y, y_split, w, b, nullptr, rows, D, s);
+    else launch_ln_mode<0>(x, y, y_split, w, b, nullptr, rows, D, s);
 }
 
 void launch_ln_glu(const float* x, float* z, const float* w, const float* b, const float* pw, int rows, int D,
                    hipStream_t s) {
-    launch_ln_mode<2>(x, z, w, b, pw, rows, D, s);
+    launch_ln_mode<2>(x, z, nullptr, w, b, pw, rows, D, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,7 +162,8 @@ void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw
 // ------------------------------------------------------------------------------------------------
 template <int NJT>
 __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
-                                                         float* __restrict__ ctx, int T, int D, int maxlen) {
+                                                         float* __restrict__ ctx, int T, int D, int maxlen,
+                                                         int split_out) {
     constexpr int DK = 64;
     // The position term lives in an LDS ring of three 32-offset tiles per query row (row stride 98 floats:
     // the skewed reads of 32 lanes land on addresses 3c + const (mod 32), i.e. 32 distinct banks).  A key tile
@@ -300,17 +306,23 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    float* ob = ctx + ((int64_t)seg * T + i0) * D + head * DK;
-    for (int il = 0; il < 32 && i0 + il < T; ++il) ob[(int64_t)il * D + lane] = lds[il * OLD + lane];
+    if (split_out) {   // ctx rows in the split-f16 GEMM operand format (split_f16.hpp) for the output projection
+        float* ob = ctx + ((int64_t)seg * T + i0) * D;
+        for (int il = 0; il < 32 && i0 + il < T; ++il)
+            split_store(reinterpret_cast<_Float16*>(ob + (int64_t)il * D), head * DK + lane, lds[il * OLD + lane]);
+    } else {
+        float* ob = ctx + ((int64_t)seg * T + i0) * D + head * DK;
+        for (int il = 0; il < 32 && i0 + il < T; ++il) ob[(int64_t)il * D + lane] = lds[il * OLD + lane];
+    }
 }
 
 void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, hipStream_t s) {
+                             int maxlen, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
     const dim3 grid(qtiles, H, nseg), block(64);
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
 #define CSS_ATT_CASE(n) \
-    case n: hipLaunchKernelGGL((relpos_attn_kernel<n>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen); break;
+    case n: hipLaunchKernelGGL((relpos_attn_kernel<n>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out); break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)
         CSS_ATT_CASE(5) CSS_ATT_CASE(6) CSS_ATT_CASE(7) CSS_ATT_CASE(8)

@@ -1,6 +1,7 @@
 // Front/back end of the CSS path outside the GEMMs: PCM layout, network input features, and the
 // overlap-add that finishes the inverse transform.
 #include "kernels.hpp"
+#include "split_f16.hpp"
 
 namespace css {
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                                                        int F, float* __restrict__ feat, int Kp,
                                                        const float* __restrict__ in_bias,
                                                        const float* __restrict__ in_scale, int64_t seg_lo, int T,
-                                                       int hop) {
+                                                       int hop, int split_out) {
     __shared__ float tile[32 * FEAT_LD];
     const int f0 = blockIdx.x * 32, m = blockIdx.y, segl = blockIdx.z;
     const int64_t st = (seg_lo + segl) * (int64_t)hop;
@@ -128,17 +129,23 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     if (f < F) {
         const int col = m * F + f;
         const float bi = in_bias[col], sc = in_scale[col];
-        float* out = feat + (int64_t)segl * T * Kp + col;
-        for (int t = wave * 2 + (lane >> 5); t < T; t += 8) out[(int64_t)t * Kp] = (tile[fl * FEAT_LD + t] + bi) * sc;
+        if (split_out) {   // rows in the split-f16 GEMM operand format (split_f16.hpp) for the embed Linear
+            float* out = feat + (int64_t)segl * T * Kp;
+            for (int t = wave * 2 + (lane >> 5); t < T; t += 8)
+                split_store(reinterpret_cast<_Float16*>(out + (int64_t)t * Kp), col, (tile[fl * FEAT_LD + t] + bi) * sc);
+        } else {
+            float* out = feat + (int64_t)segl * T * Kp + col;
+            for (int t = wave * 2 + (lane >> 5); t < T; t += 8) out[(int64_t)t * Kp] = (tile[fl * FEAT_LD + t] + bi) * sc;
+        }
     }
 }
 
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     hipStream_t s) {
+                     int split_out, hipStream_t s) {
     const dim3 grid((F + 31) / 32, C, nseg), block(256);
     hipLaunchKernelGGL(features_kernel, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                       seg_lo, T, hop);
+                       seg_lo, T, hop, split_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,43 +19,9 @@
 // one 16-byte LDS read.  A and B use the same permutation, so the dot product is unchanged.
 #include <cstdlib>
 
-#include "kernels.hpp"
+#include "gemm_common.hpp"
 
 namespace css {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BN = 128, BK = 32, LDS_LD = 36;
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// One 32x32 accumulator tile -> memory.  All 16 residual / row-bias operands are requested (at
-// clamped, always valid addresses) before the first one is consumed, so the epilogue pays one memory
-// round trip per tile instead of one per element; out-of-range elements are computed and not stored.
-__device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int M, int N, float* __restrict__ C,
-                                          int64_t ldc, const float* __restrict__ bias, int bias_m, int act,
-                                          const float* __restrict__ res, int64_t ldr, float alpha) {
-    const bool n_ok = n < N;
-    const int nc = n_ok ? n : N - 1;
-    const float bn = (bias && !bias_m) ? bias[nc] : 0.f;
-    float rv[16], bm[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        const int mc = m < M ? m : M - 1;
-        rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;
-        bm[r] = (bias && bias_m) ? bias[mc] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        float v = acc[r] + bn + bm[r];
-        if (act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
-        if (res) v = rv[r] + alpha * v;
-        if (n_ok && m < M) C[(int64_t)m * ldc + n] = v;
-    }
-}
 
 template <int BM, int WM>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
@@ -69,8 +35,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     // ---- XCD-aware tile mapping: consecutive tiles (which share an A row panel) go to one XCD/L2 ----
     const int n_tiles = tiles_m * tiles_n * g.batch;
     const int L = blockIdx.x;
-    const int q = n_tiles >> 3, rem = n_tiles & 7, xcd = L & 7;
-    const int tile = xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
+    const int tile = xcd_tile(L, n_tiles);
     const int per_batch = tiles_m * tiles_n;
     const int bz = tile / per_batch;
     const int t2 = tile - bz * per_batch;
@@ -181,11 +146,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
     const int mrow = m0 + wm * (BM / WM) + 4 * h, ncol = n0 + wn * 64 + c;
-    emit_tile(acc00, mrow, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
-    emit_tile(acc01, mrow, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
+    emit_tile(acc00, mrow, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
+    emit_tile(acc01, mrow, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
     if constexpr (TM == 2) {
-        emit_tile(acc10, mrow + 32, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
-        emit_tile(acc11, mrow + 32, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha);
+        emit_tile(acc10, mrow + 32, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
+        emit_tile(acc11, mrow + 32, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
     }
 }
 
@@ -197,6 +162,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 // CSS_GEMM_LAYOUT=8|4|64 forces one (experiments; tools/gemm_bench.hip).
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
+    if (g.split_in) return launch_gemm_split(g, s);
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_LAYOUT"); return e ? std::atoi(e) : 0; }();
     const int tiles_n = (g.N + BN - 1) / BN;
     const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;

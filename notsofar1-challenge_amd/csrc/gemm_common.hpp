@@ -1,0 +1,54 @@
+// Pieces shared by the two MFMA GEMM kernels (gemm.hip: exact float32; gemm_split.hip: split-f16 operands):
+// tile constants, the XCD-aware tile mapping and the fused epilogue.
+#pragma once
+#include "kernels.hpp"
+#include "split_f16.hpp"
+
+namespace css {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BN = 128, BK = 32, LDS_LD = 36;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// XCD-aware tile mapping: workgroup L runs on XCD L % 8; give each XCD a contiguous range of tiles (which
+// share A row panels), so that a panel is fetched into ONE of the eight L2s.
+__device__ __forceinline__ int xcd_tile(int L, int n_tiles) {
+    const int q = n_tiles >> 3, rem = n_tiles & 7, xcd = L & 7;
+    return xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
+}
+
+// One 32x32 accumulator tile -> memory.  All 16 residual / row-bias operands are requested (at
+// clamped, always valid addresses) before the first one is consumed, so the epilogue pays one memory
+// round trip per tile instead of one per element; out-of-range elements are computed and not stored.
+// split_out: C is a split-f16 matrix (split_f16.hpp) with ldc elements (= ldc floats) per row.
+__device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int M, int N, float* __restrict__ C,
+                                          int64_t ldc, const float* __restrict__ bias, int bias_m, int act,
+                                          const float* __restrict__ res, int64_t ldr, float alpha, int split_out) {
+    const bool n_ok = n < N;
+    const int nc = n_ok ? n : N - 1;
+    const float bn = (bias && !bias_m) ? bias[nc] : 0.f;
+    float rv[16], bm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const int mc = m < M ? m : M - 1;
+        rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;
+        bm[r] = (bias && bias_m) ? bias[mc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + bn + bm[r];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+        if (res) v = rv[r] + alpha * v;
+        if (n_ok && m < M) {
+            if (split_out) split_store(reinterpret_cast<_Float16*>(C + (int64_t)m * ldc), n, v);
+            else C[(int64_t)m * ldc + n] = v;
+        }
+    }
+}
+
+}  // namespace css

@@ -24,15 +24,24 @@ struct GemmArgs {
     const float* residual;  // nullptr or [M][ldr]: C = residual + alpha * (acc + bias)
     int64_t ldr;
     float alpha;            // only with residual
+    // split-f16 operands (split_f16.hpp): A and B are split matrices addressed as float matrices (lda / ldb = their
+    // padded K); three f16 MFMAs per product, float32 accumulation.  split_out: C is written as a split matrix
+    // (ldc = its padded row length in elements) for the next GEMM to consume.
+    int split_in;
+    int split_out;
 };
-void launch_gemm(const GemmArgs& g, hipStream_t s);
+void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
+void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
+// float32 [rows][K] (row stride ld_src) -> split-f16 [rows][Kp] (Kp % 32 == 0, zero padded past K)
+void launch_split_convert(const float* src, int64_t ld_src, float* dst, int64_t rows, int K, int Kp, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // encoder.hip -- the non-GEMM pieces of the Conformer
 // ------------------------------------------------------------------------------------------------
-// y = LN(x) * w + b over rows of length D (D % 256 == 0, D <= 1024); optional ReLU.
-void launch_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int D, int relu,
-                      hipStream_t s);
+// y = LN(x) * w + b over rows of length D (D % 256 == 0, D <= 1024); optional ReLU.  y (float32) and y_split
+// (the same rows as a split-f16 GEMM operand, split_f16.hpp) are each optional.
+void launch_layernorm(const float* x, float* y, float* y_split, const float* w, const float* b, int rows, int D,
+                      int relu, hipStream_t s);
 // conv-module front half: u = LN(x); z = (pw[0]*u + pw[1]) * sigmoid(pw[2]*u + pw[3])
 void launch_ln_glu(const float* x, float* z, const float* w, const float* b, const float* pw, int rows, int D,
                    hipStream_t s);
@@ -40,9 +49,9 @@ void launch_ln_glu(const float* x, float* z, const float* w, const float* b, con
 // ReLU, scalar pointwise conv, residual:  h += pw[4] * relu((conv(z) + dw_b) * alpha + beta) + pw[5]
 void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
                    const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s);
-// relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D]
+// relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows)
 void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, hipStream_t s);
+                             int maxlen, int split_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add
@@ -50,10 +59,11 @@ void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, in
 // samples [i_lo, i_hi) of every channel: pcm [n][C] -> pcm_cm [C][n_pad] (zeros past n)
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
                          hipStream_t s);
-// features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded)
+// features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
+// or split-f16 rows (split_f16.hpp; the padding columns are never written and must be zero)
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     hipStream_t s);
+                     int split_out, hipStream_t s);
 // out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
 // only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
 void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,

@@ -1,6 +1,7 @@
 // Stand-alone timing of css::launch_gemm on the shapes of the CSS path (tools only, not shipped).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip notsofar1-challenge_amd/csrc/gemm.hip \
 //         -Inotsofar1-challenge_amd/csrc -o gpurun_out/gemm_bench && gpurun_out/gemm_bench
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -13,8 +14,10 @@ int main() {
                       {514, 3749, 512, 7, "stft"}, {23808, 512, 512, 1, "wo 128seg"}, {23808, 1536, 512, 1, "qkv 128seg"},
                       {4096, 4096, 4096, 1, "4096^3"}};
     size_t maxe = 4096ull * 4096 * 2;
-    float *A, *B, *C;
+    float *A, *B, *C, *As, *Bs, *Cs;
     hipMalloc(&A, maxe * 4 * 2); hipMalloc(&B, maxe * 4 * 2); hipMalloc(&C, maxe * 4 * 2);
+    hipMalloc(&As, maxe * 4 * 2); hipMalloc(&Bs, maxe * 4 * 2); hipMalloc(&Cs, maxe * 4 * 2);
+    std::vector<float> c32(maxe * 2), c16(maxe * 2);
     std::vector<float> h(maxe * 2);
     unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
     hipMemcpy(A, h.data(), maxe * 8, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), maxe * 8, hipMemcpyHostToDevice);
@@ -37,6 +40,28 @@ int main() {
         printf("%-12s M=%6d N=%5d K=%5d b=%d  %8.2f us  %7.2f TFLOP/s  blocks=%d\n", sh.name, sh.M, sh.N, sh.K, sh.batch,
                1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12, ((sh.M + 127) / 128) * ((sh.N + 127) / 128) * sh.batch);
         hipMemcpy(h.data(), C, 64 * 4, hipMemcpyDeviceToHost); double cs = 0; for (int i = 0; i < 64; ++i) cs += h[i] * (i + 1); printf("      checksum %.9g\n", cs);
+        // ---- the same product with split-f16 operands (3 f16 MFMAs per product) ----
+        if (sh.batch == 1) {
+            launch_split_convert(A, sh.K, As, sh.M, sh.K, sh.K, st);
+            launch_split_convert(B, sh.K, Bs, sh.N, sh.K, sh.K, st);
+            GemmArgs q = g; q.A = As; q.B = Bs; q.C = Cs; q.split_in = 1;
+            if (sh.mode == 1) q.residual = C;
+            GemmArgs r = g; if (sh.mode == 1) { r.C = Cs + maxe; }
+            // reference for the residual case: fp32 into a separate buffer reading residual C
+            for (int i = 0; i < 3; ++i) launch_gemm(q, st);
+            hipEventRecord(e0, st);
+            for (int i = 0; i < it; ++i) launch_gemm(q, st);
+            hipEventRecord(e1, st); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            double maxd = -1, maxv = 0;
+            if (sh.mode != 1) {
+                size_t ne = (size_t)sh.M * sh.N;
+                hipMemcpy(c32.data(), C, ne * 4, hipMemcpyDeviceToHost); hipMemcpy(c16.data(), Cs, ne * 4, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < ne; ++i) { double d = fabs((double)c32[i] - c16[i]); if (d > maxd) maxd = d; if (fabs(c32[i]) > maxv) maxv = fabs(c32[i]); }
+            }
+            printf("   split-f16x3           %8.2f us  %7.2f TFLOP/s (fp32-equivalent)   max|diff vs f32| %.3g (max|C| %.3g)\n",
+                   1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12, maxd, maxv);
+        }
     }
     return 0;
 }
