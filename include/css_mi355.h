@@ -179,6 +179,15 @@ int css_get_timings(css_handle_t h, CssTimings* out);
 /* enable != 0: bracket every MFMA GEMM launch of the mask estimator with HIP events on the handle's
  * stream, so that CssTimings.gemm_ms / gemm_launches report the live average launch duration. */
 int css_set_profile(css_handle_t h, int enable);
+/* Arithmetic of the Conformer's Linear layers (torch.nn.Linear in conformer.py:49-53,139-142,206,285):
+ *   CSS_LINEAR_SPLIT_F16 (default)  operands carried as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product,
+ *                                   float32 accumulation: float32-grade accuracy at 5.3x the float32 matrix rate;
+ *   CSS_LINEAR_EXACT_F32            the exact float32 MFMA chain (bit-identical to an fmaf loop over k).
+ * The default of a new handle is CSS_LINEAR_SPLIT_F16 unless the environment holds CSS_EXACT_F32=1 at css_create.
+ * May be switched between runs. */
+enum css_linear_mode { CSS_LINEAR_SPLIT_F16 = 0, CSS_LINEAR_EXACT_F32 = 1 };
+int css_set_linear_mode(css_handle_t h, int mode);
+int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css_status */
 int css_get_plan(css_handle_t h, CssPlan* out);
 
 /* ---- stages (each replaces one reference function; state lives in the handle) -------------- */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_get_timings": (C.c_int, [_P, C.POINTER(CssTimings)]),
     "css_set_profile": (C.c_int, [_P, C.c_int]),
+    "css_set_linear_mode": (C.c_int, [_P, C.c_int]),
+    "css_get_linear_mode": (C.c_int, [_P]),
     "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
     "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
     "css_stage_stft": (C.c_int, [_P]),
@@ -253,6 +255,16 @@ class Handle:
 
     def set_profile(self, enable: bool):
         check(self.h, self.lib.css_set_profile(self.h, int(enable)))
+
+    def set_linear_mode(self, mode):
+        """"split_f16" (default: float32-grade accuracy on the f16 matrix cores) or "exact_f32"."""
+        check(self.h, self.lib.css_set_linear_mode(self.h, {"split_f16": 0, "exact_f32": 1}[mode]))
+
+    def linear_mode(self):
+        m = self.lib.css_get_linear_mode(self.h)
+        if m < 0:
+            check(self.h, m)
+        return ("split_f16", "exact_f32")[m]
 
     def get_plan(self) -> CssPlan:
         p = CssPlan()

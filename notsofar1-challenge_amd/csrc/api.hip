@@ -276,6 +276,28 @@ int ensure_activations(css_ctx* h, int64_t nb, int T) {
     return CSS_OK;
 }
 
+// split-f16 images of every Linear weight, at the blob's own offsets (a split matrix has the size of its source)
+int make_split_weights(css_ctx* h) {
+    if (h->wsplit) return CSS_OK;
+    const CssModelDesc& d = h->d;
+    const int64_t need = bind_weights(d, nullptr, nullptr);
+    HIPCHK(h, hipMalloc((void**)&h->wsplit, need * sizeof(float)));
+    const int D = d.attention_dim, FF = d.linear_units;
+    auto conv = [&](const float* w, int64_t rows, int K) {
+        launch_split_convert(w, K, h->wsplit + (w - h->blob), rows, K, K, h->stream);
+    };
+    conv(h->w.embed_w, D, h->Kp);
+    for (const BlockWeights& b : h->w.blocks) {
+        conv(b.ffi_w1, FF, D); conv(b.ffi_w2, D, FF);
+        conv(b.wqkv, 3 * D, D); conv(b.wo, D, D);
+        conv(b.ffo_w1, FF, D); conv(b.ffo_w2, D, FF);
+    }
+    conv(h->w.head_w, (int64_t)d.num_bins * (d.num_spks + d.num_nois), D);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
 int check_session(css_ctx* h) {
     if (!h) return CSS_ERR_INVALID_ARG;
     if (!h->has_session) return fail(h, CSS_ERR_STATE, "no session: call css_begin first");
@@ -337,22 +359,7 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         return bail(CSS_ERR_HIP, "weight upload failed");
     bind_weights(*desc, h->blob, &h->w);
     if (const char* e = std::getenv("CSS_EXACT_F32")) h->split = !(e[0] == '1');
-    if (h->split) {
-        if (hipMalloc((void**)&h->wsplit, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(split weights) failed");
-        const int D = desc->attention_dim, FF = desc->linear_units;
-        auto conv = [&](const float* w, int64_t rows, int K) {
-            launch_split_convert(w, K, h->wsplit + (w - h->blob), rows, K, K, h->stream);
-        };
-        conv(h->w.embed_w, D, h->Kp);
-        for (const BlockWeights& b : h->w.blocks) {
-            conv(b.ffi_w1, FF, D); conv(b.ffi_w2, D, FF);
-            conv(b.wqkv, 3 * D, D); conv(b.wo, D, D);
-            conv(b.ffo_w1, FF, D); conv(b.ffo_w2, D, FF);
-        }
-        conv(h->w.head_w, (int64_t)desc->num_bins * (desc->num_spks + desc->num_nois), D);
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess)
-            return bail(CSS_ERR_HIP, "split-f16 weight conversion failed");
-    }
+    if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
 
     // transform matrices (feature.py:19-45): analysis = Hann * DFT, S = 1; synthesis = sqrt-Hann * DFT / 16
     const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
@@ -778,6 +785,26 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                    float* wav_dev, int64_t cap) {
     return run_impl(h, pcm_dev, n_samples, n_ch, cfg, wav_dev, cap, 1);
+}
+
+int css_set_linear_mode(css_handle_t h, int mode) {
+    if (!h || (mode != CSS_LINEAR_SPLIT_F16 && mode != CSS_LINEAR_EXACT_F32)) return fail(h, CSS_ERR_INVALID_ARG, "unknown linear mode");
+    const bool split = mode == CSS_LINEAR_SPLIT_F16;
+    if (split == h->split) return CSS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (split) {
+        int rc = make_split_weights(h);
+        if (rc) return rc;
+    }
+    // the feature rows change format; their K padding must read as zero in either
+    if (h->feat.p) HIPCHK(h, hipMemsetAsync(h->feat.p, 0, h->feat.cap, h->stream));
+    h->split = split;
+    return CSS_OK;
+}
+
+int css_get_linear_mode(css_handle_t h) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    return h->split ? CSS_LINEAR_SPLIT_F16 : CSS_LINEAR_EXACT_F32;
 }
 
 int css_set_profile(css_handle_t h, int enable) {
