@@ -276,15 +276,17 @@ int ensure_activations(css_ctx* h, int64_t nb, int T) {
     return CSS_OK;
 }
 
-// split-f16 images of every Linear weight, at the blob's own offsets (a split matrix has the size of its source)
+// split-f16 images of every Linear weight, at the blob's own offsets (a split matrix has the size of its source):
+// tile-major (gemm_split_wd.hip: the weight operand goes straight from global memory into MFMA registers) for the
+// layers whose weight is the B operand, row-major for the mask head, where the weight is the A operand.
 int make_split_weights(css_ctx* h) {
     if (h->wsplit) return CSS_OK;
     const CssModelDesc& d = h->d;
     const int64_t need = bind_weights(d, nullptr, nullptr);
     HIPCHK(h, hipMalloc((void**)&h->wsplit, need * sizeof(float)));
     const int D = d.attention_dim, FF = d.linear_units;
-    auto conv = [&](const float* w, int64_t rows, int K) {
-        launch_split_convert(w, K, h->wsplit + (w - h->blob), rows, K, K, h->stream);
+    auto conv = [&](const float* w, int rows, int K) {
+        launch_split_convert_tiled(w, K, h->wsplit + (w - h->blob), rows, K, h->stream);
     };
     conv(h->w.embed_w, D, h->Kp);
     for (const BlockWeights& b : h->w.blocks) {
@@ -292,7 +294,8 @@ int make_split_weights(css_ctx* h) {
         conv(b.wqkv, 3 * D, D); conv(b.wo, D, D);
         conv(b.ffo_w1, FF, D); conv(b.ffo_w2, D, FF);
     }
-    conv(h->w.head_w, (int64_t)d.num_bins * (d.num_spks + d.num_nois), D);
+    launch_split_convert(h->w.head_w, D, h->wsplit + (h->w.head_w - h->blob), (int64_t)d.num_bins * (d.num_spks + d.num_nois), D,
+                         D, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -547,7 +550,7 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
     auto lin = [&](const float* A, int64_t lda, const float* Wt, const float* bias, float* C, int64_t ldc, int n, int k,
                    int act, int split_out) {
         GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
-        g.split_in = sp; g.split_out = sp ? split_out : 0;
+        g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp;
         return g;
     };
     launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,

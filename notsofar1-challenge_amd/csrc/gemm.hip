@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 // CSS_GEMM_LAYOUT=8|4|64 forces one (experiments; tools/gemm_bench.hip).
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
-    if (g.split_in) return launch_gemm_split(g, s);
+    if (g.split_in) return g.b_tiled ? launch_gemm_split_wd(g, s) : launch_gemm_split(g, s);
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_LAYOUT"); return e ? std::atoi(e) : 0; }();
     const int tiles_n = (g.N + BN - 1) / BN;
     const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;

@@ -29,9 +29,15 @@ struct GemmArgs {
     // (ldc = its padded row length in elements) for the next GEMM to consume.
     int split_in;
     int split_out;
+    // b_tiled (with split_in): B is a weight matrix in the tile-major split layout of gemm_split_wd.hip
+    // (launch_split_convert_tiled); batch must be 1 and N % 32 == 0.
+    int b_tiled;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
+void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s);  // gemm_split_wd.hip (g.b_tiled)
+// float32 W [N][K] (row stride ld_src, K % 32 == 0) -> tile-major split-f16 weights, (N rounded up to 32) * K floats
+void launch_split_convert_tiled(const float* src, int64_t ld_src, float* dst, int N, int K, hipStream_t s);
 // float32 [rows][K] (row stride ld_src) -> split-f16 [rows][Kp] (Kp % 32 == 0, zero padded past K)
 void launch_split_convert(const float* src, int64_t ld_src, float* dst, int64_t rows, int K, int Kp, hipStream_t s);
 

@@ -1,7 +1,9 @@
 // Stand-alone timing of css::launch_gemm on the shapes of the CSS path (tools only, not shipped).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip notsofar1-challenge_amd/csrc/gemm.hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip notsofar1-challenge_amd/csrc/gemm.hip notsofar1-challenge_amd/csrc/gemm_split.hip notsofar1-challenge_amd/csrc/gemm_split_wd.hip \
 //         -Inotsofar1-challenge_amd/csrc -o gpurun_out/gemm_bench && gpurun_out/gemm_bench
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <cstdio>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -9,9 +11,11 @@
 using namespace css;
 int main() {
     struct Shape { int M, N, K, batch; const char* name; int mode; };  // mode 1: bias+residual, 2: row bias + sigmoid
-    Shape shapes[] = {{7440, 512, 512, 1, "wo 40seg", 0}, {7440, 512, 512, 1, "wo +res", 1}, {7440, 1024, 512, 1, "ffn1", 0}, {7440, 512, 1024, 1, "ffn2", 0}, {7440, 512, 1024, 1, "ffn2 +res", 1},
+    Shape shapes[] = {{7440, 512, 4096, 1, "K=4096", 0}, {7440, 512, 32, 1, "K=32", 0}, {7440, 512, 64, 1, "K=64", 0}, {7440, 512, 128, 1, "K=128", 0}, {7440, 512, 256, 1, "K=256", 0},
+                      {7440, 512, 32, 1, "K=32 +res", 1}, {7440, 1024, 32, 1, "K=32 N=1024", 0},
+                      {7440, 512, 512, 1, "wo 40seg", 0}, {7440, 512, 512, 1, "wo +res", 1}, {7440, 1024, 512, 1, "ffn1", 0}, {7440, 512, 1024, 1, "ffn2", 0}, {7440, 512, 1024, 1, "ffn2 +res", 1},
                       {7440, 1536, 512, 1, "qkv"}, {1028, 7440, 512, 1, "head", 0}, {1028, 7440, 512, 1, "head +sig", 2}, {7440, 512, 1824, 1, "embed"},
-                      {514, 3749, 512, 7, "stft"}, {23808, 512, 512, 1, "wo 128seg"}, {23808, 1536, 512, 1, "qkv 128seg"},
+                      {514, 3749, 512, 7, "stft"}, {23808, 512, 512, 1, "wo 128seg"}, 
                       {4096, 4096, 4096, 1, "4096^3"}};
     size_t maxe = 4096ull * 4096 * 2;
     float *A, *B, *C, *As, *Bs, *Cs;
@@ -23,7 +27,9 @@ int main() {
     hipMemcpy(A, h.data(), maxe * 8, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), maxe * 8, hipMemcpyHostToDevice);
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const char* only = getenv("GEMM_BENCH_ONLY");   // substring filter on the shape name
     for (auto& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
         GemmArgs g{};
         g.A = A; g.lda = sh.K; g.strideA = 0; g.B = B; g.ldb = sh.K; g.strideB = (int64_t)sh.N * sh.K;
         g.C = C; g.ldc = sh.N; g.strideC = (int64_t)sh.M * sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.batch = sh.batch; g.alpha = 1.f;
@@ -58,6 +64,22 @@ int main() {
                 size_t ne = (size_t)sh.M * sh.N;
                 hipMemcpy(c32.data(), C, ne * 4, hipMemcpyDeviceToHost); hipMemcpy(c16.data(), Cs, ne * 4, hipMemcpyDeviceToHost);
                 for (size_t i = 0; i < ne; ++i) { double d = fabs((double)c32[i] - c16[i]); if (d > maxd) maxd = d; if (fabs(c32[i]) > maxv) maxv = fabs(c32[i]); }
+            }
+            if (sh.N % 32 == 0) {   // weights-direct variant (B tile-major)
+                launch_split_convert_tiled(B, sh.K, Bs + maxe, sh.N, sh.K, st);
+                GemmArgs w = q; w.B = Bs + maxe; w.b_tiled = 1; w.C = Cs + maxe;
+                for (int i = 0; i < 3; ++i) launch_gemm(w, st);
+                hipEventRecord(e0, st);
+                for (int i = 0; i < it; ++i) launch_gemm(w, st);
+                hipEventRecord(e1, st); hipEventSynchronize(e1);
+                float ms2; hipEventElapsedTime(&ms2, e0, e1);
+                double md = -1;
+                if (sh.mode != 1) {
+                    size_t ne = (size_t)sh.M * sh.N;
+                    hipMemcpy(c32.data(), Cs, ne * 4, hipMemcpyDeviceToHost); hipMemcpy(c16.data(), Cs + maxe, ne * 4, hipMemcpyDeviceToHost);
+                    for (size_t i = 0; i < ne; ++i) { double d = fabs((double)c32[i] - c16[i]); if (d > md) md = d; }
+                }
+                printf("   split-f16x3 W-direct  %8.2f us  %7.2f TFLOP/s   max|diff vs split| %.3g\n", 1e3 * ms2 / it, fl / (ms2 / it * 1e-3) / 1e12, md);
             }
             printf("   split-f16x3           %8.2f us  %7.2f TFLOP/s (fp32-equivalent)   max|diff vs f32| %.3g (max|C| %.3g)\n",
                    1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12, maxd, maxv);
