@@ -296,6 +296,9 @@ int make_split_weights(css_ctx* h) {
     }
     launch_split_convert(h->w.head_w, D, h->wsplit + (h->w.head_w - h->blob), (int64_t)d.num_bins * (d.num_spks + d.num_nois), D,
                          D, h->stream);
+    // the relative-position table, row-major split: the attention kernel uses its rows like key rows
+    const int dk = D / d.attention_heads;
+    launch_split_convert(h->w.pe_k, dk, h->wsplit + (h->w.pe_k - h->blob), 2 * (int64_t)d.maxlen, dk, dk, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -564,7 +567,7 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
         auto ffn = [&](const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2) {
             launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
-            gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, 1));
+            gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, FF));
             GemmArgs g = lin(t1, FF, w2, b2, x, D, D, FF, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 0.5f;  // x + 0.5 * ff(x)  (conformer.py:179,182)
             gemm(h, g);
@@ -572,8 +575,9 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
         ffn(b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
         launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
-        gemm(h, lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 0));
-        launch_relpos_attention(qkv, W.pe_k, cb, nb, T, D, d.attention_heads, d.maxlen, sp, st);
+        // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
+        gemm(h, lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D));
+        launch_relpos_attention(qkv, WS(W.pe_k), cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
         {
             GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;

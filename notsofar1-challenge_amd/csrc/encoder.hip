@@ -6,6 +6,7 @@
 namespace css {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -160,7 +161,7 @@ void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw
 // offsets a 32-query tile can see (never the reference's [T,T,64] gather), staged through LDS to
 // apply the per-row skew B[i][j] = R[i][i - j - r0].
 // ------------------------------------------------------------------------------------------------
-template <int NJT>
+template <int NJT, bool QKS>
 __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen,
                                                          int split_out) {
@@ -180,21 +181,38 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     const int i0 = qt * 32;
     const int iq = min(i0 + c, T - 1);
 
+    // QKS: q, k and pe rows arrive as split-f16 operands (split_f16.hpp; the QKV GEMM writes them, css_create
+    // converts pe).  Chunk 2*kk + part of a row is the 16 bytes this lane feeds to v_mfma_f32_32x32x16_f16 for
+    // k = 16 kk + 8 h .. + 7 (part 0 = hi, 1 = lo): float offset (kk >> 1) * 32 + (kk & 1) * 8 + 4 h + 16 part.
     float4 q[8];
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) q[ch] = *reinterpret_cast<const float4*>(qb + (int64_t)iq * ld + 8 * ch + 4 * h);
+#define CSS_ATT_LOAD8(dst, rowptr)                                                                      \
+    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch)                                                    \
+        dst[ch] = *reinterpret_cast<const float4*>((rowptr) + (QKS ? ((ch >> 2) * 32 + ((ch >> 1) & 1) * 8 + (ch & 1) * 16) : 8 * ch) + 4 * h);
+    CSS_ATT_LOAD8(q, qb + (int64_t)iq * ld)
 
     // Operand tiles are prefetched a whole tile (8 x 16 B per lane) ahead of the 32 MFMAs that consume
     // them: the compiler's own schedule kept one load in flight (vmcnt(1) every 4 MFMAs) and exposed the
     // L2 latency 8 times per tile.
-#define CSS_ATT_LOAD8(dst, rowptr)                                                                      \
-    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) dst[ch] = *reinterpret_cast<const float4*>((rowptr) + 8 * ch + 4 * h);
-#define CSS_ATT_MFMA32(acc, src)                                                              \
-    _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                        \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].x, q[ch].x, acc, 0, 0, 0);         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].y, q[ch].y, acc, 0, 0, 0);         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].z, q[ch].z, acc, 0, 0, 0);         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].w, q[ch].w, acc, 0, 0, 0);         \
+    // acc (zero on entry) = src . q over d_k = 64: 32 float32 MFMAs, or 12 f16 MFMAs on split operands
+    // (hi*hi into acc, hi*lo + lo*hi into a second accumulator that is folded in with 2^-11)
+#define CSS_ATT_MFMA32(acc, src)                                                                  \
+    if constexpr (QKS) {                                                                          \
+        f32x16 cor_ = {0};                                                                        \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+            const f16x8 sh_ = __builtin_bit_cast(f16x8, src[2 * kk]), sl_ = __builtin_bit_cast(f16x8, src[2 * kk + 1]); \
+            const f16x8 qh_ = __builtin_bit_cast(f16x8, q[2 * kk]), ql_ = __builtin_bit_cast(f16x8, q[2 * kk + 1]);     \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, qh_, acc, 0, 0, 0);                 \
+            cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, ql_, cor_, 0, 0, 0);               \
+            cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl_, qh_, cor_, 0, 0, 0);               \
+        }                                                                                         \
+        acc += cor_ * SPLIT_LO_INV;                                                               \
+    } else {                                                                                      \
+        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                        \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].x, q[ch].x, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].y, q[ch].y, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].z, q[ch].z, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].w, q[ch].w, acc, 0, 0, 0);         \
+        }                                                                                         \
     }
     const int rel0 = i0 - (T - 1);
     auto pe_row = [&](int rt) {
@@ -317,12 +335,15 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
 }
 
 void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, int split_out, hipStream_t s) {
+                             int maxlen, int qk_split, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
     const dim3 grid(qtiles, H, nseg), block(64);
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
-#define CSS_ATT_CASE(n) \
-    case n: hipLaunchKernelGGL((relpos_attn_kernel<n>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out); break;
+#define CSS_ATT_CASE(n)                                                                                                      \
+    case n:                                                                                                                  \
+        if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out);  \
+        else hipLaunchKernelGGL((relpos_attn_kernel<n, false>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out);          \
+        break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)
         CSS_ATT_CASE(5) CSS_ATT_CASE(6) CSS_ATT_CASE(7) CSS_ATT_CASE(8)

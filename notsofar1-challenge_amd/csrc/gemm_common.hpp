@@ -22,7 +22,8 @@ __device__ __forceinline__ int xcd_tile(int L, int n_tiles) {
 // One 32x32 accumulator tile -> memory.  All 16 residual / row-bias operands are requested (at
 // clamped, always valid addresses) before the first one is consumed, so the epilogue pays one memory
 // round trip per tile instead of one per element; out-of-range elements are computed and not stored.
-// split_out: C is a split-f16 matrix (split_f16.hpp) with ldc elements (= ldc floats) per row.
+// split_out: columns [0, split_out) of C are written in the split-f16 format (split_f16.hpp; ldc elements = ldc
+// floats per row either way, the 32-column groups of the two formats coincide), the rest as float32.
 __device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int M, int N, float* __restrict__ C,
                                           int64_t ldc, const float* __restrict__ bias, int bias_m, int act,
                                           const float* __restrict__ res, int64_t ldr, float alpha, int split_out) {
@@ -45,7 +46,7 @@ __device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int 
         else if (act == ACT_SIGMOID) v = sigmoidf_(v);
         if (res) v = rv[r] + alpha * v;
         if (n_ok && m < M) {
-            if (split_out) split_store(reinterpret_cast<_Float16*>(C + (int64_t)m * ldc), n, v);
+            if (n < split_out) split_store(reinterpret_cast<_Float16*>(C + (int64_t)m * ldc), n, v);
             else C[(int64_t)m * ldc + n] = v;
         }
     }

@@ -25,8 +25,8 @@ struct GemmArgs {
     int64_t ldr;
     float alpha;            // only with residual
     // split-f16 operands (split_f16.hpp): A and B are split matrices addressed as float matrices (lda / ldb = their
-    // padded K); three f16 MFMAs per product, float32 accumulation.  split_out: C is written as a split matrix
-    // (ldc = its padded row length in elements) for the next GEMM to consume.
+    // padded K); three f16 MFMAs per product, float32 accumulation.  split_out = n > 0: columns [0, n) of C are
+    // written in the split format for the next consumer (n % 32 == 0), the remaining columns as float32.
     int split_in;
     int split_out;
     // b_tiled (with split_in): B is a weight matrix in the tile-major split layout of gemm_split_wd.hip
@@ -55,9 +55,11 @@ void launch_ln_glu(const float* x, float* z, const float* w, const float* b, con
 // ReLU, scalar pointwise conv, residual:  h += pw[4] * relu((conv(z) + dw_b) * alpha + beta) + pw[5]
 void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
                    const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s);
-// relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows)
+// relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows).
+// qk_split: the q and k columns of qkv and the rows of pe_k are split-f16 (scores on the f16 matrix cores with
+// float32-grade accuracy); v is float32 either way.
 void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, int split_out, hipStream_t s);
+                             int maxlen, int qk_split, int split_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add
