@@ -54,6 +54,7 @@ struct css_ctx {
     // with CSS_EXACT_F32=1 in the environment at css_create, the exact float32 MFMA chain of gemm.hip (A/B tests).
     bool split = true;
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
+    float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
     float* dft_fwd = nullptr;    // [2F][frame_len]
     float* dft_inv_t = nullptr;  // [frame_len][KIp]
 
@@ -66,7 +67,7 @@ struct css_ctx {
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host;
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
-        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage;
+        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part;
     int64_t last_batch_tokens = 0;
     const float* pcm_src = nullptr;  // sample-major PCM on the device for the current session
 
@@ -147,7 +148,7 @@ int64_t bind_weights(const CssModelDesc& d, const float* base, Weights* w) {
 
 const char* validate_desc(const CssModelDesc& d) {
     if (d.num_mics != 1 && d.num_mics != 7) return "num_mics must be 1 or 7";
-    if (d.frame_len != 2 * d.frame_hop || d.frame_len % 32) return "frame_len must equal 2*frame_hop and be a multiple of 32";
+    if (d.frame_len != 2 * d.frame_hop || d.frame_len % 64) return "frame_len must equal 2*frame_hop and be a multiple of 64";
     if (d.num_bins != d.frame_len / 2 + 1) return "num_bins must be frame_len/2 + 1";
     if (d.in_features != d.num_bins * d.num_mics) return "in_features must be num_bins * num_mics (magnitude + one IPD block per extra mic)";
     if (d.attention_dim % 256 || d.attention_dim > 1024 || d.attention_dim <= 0) return "attention_dim must be a multiple of 256, at most 1024";
@@ -244,6 +245,7 @@ StitchArgs stitch_args(css_ctx* h) {
     a.act_b = (uint8_t*)h->act_b.p; a.act_tmp = (uint8_t*)h->act_tmp.p; a.act_final = (uint8_t*)h->act_final.p;
     a.activity_th = h->cfg.activity_th; a.dilation = h->cfg.dilation_frames; a.erosion = h->cfg.erosion_frames;
     a.Y = (float*)h->Y.p; a.KIp = h->KIp;
+    a.y_split = h->split ? 1 : 0;
     return a;
 }
 
@@ -296,6 +298,9 @@ int make_split_weights(css_ctx* h) {
     }
     launch_split_convert(h->w.head_w, D, h->wsplit + (h->w.head_w - h->blob), (int64_t)d.num_bins * (d.num_spks + d.num_nois), D,
                          D, h->stream);
+    // the synthesis transform matrix, row-major split
+    HIPCHK(h, hipMalloc((void**)&h->dft_split, (size_t)d.frame_len * h->KIp * sizeof(float)));
+    launch_split_convert(h->dft_inv_t, h->KIp, h->dft_split, d.frame_len, h->KIp, h->KIp, h->stream);
     // the relative-position table, row-major split: the attention kernel uses its rows like key rows
     const int dk = D / d.attention_heads;
     launch_split_convert(h->w.pe_k, dk, h->wsplit + (h->w.pe_k - h->blob), 2 * (int64_t)d.maxlen, dk, dk, h->stream);
@@ -365,8 +370,6 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         return bail(CSS_ERR_HIP, "weight upload failed");
     bind_weights(*desc, h->blob, &h->w);
     if (const char* e = std::getenv("CSS_EXACT_F32")) h->split = !(e[0] == '1');
-    if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
-
     // transform matrices (feature.py:19-45): analysis = Hann * DFT, S = 1; synthesis = sqrt-Hann * DFT / 16
     const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
     std::vector<float> fwd((size_t)2 * F * N), inv((size_t)N * KI, 0.f);
@@ -390,6 +393,7 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     if (hipMemcpy(h->dft_fwd, fwd.data(), fwd.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->dft_inv_t, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "dft upload failed");
+    if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
     *out = h;
     return CSS_OK;
 }
@@ -400,11 +404,12 @@ int css_destroy(css_handle_t h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
-                      &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage};
+                      &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->wsplit) hipFree(h->wsplit);
+    if (h->dft_split) hipFree(h->dft_split);
     if (h->dft_fwd) hipFree(h->dft_fwd);
     if (h->dft_inv_t) hipFree(h->dft_inv_t);
     for (auto& e : h->ev)
@@ -451,7 +456,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     h->cfg.w_last = h->w_host.data() + 2 * T;
     h->plan = p;
     h->n_ch = n_ch;
-    h->n_pad = (n_samples + 3) / 4 * 4;
+    h->n_pad = (n_samples + 31) / 32 * 32;   // whole 32-sample groups: the rows may be stored as split-f16 operands
     h->T_ld = (p.mix_frames + 3) / 4 * 4;
     h->stft_done = h->perms_done = h->have_override = false;
     h->has_session = true;
@@ -473,6 +478,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     ENS(bfw, (size_t)nseg * S * F * 7 * 2 * sizeof(double))
     ENS(sep, (size_t)nseg * S * F * T * 2 * sizeof(float))
     ENS(costs, (size_t)std::max<int64_t>(nseg - 1, 1) * S * S * sizeof(double))
+    ENS(pit_part, pit_cost_scratch_bytes(nseg - 1))
     ENS(perms, (size_t)nseg * S * sizeof(int32_t))
     ENS(mask_st, (size_t)S * F * TL * sizeof(float))
     ENS(activity, (size_t)S * TL * sizeof(float))
@@ -510,7 +516,11 @@ int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     if (f_hi > t_lo) {
         // channel-major copy of exactly the samples these frames read, then DFT-matrix x frames
         const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
-        launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, h->stream);
+        // The analysis transform stays on the exact float32 MFMA path in either mode: the 7x7 MVDR solve amplifies
+        // rounding noise of X by the condition number of the noise covariance (~200x on the test meetings), and
+        // split-f16 operands (22 significant bits) tripled that noise -- measured: waveform distance to the reference
+        // on identical decisions 4e-5 -> 1.1e-4.  The synthesis transform has no such amplifier and does use it.
+        launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, h->stream);
         GemmArgs g{};
         g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
         g.B = (const float*)h->pcm_cm.p + t_lo * hop; g.ldb = hop; g.strideB = h->n_pad;
@@ -564,15 +574,16 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
     for (int l = 0; l < d.num_blocks; ++l) {
         const BlockWeights& b = W.blocks[l];
         const bool last = l + 1 == d.num_blocks;
-        auto ffn = [&](const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+        // (with_ln = false: u already holds LN(x), written by the fused LayerNorm pair that closed the previous block)
+        auto ffn = [&](bool with_ln, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2) {
-            launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
+            if (with_ln) launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
             gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, FF));
             GemmArgs g = lin(t1, FF, w2, b2, x, D, D, FF, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 0.5f;  // x + 0.5 * ff(x)  (conformer.py:179,182)
             gemm(h, g);
         };
-        ffn(b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
+        ffn(l == 0, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
         launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
         // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
@@ -586,9 +597,15 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
         // conv module (conformer.py:113-127)
         launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
         launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
-        ffn(b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
-        // conformer.py:184; the last block's output also feeds the mask head, as a split operand in u
-        launch_layernorm(x, x, (sp && last) ? u : nullptr, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);
+        ffn(true, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
+        if (!last) {
+            // conformer.py:184 and the next block's feed-forward LayerNorm (conformer.py:139) in one pass over x
+            const BlockWeights& nb_ = W.blocks[l + 1];
+            launch_layernorm2(x, x, b.fin_ln_w, b.fin_ln_b, sp ? nullptr : u, sp ? u : nullptr, nb_.ffi_ln_w, nb_.ffi_ln_b, M, D, st);
+        } else {
+            // conformer.py:184; the last block's output also feeds the mask head, as a split operand in u
+            launch_layernorm(x, x, sp ? u : nullptr, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);
+        }
     }
     // mask head (conformer.py:302-310), transposed so that time is the fastest axis of every mask:
     // masks[(k*F + f)][segment*T + t] = sigmoid(head_w[k*F + f] . x[token] + head_b[k*F + f])
@@ -650,7 +667,8 @@ int css_stage_pit_costs(css_handle_t h, int64_t b_lo, int64_t b_hi) {
     if (h->cfg.stitching_loss < 0 || h->cfg.stitching_loss > 1 || h->cfg.stitching_input < 0 || h->cfg.stitching_input > 1)
         return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     HIPCHK(h, hipSetDevice(h->device));
-    launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->costs.p, h->stream);
+    launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->pit_part.p,
+                     (double*)h->costs.p, h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
@@ -713,8 +731,9 @@ static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int6
     const int64_t TL = h->plan.mix_frames;
     if (f_hi > f_lo) {
         GemmArgs g{};
+        g.split_in = h->split ? 1 : 0;   // Y rows were written as split operands by the stitch stage
         g.A = (const float*)h->Y.p + f_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
-        g.B = h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
+        g.B = h->split ? h->dft_split : h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
         g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
         g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
@@ -853,7 +872,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
-    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, h->stream);
+    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, h->stream);
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
     g.B = cm; g.ldb = hop; g.strideB = n_pad;
@@ -966,9 +985,9 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(host, b->p, (size_t)need, hipMemcpyDeviceToHost));
-    if (which == CSS_BUF_FEATURES && h->split) {
+    if ((which == CSS_BUF_FEATURES || which == CSS_BUF_Y) && h->split) {
         // the device holds the rows as split-f16 GEMM operands (split_f16.hpp); hand out float32 = hi + lo * 2^-11
-        const int64_t rows = dims[0], K = dims[1];
+        const int64_t rows = which == CSS_BUF_Y ? dims[0] * dims[1] : dims[0], K = which == CSS_BUF_Y ? dims[2] : dims[1];
         std::vector<float> row((size_t)K);
         for (int64_t r = 0; r < rows; ++r) {
             float* dst = (float*)host + r * K;

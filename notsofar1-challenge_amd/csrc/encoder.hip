@@ -67,6 +67,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Two LayerNorms back to back on one row held in registers: y = LN(x; w1, b1) -> float32 rows (may alias x), then
+// z = LN(y; w2, b2) -> float32 and / or split-f16 rows.  Block l's closing LayerNorm (conformer.py:184) and block
+// l+1's feed-forward LayerNorm (conformer.py:139) read the same row; the arithmetic is that of the two separate
+// kernels, value for value.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         float* __restrict__ z, float* __restrict__ zs,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         int rows) {
+    constexpr int D = 256 * NV;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+        const float* w = pass ? w2 : w1;
+        const float* b = pass ? b2 : b1;
+        float* yo = pass ? z : y;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 g = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+            const float4 be = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+            v[i] = make_float4(v[i].x * rstd * g.x + be.x, v[i].y * rstd * g.y + be.y, v[i].z * rstd * g.z + be.z,
+                               v[i].w * rstd * g.w + be.w);
+            if (yo) reinterpret_cast<float4*>(yo + (int64_t)row * D)[lane + 64 * i] = v[i];
+            if (pass && zs)
+                split_store4(reinterpret_cast<_Float16*>(zs + (int64_t)row * D), 4 * (lane + 64 * i), v[i].x, v[i].y, v[i].z, v[i].w);
+        }
+    }
+}
+
+void launch_layernorm2(const float* x, float* y, const float* w1, const float* b1, float* z, float* z_split,
+                       const float* w2, const float* b2, int rows, int D, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (D) {
+        case 256: hipLaunchKernelGGL((layernorm2_kernel<1>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
+        case 512: hipLaunchKernelGGL((layernorm2_kernel<2>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
+        case 768: hipLaunchKernelGGL((layernorm2_kernel<3>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
+        case 1024: hipLaunchKernelGGL((layernorm2_kernel<4>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
+        default: break;
+    }
+}
+
 template <int MODE>
 static void launch_ln_mode(const float* x, float* y, float* ys, const float* w, const float* b, const float* pw,
                            int rows, int D, hipStream_t s) {

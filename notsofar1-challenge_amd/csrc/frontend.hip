@@ -16,18 +16,25 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // every later read of the frame buffer is a contiguous run of one channel
 // (conformer_wrapper.py:119 does the same moveaxis on the host).
 // ------------------------------------------------------------------------------------------------
+// split_out: each channel row is written as a split-f16 GEMM operand (split_f16.hpp; n_pad % 32 == 0).  The
+// overlapping frames the analysis GEMM reads (row stride = hop, a multiple of 32) are valid split rows of it.
 __global__ void deinterleave_kernel(const float* __restrict__ pcm, float* __restrict__ out, int64_t n, int C,
-                                    int64_t n_pad, int64_t i_lo, int64_t i_hi) {
+                                    int64_t n_pad, int64_t i_lo, int64_t i_hi, int split_out) {
     const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= i_hi) return;
-    for (int c = 0; c < C; ++c) out[(int64_t)c * n_pad + i] = i < n ? pcm[i * C + c] : 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = i < n ? pcm[i * C + c] : 0.f;
+        if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)c * n_pad + (i & ~(int64_t)31)), (int)(i & 31), v);
+        else out[(int64_t)c * n_pad + i] = v;
+    }
 }
 
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         hipStream_t s) {
+                         int split_out, hipStream_t s) {
     if (i_hi <= i_lo) return;
     const int64_t blocks = (i_hi - i_lo + 255) / 256;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad, i_lo, i_hi);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad, i_lo, i_hi,
+                       split_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -48,6 +48,9 @@ void launch_split_convert(const float* src, int64_t ld_src, float* dst, int64_t 
 // (the same rows as a split-f16 GEMM operand, split_f16.hpp) are each optional.
 void launch_layernorm(const float* x, float* y, float* y_split, const float* w, const float* b, int rows, int D,
                       int relu, hipStream_t s);
+// y = LN(x; w1, b1) (float32, may alias x), then z / z_split = LN(y; w2, b2) (each optional), one pass over the rows
+void launch_layernorm2(const float* x, float* y, const float* w1, const float* b1, float* z, float* z_split,
+                       const float* w2, const float* b2, int rows, int D, hipStream_t s);
 // conv-module front half: u = LN(x); z = (pw[0]*u + pw[1]) * sigmoid(pw[2]*u + pw[3])
 void launch_ln_glu(const float* x, float* z, const float* w, const float* b, const float* pw, int rows, int D,
                    hipStream_t s);
@@ -65,8 +68,9 @@ void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, in
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add
 // ------------------------------------------------------------------------------------------------
 // samples [i_lo, i_hi) of every channel: pcm [n][C] -> pcm_cm [C][n_pad] (zeros past n)
+// (split_out: channel rows as split-f16 GEMM operands, n_pad % 32 == 0)
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         hipStream_t s);
+                         int split_out, hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
 // or split-f16 rows (split_f16.hpp; the padding columns are never written and must be zero)
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
@@ -115,8 +119,11 @@ struct StitchArgs {
     uint8_t* act_b; uint8_t* act_tmp; uint8_t* act_final;  // [S][T_long]
     float activity_th; int dilation; int erosion;
     float* Y; int KIp;         // [S][T_long][KIp]
+    int y_split;               // Y rows as split-f16 GEMM operands (split_f16.hpp) instead of float32
 };
-void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* costs,
+// scratch: pit_cost_scratch_bytes(total boundaries) bytes, indexed by absolute boundary
+size_t pit_cost_scratch_bytes(int64_t n_boundaries);
+void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* scratch, double* costs,
                       hipStream_t s);
 void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s);
 void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms);

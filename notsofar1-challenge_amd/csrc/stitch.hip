@@ -6,7 +6,10 @@
 // (two with the shipped configuration; bit-exact segment indexing st = i * hop, css.py:183,287), so
 // nothing is accumulated with atomics and a frame range can be produced by any rank that holds the
 // segments covering it.
+#include <algorithm>
+
 #include "kernels.hpp"
+#include "split_f16.hpp"
 
 namespace css {
 
@@ -25,17 +28,22 @@ __device__ __forceinline__ double wave_sum_dd(double v) {
 //   input 0: masks   input 1: |separated spectrum|     loss 0: L1   loss 1: squared error
 // ------------------------------------------------------------------------------------------------
 constexpr int SMAX = 4;
+constexpr int PIT_CH = 16;   // frequency chunks per boundary: 39 boundaries alone would occupy 39 of 256 CUs
 
+// One block per (boundary, frequency chunk) -> partial[b][chunk][16]; a second kernel adds the chunks in a fixed
+// order, so the cost is the same bit pattern whatever boundary range or GPU computes it.
 __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, int input, int64_t b_lo,
-                                                       double* __restrict__ costs) {
+                                                       double* __restrict__ partial) {
     __shared__ double red[4][SMAX * SMAX];
     const int64_t b = b_lo + blockIdx.x;
+    const int ch = blockIdx.y;
     const int S = a.S, F = a.F, T = a.T, ov = a.T - a.hop;
+    const int f_lo = (int)((int64_t)F * ch / PIT_CH), f_hi = (int)((int64_t)F * (ch + 1) / PIT_CH);
     double acc[SMAX * SMAX];
 #pragma unroll
     for (int i = 0; i < SMAX * SMAX; ++i) acc[i] = 0.0;
-    for (int idx = threadIdx.x; idx < F * ov; idx += 256) {
-        const int f = idx / ov, t = idx % ov;
+    for (int idx = threadIdx.x; idx < (f_hi - f_lo) * ov; idx += 256) {
+        const int f = f_lo + idx / ov, t = idx % ov;
         float l[SMAX], r[SMAX];
 #pragma unroll
         for (int k = 0; k < SMAX; ++k) {
@@ -66,16 +74,33 @@ __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, i
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < S * S) {
-        const int i = threadIdx.x / S, j = threadIdx.x % S, q = i * SMAX + j;
-        costs[b * S * S + threadIdx.x] = (red[0][q] + red[1][q] + red[2][q] + red[3][q]) / ((double)F * ov);
+    if (threadIdx.x < SMAX * SMAX) {
+        const int q = threadIdx.x;
+        partial[(b * PIT_CH + ch) * (SMAX * SMAX) + q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
     }
 }
 
-void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* costs,
+__global__ __launch_bounds__(64) void pit_cost_final_kernel(const double* __restrict__ partial, int S, int F, int ov,
+                                                            int64_t b_lo, int64_t b_hi, double* __restrict__ costs) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int ss = S * S;
+    if (i >= (b_hi - b_lo) * ss) return;
+    const int64_t b = b_lo + i / ss;
+    const int e = (int)(i % ss), q = (e / S) * SMAX + e % S;
+    double v = 0.0;
+    for (int ch = 0; ch < PIT_CH; ++ch) v += partial[(b * PIT_CH + ch) * (SMAX * SMAX) + q];
+    costs[b * ss + e] = v / ((double)F * ov);
+}
+
+size_t pit_cost_scratch_bytes(int64_t n_boundaries) { return (size_t)std::max<int64_t>(n_boundaries, 1) * PIT_CH * SMAX * SMAX * sizeof(double); }
+
+void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* scratch, double* costs,
                       hipStream_t s) {
     if (b_hi <= b_lo) return;
-    hipLaunchKernelGGL(pit_cost_kernel, dim3((unsigned)(b_hi - b_lo)), dim3(256), 0, s, a, loss, input, b_lo, costs);
+    hipLaunchKernelGGL(pit_cost_kernel, dim3((unsigned)(b_hi - b_lo), PIT_CH), dim3(256), 0, s, a, loss, input, b_lo, scratch);
+    const int64_t n = (b_hi - b_lo) * a.S * a.S;
+    hipLaunchKernelGGL(pit_cost_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, scratch, a.S, a.F, a.T - a.hop, b_lo,
+                       b_hi, costs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,7 +383,11 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
     for (int r = 0; r < OT; ++r) {
         if (t0 + r >= t_hi) break;
         float* out = a.Y + ((int64_t)s * a.T_long + t0 + r) * a.KIp;
-        for (int j = threadIdx.x; j < a.KIp; j += 256) out[j] = j < 2 * a.F ? tile[r * TS + j] : 0.f;  // zero K padding
+        for (int j = threadIdx.x; j < a.KIp; j += 256) {
+            const float v = j < 2 * a.F ? tile[r * TS + j] : 0.f;  // zero K padding
+            if (a.y_split) split_store(reinterpret_cast<_Float16*>(out), j, v);   // operand rows of the synthesis GEMM
+            else out[j] = v;
+        }
     }
 }
 
