@@ -145,6 +145,17 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) == 128 ? 1 : 2) void gemm_spl
     __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM - 2 * TM - NLA, 0); \
     __builtin_amdgcn_sched_barrier(0);   /* the barrier stays behind the last MFMA: the pipe drains while waiting */
 
+    // epilogue operands (column bias, residual) are requested now and used after the K loop (gemm_common.hpp)
+    const int mrow = m0 + wm * (BM / WMV) + 4 * h, ncol = n0 + wn * 32 + c;
+    TilePre pre0, pre1, pre2, pre3;
+    const bool early = !g.bias_along_m;
+    if (early) {
+        if constexpr (0 < TM) tile_prefetch(pre0, mrow, ncol, M, N, g.bias, g.residual, g.ldr);
+        if constexpr (1 < TM) tile_prefetch(pre1, mrow + 32, ncol, M, N, g.bias, g.residual, g.ldr);
+        if constexpr (2 < TM) tile_prefetch(pre2, mrow + 64, ncol, M, N, g.bias, g.residual, g.ldr);
+        if constexpr (3 < TM) tile_prefetch(pre3, mrow + 96, ncol, M, N, g.bias, g.residual, g.ldr);
+    }
+
     CSS_GLOAD(0, 0)
     CSS_WLOAD(0, 0)
     CSS_GLOAD(1, CSS_KOFF(1))
@@ -180,11 +191,11 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) == 128 ? 1 : 2) void gemm_spl
     const int act = g.act, bias_m = g.bias_along_m, so = g.split_out;
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
-    const int mrow = m0 + wm * (BM / WMV) + 4 * h, ncol = n0 + wn * 32 + c;
 #define CSS_E1(t, ...)                                                                                      \
     if constexpr (t < TM) {                                                                                 \
         acc##t += cor##t * SPLIT_LO_INV;                                                                    \
-        emit_tile(acc##t, mrow + 32 * t, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);       \
+        if (early) emit_tile_pre(acc##t, pre##t, mrow + 32 * t, ncol, M, N, C, ldc, act, res != nullptr, alpha, so); \
+        else emit_tile(acc##t, mrow + 32 * t, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);  \
     }
     CSS_I4(CSS_E1, 0)
 #undef CSS_E1
