@@ -287,16 +287,29 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // except T = 32 (NJT - 1) + 1, where tile NJT is computed but never read.  A compile-time constant keeps the
     // whole tile schedule static (a run-time RT0 tripled the code size through duplicated branches).
     constexpr int RT0 = NJT;
-    float4 nxt[8], cur[8];
+    // Operand tiles are consumed in a fixed order -- offset tiles RT0, RT0-1, RT0-2, then key tile jt followed by
+    // offset tile RT0-3-jt while that exists -- and fetched TWO steps ahead into three rotating register buffers
+    // (tb[step % 3]; `step` is a compile-time constant after unrolling, so no copies: the earlier cur = nxt copy made
+    // the wave wait for a tile one step after requesting it, and with one wave per SIMD the L2 latency of every one
+    // of the 2 NJT + 1 tiles was exposed).
+    constexpr int NS = 2 * NJT + 1;
+    auto step_row = [&](int s_) {
+        if (s_ < 3) return pe_row(RT0 - s_);
+        const int u_ = s_ - 3;
+        if (u_ < 2 * (NJT - 2)) return (u_ & 1) ? pe_row(RT0 - 3 - (u_ >> 1)) : k_row(u_ >> 1);
+        return k_row(NJT - 2 + (u_ - 2 * (NJT - 2)));
+    };
+    float4 tb[3][8];
     f32x16 S[NJT];
-#define CSS_ATT_STEP(acc, LOADNEXT)                                         \
-    {                                                                       \
-        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) cur[ch] = nxt[ch]; \
-        LOADNEXT                                                            \
+    int step = 0;
+#define CSS_ATT_STEP(acc)                                                                                  \
+    {                                                                                                      \
+        if (step + 2 < NS) { CSS_ATT_LOAD8(tb[(step + 2) % 3], step_row(min(step + 2, NS - 1))) }          \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the MFMAs (the scheduler sinks it) */ \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;        \
-        CSS_ATT_MFMA32(acc, cur)                                            \
-        __builtin_amdgcn_sched_barrier(0);                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                       \
+        CSS_ATT_MFMA32(acc, tb[step % 3])                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        ++step;                                                                                            \
     }
 #define CSS_ATT_RING_WRITE(acc, rt)                                                          \
     {                                                                                        \
@@ -304,22 +317,20 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
             lds[c * LDR + slot_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];             \
     }
-    CSS_ATT_LOAD8(nxt, pe_row(RT0))
+    CSS_ATT_LOAD8(tb[0], step_row(0))
+    CSS_ATT_LOAD8(tb[1], step_row(1))
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int rt = RT0 - u;
         f32x16 acc;
-        if (u < 2) CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, pe_row(max(rt - 1, 0))))
-        else CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, k_row(0)))
+        CSS_ATT_STEP(acc)
         CSS_ATT_RING_WRITE(acc, rt)
     }
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
         const int rt_new = RT0 - 3 - jt;  // the offset tile key tile jt + 1 adds to the window
-        if (rt_new >= 0) CSS_ATT_STEP(S[jt], CSS_ATT_LOAD8(nxt, pe_row(rt_new)))
-        else if (jt + 1 < NJT) CSS_ATT_STEP(S[jt], CSS_ATT_LOAD8(nxt, k_row(jt + 1)))
-        else CSS_ATT_STEP(S[jt], ;)
+        CSS_ATT_STEP(S[jt])
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -332,8 +343,7 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         }
         if (rt_new >= 0) {
             f32x16 acc;
-            if (jt + 1 < NJT) CSS_ATT_STEP(acc, CSS_ATT_LOAD8(nxt, k_row(jt + 1)))
-            else CSS_ATT_STEP(acc, ;)
+            CSS_ATT_STEP(acc)
             CSS_ATT_RING_WRITE(acc, rt_new)  // overwrites tile RT0 - jt, which key tile jt was the last to read
         }
     }
@@ -355,25 +365,25 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // ---- O^T[d][i] = sum_j v[j][d] * P[i][j]; the MFMA k index of half h at step (jt, r) is the key
     //      row this lane's S[jt][r] belongs to, so P feeds the B operand straight from registers.
     constexpr int OLD = 65;
-    float vn[16], vc[16];
-#define CSS_ATT_LOADV(dst, dt, jt)                                                            \
+    // V groups (dt, jt) are consumed in order g = dt * NJT + jt and fetched two groups ahead (vb3[g % 3])
+    float vb3[3][16];
+#define CSS_ATT_LOADV(dst, g_)                                                                \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
-        const int j = min((jt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, T - 1);                 \
-        dst[r] = vb[(int64_t)j * ld + (dt) * 32 + c];                                         \
+        const int j = min(((g_) % NJT) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, T - 1);         \
+        dst[r] = vb[(int64_t)j * ld + ((g_) / NJT) * 32 + c];                                 \
     }
-    CSS_ATT_LOADV(vn, 0, 0)
+    CSS_ATT_LOADV(vb3[0], 0)
+    CSS_ATT_LOADV(vb3[1], 1)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         f32x16 o = {0};
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) vc[r] = vn[r];
-            if (jt + 1 < NJT) { CSS_ATT_LOADV(vn, dt, jt + 1) }
-            else if (dt == 0) { CSS_ATT_LOADV(vn, 1, 0) }
+            const int g = dt * NJT + jt;
+            if (g + 2 < 2 * NJT) { CSS_ATT_LOADV(vb3[(g + 2) % 3], g + 2) }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], S[jt][r], o, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vb3[g % 3][r], S[jt][r], o, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
