@@ -583,7 +583,8 @@ struct MaskIo {
 
 // The mask estimator over `nb` segments starting at `s0` on one lane (stream + activation set), phases [ph_lo, ph_hi):
 // phase -1 = features + embed, phase l = Conformer block l, phase num_blocks = mask head.
-static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int lane, int ph_lo, int ph_hi) {
+static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int lane, int ph_lo, int ph_hi,
+                        bool concurrent = false) {
     const CssModelDesc& d = h->d;
     const int T = io.T, D = d.attention_dim, FF = d.linear_units, F = d.num_bins;
     const int M = nb * T;
@@ -599,7 +600,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     auto lin = [&](const float* A, int64_t lda, const float* Wt, const float* bias, float* C, int64_t ldc, int n, int k,
                    int act, int split_out) {
         GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
-        g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp;
+        g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
         return g;
     };
     if (ph_lo < 0) {
@@ -674,7 +675,7 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
     for (int ph = -1; ph <= L; ++ph)
         for (int l = 0; l < nl; ++l) {
             const int lo = l * per, n = std::min(per, nb - lo);
-            if (n > 0 && (rc = masknet_lane(h, io, s0 + lo, n, l, ph, ph + 1)) != CSS_OK) return rc;
+            if (n > 0 && (rc = masknet_lane(h, io, s0 + lo, n, l, ph, ph + 1, true)) != CSS_OK) return rc;
         }
     for (int l = 1; l < nl; ++l) {
         HIPCHK(h, hipEventRecord(h->ev_join[l], h->lane_stream[l]));

@@ -253,7 +253,7 @@ void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s) {
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WD_WAVES"); return e ? std::atoi(e) : 0; }();
     if (forced == 4) {
         hipLaunchKernelGGL((gemm_split_wd_kernel<128, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g, tiles_m, tiles_n);
-    } else if (forced == 64) {
+    } else if (forced == 64 || (!forced && g.concurrent)) {
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
     } else {

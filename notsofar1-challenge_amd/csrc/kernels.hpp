@@ -32,6 +32,9 @@ struct GemmArgs {
     // b_tiled (with split_in): B is a weight matrix in the tile-major split layout of gemm_split_wd.hip
     // (launch_split_convert_tiled); batch must be 1 and N % 32 == 0.
     int b_tiled;
+    // hint: other kernels run beside this launch (two-lane mask estimator): prefer 4-wave 64-row tiles, two of which
+    // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
+    int concurrent;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
