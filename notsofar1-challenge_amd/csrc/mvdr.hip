@@ -27,16 +27,35 @@ __device__ __forceinline__ int valid_frames(int64_t stft_frames, int64_t seg, in
 //   w_k[f,t] = mask_k[f,t] if it is the maximum over the S speaker masks and the summed noise mask,
 //              else 1e-10                                            (mvdr_util.py:50-55)
 //   Phi_k[f] = sum_t w_k[f,t] x[f,t] x[f,t]^H  (+ 1e-15 I)            (mvdr_util.py:61-65)
-// Block = (bin f, segment); wave k accumulates mask k: lanes run over time (contiguous reads of the
-// seven Re/Im plane rows), 49 float64 accumulators per lane, wavefront-shuffle reduction.
+// A group of 16 lanes owns one (bin f, mask k) of a segment: its lanes stride over time (64-byte contiguous reads
+// of the seven Re/Im plane rows), 49 float64 accumulators per lane, and the 16 partial sums are combined with four
+// DPP steps (quad swaps, then the 8- and 16-lane mirrors) -- no LDS, no wave-wide butterfly: the 49 x 6
+// ds_bpermute reductions of the earlier one-wave-per-mask version left its waves parked 65 % of the time (303 us for
+// 40 segments).  Block = 4 bins x 4 masks.
 // ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+// sum over the 16 lanes of a DPP row; every lane ends up with the total
+__device__ __forceinline__ double row16_sum(double v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
+    v = dpp_add<0x140>(v);   // row_mirror:      lane i <-> 15 - i
+    return v;
+}
+
 __global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
-    const int f = blockIdx.x, segl = blockIdx.y;
+    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int f = blockIdx.x * 4 + (grp >> 2), k = grp & 3, segl = blockIdx.y;
     const int64_t seg = a.seg_lo + segl;
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nm = a.S + 1;
-    if (k >= nm) return;
     const int F = a.F, T = a.T;
+    if (k >= nm || f >= F) return;   // whole 16-lane rows leave together
     const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
     const int64_t st = seg * (int64_t)a.hop;
     double acc[NPACK];
@@ -45,7 +64,7 @@ __global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
     const float* mrow = a.masks + (int64_t)f * a.mask_ld + seg * (int64_t)T;
     const int64_t mstride = (int64_t)F * a.mask_ld;
     const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
-    for (int t = lane; t < tv; t += 64) {
+    for (int t = l16; t < tv; t += 16) {
         // masks of this TF point: S speakers, then the noise mask (sum over noise outputs; one here)
         float mk = 0.f, mx = -INFINITY;
         for (int j = 0; j < nm; ++j) {
@@ -77,14 +96,14 @@ __global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
     double* out = a.scm + ((seg * nm + k) * (int64_t)F + f) * NPACK;
 #pragma unroll
     for (int i = 0; i < NPACK; ++i) {
-        double v = wave_sum_d(acc[i]);
+        double v = row16_sum(acc[i]);
         if (i < NC) v += 1e-15;  // Ri += 1e-15 * I   (mvdr_util.py:63-65)
-        if (lane == 0) out[i] = v;
+        if (l16 == (i & 15)) out[i] = v;   // the 49 results leave through all 16 lanes
     }
 }
 
 void launch_scm(const MvdrArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(scm_kernel, dim3(a.F, a.nseg), dim3(64 * (a.S + 1)), 0, s, a);
+    hipLaunchKernelGGL(scm_kernel, dim3((a.F + 3) / 4, a.nseg), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
