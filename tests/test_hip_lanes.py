@@ -1,0 +1,69 @@
+"""The mask estimator's schedule must not change a bit of the result: one, two or three lanes (kernel chains on
+separate streams), any batch size, odd splits.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _separator(mc_state, lanes, max_batch):
+    old = os.environ.get("CSS_MASKNET_LANES")
+    os.environ["CSS_MASKNET_LANES"] = str(lanes)      # read at css_create
+    try:
+        return pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=max_batch)
+    finally:
+        if old is None:
+            del os.environ["CSS_MASKNET_LANES"]
+        else:
+            os.environ["CSS_MASKNET_LANES"] = old
+
+
+@pytest.mark.parametrize("seconds", [15.0, 21.2])     # 9 and 13 segments (plus a ragged last one)
+def test_lanes_and_batching_are_bit_invariant(mc_state, mix60, seconds):
+    if pkg("_lib").load().css_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    CSS, L = pkg("css"), pkg("_lib")
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    mix = np.ascontiguousarray(mix60[0, :int(seconds * 16000)])
+    ref = None
+    for lanes, mb in [(1, 64), (2, 64), (3, 64), (2, 6), (2, 7), (4, 5), (2, 12)]:
+        sep = _separator(mc_state, lanes, mb)
+        try:
+            h = sep.handle
+            wav = h.run(mix, run_cfg)
+            masks = h.read(L.BUF_MASKS)
+            perms = h.read(L.BUF_PERMS)
+            nseg = h.get_plan().num_segments
+        finally:
+            sep.close()
+        assert np.isfinite(wav).all()
+        if ref is None:
+            ref = (wav, masks, perms, nseg)
+            assert nseg >= 9
+        else:
+            assert nseg == ref[3]
+            assert np.array_equal(masks, ref[1]), (lanes, mb)
+            assert np.array_equal(perms, ref[2]), (lanes, mb)
+            assert np.array_equal(wav, ref[0]), (lanes, mb)
+
+
+def test_lanes_in_exact_mode(mc_state, mix60):
+    """Same invariance with the exact float32 Linear layers."""
+    CSS, L = pkg("css"), pkg("_lib")
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    mix = np.ascontiguousarray(mix60[0, :int(15.0 * 16000)])
+    out = []
+    for lanes in (1, 2):
+        sep = _separator(mc_state, lanes, 64)
+        try:
+            sep.handle.set_linear_mode("exact_f32")
+            out.append(sep.handle.run(mix, run_cfg))
+        finally:
+            sep.close()
+    assert np.array_equal(out[0], out[1])
