@@ -220,6 +220,15 @@ def main():
         host_ms = 1e3 * (time.perf_counter() - t0) / 5
         result["host_buffers"] = {"ms_per_step": round(host_ms, 3), "value": round(total_seconds / (host_ms * 1e-3), 2),
                                   "note": "css_run from/to pageable host memory (PCIe-inclusive)"}
+        # ... and between the wav edges (css_run_pcm16: int16 planes up, peak-normalised PCM16 down, converted on the GPU)
+        planes = [np.ascontiguousarray(np.clip(np.rint(mix[0, :, c] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)) for c in range(7)]
+        h.run_pcm16(planes, run_cfg)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            h.run_pcm16(planes, run_cfg)
+        p16_ms = 1e3 * (time.perf_counter() - t0) / 5
+        result["pcm16_edges"] = {"ms_per_step": round(p16_ms, 3), "value": round(total_seconds / (p16_ms * 1e-3), 2),
+                                 "note": "css_run_pcm16: 7 int16 planes from host memory -> 3 PCM16 streams in host memory"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, total_seconds),
                                                   {"activity_th": 0.3})

@@ -175,6 +175,14 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
 /* Same with input and output resident in HBM (pcm_dev [n_samples][n_ch], wav_dev [S][n_out]). */
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                    float* wav_dev, int64_t wav_capacity_per_stream);
+/* The same path between the two wav edges: n_ch mono PCM16 planes in host memory -- what
+ * css/helpers.py:40 load_audio reads from a session's wav files, scaled by 2^-15 on the device as libsndfile scales
+ * them -- to the S separated streams as the PCM16 samples utils/audio_utils.py:37 write_wav would put into
+ * sep_stream{i}.wav: peak normalisation x * 0.99 / (max|x| + 1e-7) in float32, then lrint(x * 32767), both on the
+ * device.  Half the PCIe bytes of css_run and no host pass over the samples.  peaks_host: NULL or S floats, max|x|
+ * of each stream before normalisation. */
+int css_run_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                  int16_t* wav_pcm16_host, int64_t wav_capacity_per_stream, float* peaks_host);
 int css_get_timings(css_handle_t h, CssTimings* out);
 /* enable != 0: bracket every MFMA GEMM launch of the mask estimator with HIP events on the handle's
  * stream, so that CssTimings.gemm_ms / gemm_launches report the live average launch duration. */

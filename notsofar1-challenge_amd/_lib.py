@@ -78,6 +78,7 @@ SIGNATURES = {
     "css_pit_scan": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
+    "css_run_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
     "css_get_timings": (C.c_int, [_P, C.POINTER(CssTimings)]),
     "css_set_profile": (C.c_int, [_P, C.c_int]),
     "css_set_linear_mode": (C.c_int, [_P, C.c_int]),
@@ -247,6 +248,23 @@ class Handle:
     def run_device(self, pcm_ptr: int, n: int, c: int, cfg: RunCfg, wav_ptr: int, cap: int):
         check(self.h, self.lib.css_run_device(self.h, C.c_void_p(pcm_ptr), n, c, C.byref(cfg.c),
                                               C.c_void_p(wav_ptr), cap))
+
+    def run_pcm16(self, planes, cfg: RunCfg):
+        """planes: sequence of C mono int16 arrays of equal length (the session's wav payloads).
+        -> (int16 [S, n_out] peak-normalised PCM16 samples of the separated streams, float32 [S] peaks)."""
+        planes = [np.ascontiguousarray(p, dtype=np.int16) for p in planes]
+        n = planes[0].shape[0]
+        if any(p.ndim != 1 or p.shape[0] != n for p in planes):
+            raise ValueError("all channel planes must be one-dimensional and of equal length")
+        c = len(planes)
+        pl = plan(self.desc, cfg, n)
+        S = int(self.desc.num_spks)
+        out = np.empty((S, pl.n_out), dtype=np.int16)
+        peaks = np.empty((S,), dtype=np.float32)
+        ptrs = (C.c_void_p * c)(*[p.ctypes.data for p in planes])
+        check(self.h, self.lib.css_run_pcm16(self.h, ptrs, n, c, C.byref(cfg.c), out.ctypes.data_as(C.c_void_p), pl.n_out,
+                                             peaks.ctypes.data_as(C.c_void_p)))
+        return out, peaks
 
     def timings(self) -> dict:
         t = CssTimings()

@@ -67,7 +67,7 @@ struct css_ctx {
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host;
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
-        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part;
+        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
     // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two chains drift out of
@@ -431,7 +431,8 @@ int css_destroy(css_handle_t h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
-                      &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part};
+                      &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
+                      &h->in16, &h->pcm_f, &h->enc};
     for (int l = 1; l < css_ctx::MAX_LANES; ++l) {
         for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lctx[l]})
             if (b->p) hipFree(b->p);
@@ -829,10 +830,12 @@ int css_sync(css_handle_t h) {
     return CSS_OK;
 }
 
+// wav16 != nullptr: instead of the float32 waveforms, the peak-normalised PCM16 encoding goes to the host (and the
+// peaks, if asked for)
 static int run_impl(css_handle_t h, const float* pcm, int64_t n, int32_t n_ch, const CssRunCfg* cfg, float* wav,
-                    int64_t cap, int device_io) {
+                    int64_t cap, int device_io, int16_t* wav16 = nullptr, float* peaks = nullptr) {
     int rc;
-    if (!h || !wav) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (!h || (!wav && !wav16)) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if ((rc = css_begin(h, pcm, n, n_ch, cfg, device_io)) != CSS_OK) return rc;
     if (cap < h->plan.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(h->plan.n_out) + " samples per stream");
     const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
@@ -844,9 +847,21 @@ static int run_impl(css_handle_t h, const float* pcm, int64_t n, int32_t n_ch, c
     if ((rc = css_stage_stitch(h, 0, TL)) != CSS_OK) return rc;
     if ((rc = css_stage_istft(h, 0, TL)) != CSS_OK) return rc;
     const int S = h->d.num_spks;
-    HIPCHK(h, hipMemcpy2DAsync(wav, (size_t)cap * sizeof(float), h->wav.p, (size_t)h->plan.n_out * sizeof(float),
-                               (size_t)h->plan.n_out * sizeof(float), S,
-                               device_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if (wav16) {
+        const int64_t n_out = h->plan.n_out;
+        const size_t need16 = (size_t)S * n_out * sizeof(int16_t) + 64;
+        if ((rc = ensure(h, h->enc, need16)) != CSS_OK) return rc;
+        unsigned int* pk = (unsigned int*)h->enc.p;
+        int16_t* o16 = (int16_t*)((char*)h->enc.p + 64);
+        launch_encode_pcm16((const float*)h->wav.p, S, n_out, pk, o16, n_out, h->stream);
+        HIPCHK(h, hipMemcpy2DAsync(wav16, (size_t)cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
+                                   (size_t)n_out * sizeof(int16_t), S, hipMemcpyDeviceToHost, h->stream));
+        if (peaks) HIPCHK(h, hipMemcpyAsync(peaks, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpy2DAsync(wav, (size_t)cap * sizeof(float), h->wav.p, (size_t)h->plan.n_out * sizeof(float),
+                                   (size_t)h->plan.n_out * sizeof(float), S,
+                                   device_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    }
     hipEventRecord(h->ev[7], h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
@@ -873,6 +888,29 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                    float* wav_dev, int64_t cap) {
     return run_impl(h, pcm_dev, n_samples, n_ch, cfg, wav_dev, cap, 1);
+}
+
+int css_run_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                  int16_t* wav_pcm16_host, int64_t cap, float* peaks_host) {
+    if (!h || !planes_host || !wav_pcm16_host || n_samples < 1 || n_ch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t plane_b = (size_t)n_samples * sizeof(int16_t);
+    if ((rc = ensure(h, h->in16, plane_b * n_ch)) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->pcm_f, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
+    hipEventRecord(h->ev[8], h->stream);
+    for (int c = 0; c < n_ch; ++c) {
+        if (!planes_host[c]) return fail(h, CSS_ERR_INVALID_ARG, "null channel plane");
+        HIPCHK(h, hipMemcpyAsync((char*)h->in16.p + plane_b * c, planes_host[c], plane_b, hipMemcpyHostToDevice, h->stream));
+    }
+    launch_pcm16_to_float((const int16_t*)h->in16.p, (float*)h->pcm_f.p, n_samples, n_ch, h->stream);
+    rc = run_impl(h, (const float*)h->pcm_f.p, n_samples, n_ch, cfg, nullptr, cap, 1, wav_pcm16_host, peaks_host);
+    if (rc == CSS_OK) {   // the upload of the planes counts as upload time
+        float v = 0.f;
+        hipEventElapsedTime(&v, h->ev[8], h->ev[0]);
+        h->tim.upload += v; h->tim.total += v;
+    }
+    return rc;
 }
 
 int css_set_linear_mode(css_handle_t h, int mode) {

@@ -38,6 +38,55 @@ void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two wav edges of the path on the device.
+//   in : C mono PCM16 planes (the 7 files of a session, css/helpers.py:40 load_audio; libsndfile scales int16 by
+//        2^-15) -> sample-major float32 [n][C]
+//   out: peak normalisation x * 0.99 / (max|x| + 1e-7) in float32 (utils/audio_utils.py:44-45), then libsndfile's
+//        float -> PCM16 conversion lrint(x * 32767): the same operations, value for value, as wavio.write_wav.
+// ------------------------------------------------------------------------------------------------
+__global__ void pcm16_to_float_kernel(const int16_t* __restrict__ planes, float* __restrict__ pcm, int64_t n, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < C; ++c) pcm[i * C + c] = (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f);
+}
+
+void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes, pcm, n, C);
+}
+
+// peak[s] = max |wav[s][:]| (as float bits: non-negative floats order like unsigned integers; peak zeroed by the caller)
+__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ wav, int64_t n, unsigned int* __restrict__ peak) {
+    const int s = blockIdx.y;
+    const float* w = wav + (int64_t)s * n;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak + s, __float_as_uint(m));
+}
+
+__global__ void encode_pcm16_kernel(const float* __restrict__ wav, int64_t n, const unsigned int* __restrict__ peak,
+                                    int16_t* __restrict__ out, int64_t out_ld) {
+    const int s = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float den = __fadd_rn(__uint_as_float(peak[s]), 1e-7f);
+    const float y = __fdiv_rn(__fmul_rn(wav[(int64_t)s * n + i], 0.99f), den);
+    double v = rint((double)y * 32767.0);
+    v = fmin(fmax(v, -32768.0), 32767.0);
+    out[(int64_t)s * out_ld + i] = (int16_t)v;
+}
+
+void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
+                         hipStream_t s) {
+    if (n <= 0) return;
+    hipMemsetAsync(peak_bits, 0, (size_t)S * sizeof(unsigned int), s);
+    hipLaunchKernelGGL(peak_kernel, dim3(256, S), dim3(256), 0, s, wav, n, peak_bits);
+    hipLaunchKernelGGL(encode_pcm16_kernel, dim3((unsigned)((n + 255) / 256), S), dim3(256), 0, s, wav, n, peak_bits, out, out_ld);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Network input features of one segment (feature.py:478-508 compute_spectra, 198-249 IPDFeature,
 // then the global affine of conformer.py:298-299), written straight into the row-major
 // [token][K_pad] operand of the embed GEMM.

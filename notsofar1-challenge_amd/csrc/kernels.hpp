@@ -74,6 +74,11 @@ void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, in
 // (split_out: channel rows as split-f16 GEMM operands, n_pad % 32 == 0)
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
                          int split_out, hipStream_t s);
+// wav edges on the device: C mono PCM16 planes [C][n] -> sample-major float32 [n][C]; and peak-normalised PCM16
+// encoding of the S output streams (peak_bits: S words of scratch, holds max|x| as float bits afterwards)
+void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s);
+void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
+                         hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
 // or split-f16 rows (split_f16.hpp; the padding columns are never written and must be zero)
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,

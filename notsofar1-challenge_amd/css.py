@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _lib
 from .separator import HipSeparator, load_css_model
-from .wavio import load_audio, write_wav
+from .wavio import NUM_MICS_MC, load_audio, read_wav_pcm16, write_pcm16_samples, write_wav
 
 _LOG = logging.getLogger('css')
 
@@ -183,6 +183,32 @@ def css_inference(out_dir: str, models_dir: str, session, cfg: CssCfg, fetch_fro
     separator, _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if session.is_mc else cfg.checkpoint_sc))
     device = f"cuda:{cfg.device_id}"
     separator.eval()
+
+    # Device-side wav edges: when every input file is mono 16-bit PCM -- the NOTSOFAR recordings
+    # are -- the raw int16 samples go to the GPU (half the bytes of float32), are scaled there, and the separated
+    # streams come back already peak-normalised and PCM16-encoded exactly as write_wav encodes them.
+    raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
+    if raw and all(r is not None for r in raw) and len({r[0].shape[0] for r in raw}) == 1 and len({r[1] for r in raw}) == 1:
+        if session.is_mc:
+            assert len(raw) == NUM_MICS_MC, f'expecting {NUM_MICS_MC} microphones'
+        else:
+            assert len(raw) == 1
+        sr = raw[0][1]
+        separator.to(device)
+        desc = separator.desc
+        run_cfg = make_run_cfg(cfg, sr, len(raw), desc.frame_len, desc.frame_hop)
+        pcm16, _ = separator.handle.run_pcm16([r[0] for r in raw], run_cfg)
+        separator.close()
+        write_wav(css_out_dir / 'input_mixture.wav', samps=raw[0][0].astype(np.float32) / np.float32(32768.0), sr=sr)
+        sep_wav_file_names = []
+        for i in range(pcm16.shape[0]):
+            filename = css_out_dir / f"sep_stream{i}.wav"
+            _LOG.info(f"CSS: saving separated wav to {filename}")
+            write_pcm16_samples(filename, pcm16[i], sr)
+            sep_wav_file_names.append(str(filename))
+        session_css['sep_wav_file_names'] = sep_wav_file_names
+        return session_css
+
     mixwav, sr = load_audio(session.wav_file_names, is_mc=session.is_mc)
 
     if cfg.slice_audio_for_debug:

@@ -63,6 +63,40 @@ def read_wav(path) -> Tuple[np.ndarray, int]:
     return x, int(rate)
 
 
+def read_wav_pcm16(path):
+    """-> (int16 samples [n], sample_rate) if `path` is a mono 16-bit PCM wav, else None (the device-side wav edge
+    of css_inference takes the raw samples; anything else goes through read_wav)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", data[pos + 8:pos + 24])
+        elif cid == b"data":
+            payload = data[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None or fmt[0] != 1 or fmt[1] != 1 or fmt[5] != 16:
+        return None
+    return np.frombuffer(payload, dtype="<i2"), int(fmt[2])
+
+
+def write_pcm16_samples(path, pcm: np.ndarray, sr: int) -> None:
+    """Writes already encoded int16 samples as a mono 16-bit PCM wav."""
+    pcm = np.ascontiguousarray(pcm, dtype="<i2")
+    assert pcm.ndim == 1
+    dir_name = os.path.dirname(str(path))
+    if dir_name:
+        os.makedirs(dir_name, exist_ok=True)
+    payload = pcm.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + \
+        struct.pack("<IHHIIHH", 16, 1, 1, int(sr), int(sr) * 2, 2, 16) + b"data" + struct.pack("<I", len(payload))
+    with open(path, "wb") as f:
+        f.write(hdr + payload)
+
+
 def write_pcm16(path, samps: np.ndarray, sr: int) -> None:
     samps = np.asarray(samps)
     assert samps.ndim == 1

@@ -104,3 +104,40 @@ def test_session_loop_shards_by_session(tmp_path, tiny_models):
             assert len(row.sep_wav_file_names) == 3 and all(os.path.exists(f) for f in row.sep_wav_file_names)
             y, sr = wavio.read_wav(row.sep_wav_file_names[0])
             assert sr == 16000 and np.isfinite(y).all() and abs(np.abs(y).max() - 0.99) < 1e-3
+
+
+def test_pcm16_wav_edges_on_device_are_bit_exact(tmp_path, tiny_models):
+    """css_run_pcm16: int16 planes in, peak-normalised PCM16 out, both conversions on the device,
+    must give exactly the samples the host path (load_audio -> css_run -> write_wav) puts into the files."""
+    css, wavio, sep_mod = pkg("css"), pkg("wavio"), pkg("separator")
+    _, models = tiny_models
+    mix = (pkg("synth").synth_meeting(7.3, 7, seed=5) * 0.07).astype(np.float32)
+    sess = _write_session(tmp_path, wavio, mix, "MTG_2", True)
+    raw = [wavio.read_wav_pcm16(p) for p in sess["wav_file_names"]]
+    assert all(r is not None and r[1] == 16000 for r in raw)
+    mixq, _ = wavio.load_audio(sess["wav_file_names"], is_mc=True)
+    assert np.array_equal(mixq[0, :, 3], raw[3][0].astype(np.float32) / np.float32(32768.0))
+    st, desc = models["mc"]
+    sep = sep_mod.HipSeparator(st, None, device=0)
+    try:
+        cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
+        run_cfg = css.make_run_cfg(cfg, 16000, 7)
+        h = sep.handle
+        pcm16, peaks = h.run_pcm16([r[0] for r in raw], run_cfg)
+        wav = h.run(mixq[0], run_cfg)
+        assert pcm16.dtype == np.int16 and pcm16.shape == wav.shape
+        for i in range(3):
+            assert peaks[i] == np.max(np.abs(wav[i]))
+            y = wav[i] * 0.99 / (np.max(np.abs(wav[i])) + 1e-7)                     # utils/audio_utils.py:44-45
+            assert y.dtype == np.float32
+            expect = np.clip(np.rint(y.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+            assert np.array_equal(pcm16[i], expect)
+            assert np.abs(pcm16[i]).max() == 32439                                   # rint(0.99 * 32767)
+        with pytest.raises(ValueError):
+            h.run_pcm16([raw[0][0], raw[1][0][:-1]], run_cfg)
+    finally:
+        sep.close()
+    # written and read back through the wav codec
+    wavio.write_pcm16_samples(tmp_path / "s.wav", pcm16[0], 16000)
+    back = wavio.read_wav_pcm16(tmp_path / "s.wav")
+    assert back[1] == 16000 and np.array_equal(back[0], pcm16[0])
