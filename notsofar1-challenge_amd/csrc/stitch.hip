@@ -253,13 +253,16 @@ __device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Cont
 //   activity[s][t]   = mean_f mask_st[s][f][t];   act_b = activity >= th
 // The float32 operation order of the reference (multiply, add in ascending segment order, divide) is
 // reproduced with explicit round-to-nearest intrinsics so no FMA contraction changes a bit.
-// Block = 64 frames x 4 frequency groups; lanes run over time (contiguous mask reads).
+// Block = 16 frames x 16 frequency groups (a 60 s meeting is only 3749 frames: 64-frame blocks gave 177 blocks for
+// 256 CUs); lanes run over time (contiguous mask reads); the frequency mean is accumulated in float64 and the 16
+// partial sums are added in a fixed order.
 // ------------------------------------------------------------------------------------------------
+constexpr int OM_T = 16, OM_FG = 16;
 __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_lo, int64_t t_hi) {
-    __shared__ double red[4][64];
+    __shared__ double red[OM_FG][OM_T];
     const int s = blockIdx.y;
-    const int lane = threadIdx.x & 63, fg = threadIdx.x >> 6;
-    const int64_t t = t_lo + (int64_t)blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & (OM_T - 1), fg = threadIdx.x / OM_T;
+    const int64_t t = t_lo + (int64_t)blockIdx.x * OM_T + lane;
     const bool active = t < t_hi;
     Contrib c[MAXC];
     int n = 0;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
     double sum = 0.0;
     if (active && n > 0) {
         float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
-        for (int f = fg; f < a.F; f += 4) {
+        for (int f = fg; f < a.F; f += OM_FG) {
             float v = __fmul_rn(c[0].w, mp[0][(int64_t)f * a.mask_ld]);
 #pragma unroll
             for (int i = 1; i < MAXC; ++i)
@@ -290,7 +293,10 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
     red[fg][lane] = sum;
     __syncthreads();
     if (fg == 0 && active) {
-        const float act = (float)((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (double)a.F);
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < OM_FG; ++g) tot += red[g][lane];
+        const float act = (float)(tot / (double)a.F);
         a.activity[(int64_t)s * a.T_long + t] = act;
         a.act_b[(int64_t)s * a.T_long + t] = act >= a.activity_th ? 1 : 0;
     }
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
 
 void launch_ola_masks(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
     if (t_hi <= t_lo) return;
-    hipLaunchKernelGGL(ola_masks_kernel, dim3((unsigned)((t_hi - t_lo + 63) / 64), a.S), dim3(256), 0, s, a, t_lo, t_hi);
+    hipLaunchKernelGGL(ola_masks_kernel, dim3((unsigned)((t_hi - t_lo + OM_T - 1) / OM_T), a.S), dim3(OM_T * OM_FG), 0, s, a, t_lo, t_hi);
 }
 
 // ------------------------------------------------------------------------------------------------
