@@ -614,16 +614,17 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     for (int l = std::max(ph_lo, 0); l < std::min(ph_hi, d.num_blocks); ++l) {
         const BlockWeights& b = W.blocks[l];
         const bool last = l + 1 == d.num_blocks;
-        // (with_ln = false: u already holds LN(x), written by the fused LayerNorm pair that closed the previous block)
-        auto ffn = [&](bool with_ln, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                       const float* b2) {
-            if (with_ln) launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
+        // x = xin + 0.5 * ff(xin)  (conformer.py:179,182).  with_ln = false: u already holds LN(xin), written by the fused
+        // LayerNorm pair that closed the previous block.
+        auto ffn = [&](bool with_ln, const float* xin, const float* lnw, const float* lnb, const float* w1, const float* b1,
+                       const float* w2, const float* b2) {
+            if (with_ln) launch_layernorm(xin, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
             gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, FF), st);
             GemmArgs g = lin(t1, FF, w2, b2, x, D, D, FF, ACT_NONE, 0);
-            g.residual = x; g.ldr = D; g.alpha = 0.5f;  // x + 0.5 * ff(x)  (conformer.py:179,182)
+            g.residual = xin; g.ldr = D; g.alpha = 0.5f;
             gemm(h, g, st);
         };
-        ffn(l == 0, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
+        ffn(l == 0, x, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
         launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
         // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
@@ -634,10 +635,17 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
             g.residual = x; g.ldr = D; g.alpha = 1.f;
             gemm(h, g, st);
         }
-        // conv module (conformer.py:113-127)
-        launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
-        launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
-        ffn(true, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
+        // conv module (conformer.py:113-127): one kernel, x -> cb (the attention context buffer is free again; the
+        // kernel must not write where neighbouring blocks still read), and the second feed-forward takes cb as its
+        // input and residual and writes x.  Uncovered (D, taps): LayerNorm+GLU -> u, depthwise conv in place.
+        const float* xc = cb;
+        if (!launch_conv_module(x, cb, b.conv_ln_w, b.conv_ln_b, b.pw, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, nb, T, D,
+                                d.kernel_size, st)) {
+            launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
+            launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
+            xc = x;
+        }
+        ffn(true, xc, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
         if (!last) {
             // conformer.py:184 and the next block's feed-forward LayerNorm (conformer.py:139) in one pass over x
             const BlockWeights& nb_ = W.blocks[l + 1];

@@ -61,6 +61,11 @@ void launch_ln_glu(const float* x, float* z, const float* w, const float* b, con
 // ReLU, scalar pointwise conv, residual:  h += pw[4] * relu((conv(z) + dw_b) * alpha + beta) + pw[5]
 void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
                    const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s);
+// the whole conv module in one kernel: x_out = x_in + conv_module(x_in); x_out must not alias x_in.  Returns false when
+// (D, taps) is not covered and nothing was launched (use launch_ln_glu + launch_dwconv).
+bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, const float* ln_b, const float* pw,
+                        const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta, int nseg, int T,
+                        int D, int taps, hipStream_t s);
 // relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows).
 // qk_split: the q and k columns of qkv and the rows of pe_k are split-f16 (scores on the f16 matrix cores with
 // float32-grade accuracy); v is float32 either way.
