@@ -5,10 +5,22 @@
 
 namespace css {
 
+// sum over the 64 lanes (every lane gets the total): DPP inside the rows of 16, row totals through scalar registers
+// (no ds_bpermute round trips; see wave_sum in encoder.hip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_addf_(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = dpp_addf_<0xB1>(v);
+    v = dpp_addf_<0x4E>(v);
+    v = dpp_addf_<0x141>(v);
+    v = dpp_addf_<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ------------------------------------------------------------------------------------------------
