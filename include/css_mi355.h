@@ -238,6 +238,11 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
 /* separate (conformer_wrapper.py:79): X planes [C][2F][B*T] holding B independent segments of T frames
  * back to back along time -> masks [(S+1)F][B*T] (row k*F + f, column b*T + t). */
 int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks);
+/* ConformerCssWrapper.forward (conformer_wrapper.py:58-77: stft -> separate) for a batch of equally long clips, fused
+ * on the device -- the validation forward of the reference's training loop (train.py:529 eval_model).
+ * pcm_host [batch][n_samples][n_ch] -> masks_host [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1
+ * (2 <= T' <= 256), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
+int css_forward_host(css_handle_t h, const float* pcm_host, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks_host);
 /* istft: Y [B][2F][T] planes (Re rows then Im rows, time fastest) -> wav [B][(T-1)*hop + frame_len]. */
 int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav);
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "css_sync": (C.c_int, [_P]),
     "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "css_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     "css_buffer_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "css_read_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -351,6 +352,15 @@ class Handle:
         assert c == self.desc.num_mics and f2 == 2 * self.desc.num_bins and tt % batch == 0
         out = np.empty(((self.desc.num_spks + self.desc.num_nois) * self.desc.num_bins, tt), dtype=np.float32)
         check(self.h, self.lib.css_separate_host(self.h, _np_ptr(planes), batch, tt // batch, _np_ptr(out)))
+        return out
+
+    def forward_host(self, pcm: np.ndarray) -> np.ndarray:
+        """pcm [B, n, C] (equally long clips) -> masks [(S+1)F, B*T'], clip b in columns [b T', (b+1) T')."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        b, n, c = pcm.shape
+        t = (n - self.desc.frame_len) // self.desc.frame_hop + 1
+        out = np.empty(((self.desc.num_spks + self.desc.num_nois) * self.desc.num_bins, b * max(t, 0)), dtype=np.float32)
+        check(self.h, self.lib.css_forward_host(self.h, _np_ptr(pcm), b, n, c, _np_ptr(out)))
         return out
 
     def istft_host(self, planes: np.ndarray) -> np.ndarray:

@@ -1019,6 +1019,52 @@ int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int3
     return CSS_OK;
 }
 
+// ConformerCssWrapper.forward (conformer_wrapper.py:58-77) for a batch of equally long clips, fused on the device:
+// the training loop's validation forward.  pcm [batch][n_samples][n_ch] -> masks
+// [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1, clip b in columns [b T', (b+1) T').
+int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks) {
+    if (!h || !pcm || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    const int F = h->d.num_bins, C = h->d.num_mics, N = h->d.frame_len, hop = h->d.frame_hop;
+    const int nm = h->d.num_spks + h->d.num_nois;
+    if (n_ch != C) return fail(h, CSS_ERR_SHAPE, "the model expects " + std::to_string(C) + " channels");
+    if (n_samples < N) return fail(h, CSS_ERR_INVALID_ARG, "clip shorter than one frame");
+    const int64_t T64 = (n_samples - N) / hop + 1;
+    if (T64 < 2 || T64 > 256) return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2..256 frames");
+    if (T64 - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "clip longer than the relative-position table");
+    const int T = (int)T64;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t TT = (int64_t)batch * T;
+    const int64_t n_pad = (n_samples + 31) / 32 * 32;
+    const size_t in_f = (size_t)batch * n_samples * C, cm_f = (size_t)batch * C * n_pad;
+    const size_t x_f = (size_t)C * 2 * F * TT, m_f = (size_t)nm * F * TT;
+    int rc;
+    if ((rc = ensure(h, h->stage, (in_f + cm_f + x_f + m_f + 64) * sizeof(float))) != CSS_OK) return rc;
+    float* in = (float*)h->stage.p;
+    float* cm = in + (in_f + 15) / 16 * 16;
+    float* X = cm + (cm_f + 15) / 16 * 16;
+    float* M = X + (x_f + 15) / 16 * 16;
+    HIPCHK(h, hipMemcpyAsync(in, pcm, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    for (int b = 0; b < batch; ++b) {
+        // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
+        launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
+        GemmArgs g{};
+        g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
+        g.B = cm + (size_t)b * C * n_pad; g.ldb = hop; g.strideB = n_pad;
+        g.C = X + (int64_t)b * T; g.ldc = TT; g.strideC = (int64_t)2 * F * TT;
+        g.M = 2 * F; g.N = T; g.K = N; g.batch = C; g.alpha = 1.f;
+        launch_gemm(g, h->stream);
+    }
+    const int64_t cap = std::min<int64_t>(h->max_batch, batch);
+    if ((rc = ensure_activations(h, cap, T)) != CSS_OK) return rc;
+    MaskIo io{X, TT, TT, T, T, M, TT};  // clip b is the "segment" starting at frame b*T
+    for (int64_t s0 = 0; s0 < batch; s0 += cap)
+        if ((rc = masknet_batch(h, io, s0, (int)std::min<int64_t>(cap, batch - s0))) != CSS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(masks, M, m_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
 int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav) {
     if (!h || !y_planes || !wav || batch < 1 || t_frames < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop, KI = h->KIp;

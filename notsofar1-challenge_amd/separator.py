@@ -210,9 +210,15 @@ class HipSeparator:
         """[Batch, T, Mics] time-domain mixture -> masks (conformer_wrapper.py:58-77)."""
         assert (mix.shape[2] == 1) == (self.desc.num_mics == 1), \
             "IPD extractor is expected iff the number of microphones is greater than 1"
-        if mix.shape[2] == 1:
-            mix = mix[:, :, 0]
-        return self.separate(self.stft(mix))
+        # fused on the device (css_forward_host): batched analysis transform, features, mask estimator
+        torch = _torch()
+        x = mix.detach().cpu().numpy() if hasattr(mix, "detach") else np.asarray(mix)
+        b = x.shape[0]
+        m = self.handle.forward_host(x)  # [(S+1)F, B*T']
+        nm, f = self.desc.num_spks + self.desc.num_nois, self.desc.num_bins
+        m = m.reshape(nm, f, b, -1).transpose(2, 1, 3, 0)  # [B, F, T', S+1]
+        m = _like(torch.from_numpy(np.ascontiguousarray(m)), mix)
+        return {'spk_masks': m[..., :self.desc.num_spks], 'noise_masks': m[..., self.desc.num_spks:]}
 
     __call__ = forward
 

@@ -379,3 +379,21 @@ def test_full_size_60s_properties(L, CSS, sep_mc, mix60):
     # so x -> 0.5 x halves the output (up to float32-rounding-level winner-take-all flips)
     wh = h.run(0.5 * mix60[0], run_cfg)
     assert rel_rms(wh, 0.5 * w1) < 1e-3
+
+
+def test_batched_forward_is_stft_then_separate(L, sep_mc, sep_sc, mix60):
+    """ConformerCssWrapper.forward (conformer_wrapper.py:58-77) fused on the device (css_forward_host, the validation
+    forward of the training loop) gives bit for bit what the stft -> separate protocol calls give, for a batch of clips,
+    multi- and single-channel, and rejects what the reference's assert rejects."""
+    import torch
+    clips = np.stack([mix60[0, s:s + 48000] for s in (0, 16000, 40000, 123456, 300000)])           # [5, 48000, 7]
+    out = sep_mc.forward(torch.from_numpy(clips))
+    ref = sep_mc.separate(sep_mc.stft(torch.from_numpy(clips)))
+    assert tuple(out["spk_masks"].shape) == (5, F, T, 3) and tuple(out["noise_masks"].shape) == (5, F, T, 1)
+    assert torch.equal(out["spk_masks"], ref["spk_masks"]) and torch.equal(out["noise_masks"], ref["noise_masks"])
+    short = clips[:2, :20000, :1]                                                                     # [2, 20000, 1]
+    o1 = sep_sc.forward(torch.from_numpy(short))
+    r1 = sep_sc.separate(sep_sc.stft(torch.from_numpy(short[:, :, 0])))
+    assert tuple(o1["spk_masks"].shape) == (2, F, 77, 3) and torch.equal(o1["spk_masks"], r1["spk_masks"])
+    with pytest.raises(AssertionError):
+        sep_mc.forward(torch.from_numpy(short))                                                       # 1 channel into the MC model
