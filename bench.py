@@ -200,10 +200,20 @@ def main():
             peak = PEAK_FP32_MATRIX_TFLOPS
             kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
             extra = {}
+        # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes
+        # from the committed PMC passes of the same command (profiles/README.md), when present
+        traffic = None
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic.json")
+            if os.path.exists(tj):
+                with open(tj) as f:
+                    traffic = round(json.load(f)["traffic_bytes_per_launch"])
+                extra["traffic_source"] = f"profiles/{tag}_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                break
         result["roofline"] = {
             "bound": "mfma", "kernel": kernel,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": int(t["gemm_launches"]),
             "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
             "flops_per_step": t["gemm_flops"], **extra,

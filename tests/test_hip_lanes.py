@@ -67,3 +67,24 @@ def test_lanes_in_exact_mode(mc_state, mix60):
         finally:
             sep.close()
     assert np.array_equal(out[0], out[1])
+
+
+def test_long_meeting_multi_batch_is_lane_invariant(mc_state):
+    """5 minutes (201 segments, four batches of 64): the lane schedule and the batch boundaries leave no trace."""
+    CSS, L = pkg("css"), pkg("_lib")
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    mix = np.ascontiguousarray(pkg("synth").synth_meeting(302.0, 7, seed=3)[0])
+    out = []
+    for lanes, mb in [(1, 256), (2, 64), (3, 50)]:
+        sep = _separator(mc_state, lanes, mb)
+        try:
+            wav = sep.handle.run(mix, run_cfg)
+            nseg = sep.handle.get_plan().num_segments
+            perms = sep.handle.read(L.BUF_PERMS)
+        finally:
+            sep.close()
+        out.append((wav, perms))
+        assert nseg >= 200 and np.isfinite(wav).all()
+    for wav, perms in out[1:]:
+        assert np.array_equal(perms, out[0][1]) and np.array_equal(wav, out[0][0])

@@ -12,6 +12,6 @@ cp gpurun_out/${tag}_prof/p_kernel_stats.csv gpurun_out/${tag}_rocprofv3_kernel_
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/${tag}_pmc1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc2 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc3 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python tools/summarize_pmc.py gpurun_out/${tag}_pmc1 gpurun_out/${tag}_pmc2 gpurun_out/${tag}_pmc3 > gpurun_out/${tag}_pmc.md
+CSS_TRAFFIC_JSON=gpurun_out/${tag}_gemm_traffic.json python tools/summarize_pmc.py gpurun_out/${tag}_pmc1 gpurun_out/${tag}_pmc2 gpurun_out/${tag}_pmc3 > gpurun_out/${tag}_pmc.md
 python tools/parity_margins.py > gpurun_out/${tag}_parity_margins.txt 2>/dev/null
 head -c 1500 gpurun_out/${tag}_bench.json; echo; head -30 gpurun_out/${tag}_pmc.md

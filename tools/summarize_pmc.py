@@ -38,3 +38,21 @@ for k, r in m.iterrows():
         continue
     print(f"| `{k}` | {int(r['n'])} | {r['dur_us']:.1f} | {r['clk_GHz']:.2f} | {100 * r['mfma_util']:.1f}% | {100 * r['wait_frac']:.0f}% | "
           f"{r['fetch_MB']:.1f} | {r['write_MB']:.1f} | {r['hbm_GBps_raw']:.0f} | {r['hbm_GBps_fetch_x2']:.0f} |")
+
+# HBM traffic per launch of the dominant kernel for bench.py's roofline.traffic (FETCH_SIZE doubled as the guide
+# prescribes for gfx950's wide reads, + WRITE_SIZE), launch-weighted over the Linear-layer GEMM instantiations
+import json, os
+# (the <128, 2> instantiation = the full-batch launches of bench.py's single-lane profile pass, which is what
+#  roofline.achieved is measured on; the two-lane half-batch launches run the <64, 1> instantiation)
+g = m[m.index.str.contains("gemm_split_wd_kernel<128, 2>", regex=False)]
+if len(g):
+    wgt = g["n"]
+    out = {"kernel": "css::gemm_split_wd_kernel", "launches": int(wgt.sum()),
+           "fetch_bytes_raw": float((g["fetch_kb"] * 1024 * wgt).sum() / wgt.sum()),
+           "write_bytes": float((g["write_kb"] * 1024 * wgt).sum() / wgt.sum()),
+           "traffic_bytes_per_launch": float(((2 * g["fetch_kb"] + g["write_kb"]) * 1024 * wgt).sum() / wgt.sum()),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 per MI355X_MICROARCH.md"}
+    dst = os.environ.get("CSS_TRAFFIC_JSON")
+    if dst:
+        with open(dst, "w") as f:
+            json.dump(out, f, indent=1)
