@@ -397,3 +397,27 @@ def test_batched_forward_is_stft_then_separate(L, sep_mc, sep_sc, mix60):
     assert tuple(o1["spk_masks"].shape) == (2, F, 77, 3) and torch.equal(o1["spk_masks"], r1["spk_masks"])
     with pytest.raises(AssertionError):
         sep_mc.forward(torch.from_numpy(short))                                                       # 1 channel into the MC model
+
+
+@pytest.mark.parametrize("dims", [(256, 4, 512, 33), (768, 12, 1536, 33), (512, 8, 1024, 17), (512, 8, 1056, 31)])
+def test_other_model_widths_vs_oracle(L, mix_stage, dims):
+    """Narrower / wider models and another depthwise kernel size exercise the other template instantiations
+    (LayerNorm NV = 1 / 3, the fused conv module for D = 256 and its two-kernel fallback, GEMM tails): masks of a
+    2-block model against the oracle in both arithmetic modes."""
+    import torch
+    w = pkg("weights")
+    D, H, FFu, ks = dims
+    desc = w.ModelDesc(attention_dim=D, attention_heads=H, linear_units=FFu, num_blocks=2, kernel_size=ks)
+    st = w.apply_golden_recipe(w.portable_state_dict(desc, 31))
+    params = O.ConformerParams(st)
+    sep = pkg("separator").HipSeparator(st, None, device=0)
+    try:
+        xo = O.stft(mix_stage[0])
+        om = O.conformer_forward(params, O.features(xo[:, :T]))                        # [4, F, T]
+        for mode in ("split_f16", "exact_f32"):
+            sep.handle.set_linear_mode(mode)
+            out = sep.forward(torch.from_numpy(mix_stage[:, :48000]))
+            m = np.concatenate([out["spk_masks"].numpy()[0], out["noise_masks"].numpy()[0]], axis=-1)   # [F, T, 4]
+            assert np.abs(np.moveaxis(m, 2, 0) - om).max() < 5e-5, (dims, mode)
+    finally:
+        sep.close()
