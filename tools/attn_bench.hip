@@ -14,15 +14,18 @@ int main() {
     hipMemcpy(qkv, h.data(), nq * 4, hipMemcpyHostToDevice); hipMemcpy(pe, h.data(), npe * 4, hipMemcpyHostToDevice);
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, st);
-    hipEventRecord(e0, st);
-    const int it = 50;
-    for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, st);
-    hipEventRecord(e1, st); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<float> o(64); hipMemcpy(o.data(), ctx + 12345, 64 * 4, hipMemcpyDeviceToHost);
-    double cs = 0; for (int i = 0; i < 64; ++i) cs += o[i] * (i + 1);
-    const double mfma = (double)nseg * H * 6 * 608 * 4096.0;
-    printf("attention %d seg: %.2f us per launch, %.1f TFLOP/s MFMA-issued, checksum %.9g\n", nseg, 1e3 * ms / it, mfma / (ms / it * 1e-3) / 1e12, cs);
+    // qk_split = 0: q, k, pe read as float32 (exact mode); 1: the same bits interpreted as split-f16 operands --
+    // timing only, the values are then not a split of anything
+    for (int qks = 0; qks < 2; ++qks) {
+        for (int i = 0; i < 3; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
+        hipEventRecord(e0, st);
+        const int it = 50;
+        for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<float> o(64); hipMemcpy(o.data(), ctx + 12345, 64 * 4, hipMemcpyDeviceToHost);
+        double cs = 0; for (int i = 0; i < 64; ++i) cs += o[i] * (i + 1);
+        printf("attention %d seg, %s scores: %.2f us per launch, checksum %.9g\n", nseg, qks ? "split-f16" : "float32", 1e3 * ms / it, cs);
+    }
     return 0;
 }
