@@ -73,7 +73,7 @@ __device__ __forceinline__ void tile_prefetch(TilePre& p, int mb, int n, int M, 
 }
 __device__ __forceinline__ void emit_tile_pre(const f32x16& acc, const TilePre& p, int mb, int n, int M, int N,
                                               float* __restrict__ C, int64_t ldc, int act, bool has_res, float alpha,
-                                              int split_out) {
+                                              int split_out, int nt = 0) {
     const bool n_ok = n < N;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -83,8 +83,73 @@ __device__ __forceinline__ void emit_tile_pre(const f32x16& acc, const TilePre& 
         else if (act == ACT_SIGMOID) v = sigmoidf_(v);
         if (has_res) v = p.rv[r] + alpha * v;
         if (n_ok && m < M) {
+            if (nt) {
+            if (n < split_out) {
+                _Float16 hi_, lo_;
+                split_f16(v, hi_, lo_);
+                _Float16* row_ = reinterpret_cast<_Float16*>(C + (int64_t)m * ldc);
+                const int i_ = split_index(n);
+                __builtin_nontemporal_store(hi_, row_ + i_);
+                __builtin_nontemporal_store(lo_, row_ + i_ + 32);
+            } else {
+                __builtin_nontemporal_store(v, C + (int64_t)m * ldc + n);
+            }
+            } else {
             if (n < split_out) split_store(reinterpret_cast<_Float16*>(C + (int64_t)m * ldc), n, v);
             else C[(int64_t)m * ldc + n] = v;
+            }
+        }
+    }
+}
+
+// The same epilogue with 16-byte stores.  In the accumulator layout a lane owns ONE column of 16 rows, so the plain
+// epilogue issues 16 four-byte (or 32 two-byte) store instructions per tile, and on this hardware the epilogue of a
+// launch is bound by store ISSUE, not bandwidth (MI355X_MICROARCH.md: ~7 B/clk/CU for narrow row-per-lane stores;
+// tools/gemm_wd_epilogue_ablation.sh: the epilogue is 5.5 of the 9 us a K = 32 launch takes).  The finished tile
+// therefore takes a turn through a wave-private LDS patch [32][LDS_LD] and leaves as 4 float4 row segments per lane
+// (split columns: 4 x {8-byte hi, 8-byte lo}).  Requires N % 4 == 0 for the columns of this tile.
+__device__ __forceinline__ void emit_tile_pre_wide(const f32x16& acc, const TilePre& p, int mb0, int h, int c, int nb, int M,
+                                                   int N, float* __restrict__ C, int64_t ldc, int act, bool has_res,
+                                                   float alpha, int split_out, int nt, float* __restrict__ patch) {
+    // mb0 = first row of the tile, nb = first column; this lane computed column nb + c of rows mb0 + 4h + {0..3} + 8 i
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + p.bn;
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+        if (has_res) v = p.rv[r] + alpha * v;
+        patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_LD + c] = v;
+    }
+    const int lane = c + 32 * h;
+    const int col4 = (lane & 7) * 4, n = nb + col4;
+    if (n >= N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, m = mb0 + row;
+        const float4 v = *reinterpret_cast<const float4*>(patch + row * LDS_LD + col4);
+        if (m >= M) continue;
+        float* dst = C + (int64_t)m * ldc;
+        if (n < split_out) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hi, lo;
+            _Float16 a, b;
+            split_f16(v.x, a, b); hi[0] = a; lo[0] = b;
+            split_f16(v.y, a, b); hi[1] = a; lo[1] = b;
+            split_f16(v.z, a, b); hi[2] = a; lo[2] = b;
+            split_f16(v.w, a, b); hi[3] = a; lo[3] = b;
+            _Float16* rowh = reinterpret_cast<_Float16*>(dst) + split_index(n);
+            if (nt) {
+                __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(rowh));
+                __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(rowh + 32));
+            } else {
+                *reinterpret_cast<f16x4*>(rowh) = hi;
+                *reinterpret_cast<f16x4*>(rowh + 32) = lo;
+            }
+        } else {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 vv = {v.x, v.y, v.z, v.w};
+            if (nt) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(dst + n));
+            else *reinterpret_cast<f32x4*>(dst + n) = vv;
         }
     }
 }

@@ -191,10 +191,26 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) == 128 ? 1 : 2) void gemm_spl
     const int act = g.act, bias_m = g.bias_along_m, so = g.split_out;
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
+#ifdef CSS_ABL_NO_EMIT   /* ablation (tools only): one store per wave keeps the accumulators alive, nothing else is written */
+    {
+        float keep_ = 0.f;
+        for (int e = 0; e < 16; ++e) keep_ += acc0[e] + acc1[e] + acc2[e] + acc3[e] + cor0[e] + cor1[e] + cor2[e] + cor3[e];
+        if (lane == 0) C[(int64_t)min(m0 + wm * (BM / WMV), M - 1) * g.ldc + min(n0 + wn * 32, N - 1)] = keep_;
+    }
+    return;
+#endif
+    // wide epilogue (gemm_common.hpp): each wave's finished tiles pass through its own [32][LDS_LD] patch of the slab
+    // buffers, which nobody reads any more after the loop's last barrier
+    float* patch = lds + wave * (32 * LDS_LD);
+    static_assert(2 * STAGE >= (WMV * 4) * 32 * LDS_LD, "epilogue patches must fit in the slab buffers");
+    const int mtile = m0 + wm * (BM / WMV), ntile = n0 + wn * 32;
+    const bool wide = early && !g.narrow_epilogue;
 #define CSS_E1(t, ...)                                                                                      \
     if constexpr (t < TM) {                                                                                 \
         acc##t += cor##t * SPLIT_LO_INV;                                                                    \
-        if (early) emit_tile_pre(acc##t, pre##t, mrow + 32 * t, ncol, M, N, C, ldc, act, res != nullptr, alpha, so); \
+        if (wide) emit_tile_pre_wide(acc##t, pre##t, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, res != nullptr, alpha, so, \
+                                     g.nt_store, patch);                                                    \
+        else if (early) emit_tile_pre(acc##t, pre##t, mrow + 32 * t, ncol, M, N, C, ldc, act, res != nullptr, alpha, so, g.nt_store); \
         else emit_tile(acc##t, mrow + 32 * t, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);  \
     }
     CSS_I4(CSS_E1, 0)
@@ -247,8 +263,11 @@ void launch_split_convert_tiled(const float* src, int64_t ld_src, float* dst, in
     hipLaunchKernelGGL(split_convert_tiled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, N, K);
 }
 
-void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0) return;
+void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
+    if (g_in.M <= 0 || g_in.N <= 0) return;
+    static const int nt_env = [] { const char* e = std::getenv("CSS_EPI_NT"); return e ? std::atoi(e) : -1; }();
+    GemmArgs g = g_in;
+    if (nt_env >= 0) g.nt_store = nt_env;
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WD_WAVES"); return e ? std::atoi(e) : 0; }();
     if (forced == 4) {

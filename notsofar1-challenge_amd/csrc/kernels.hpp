@@ -35,6 +35,8 @@ struct GemmArgs {
     // hint: other kernels run beside this launch (two-lane mask estimator): prefer 4-wave 64-row tiles, two of which
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
+    int nt_store;   // epilogue stores bypass the caches (nontemporal)
+    int narrow_epilogue;   // tools: keep the 4-byte-per-lane epilogue of the weights-direct kernel (A/B timing)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
