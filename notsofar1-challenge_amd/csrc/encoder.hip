@@ -530,13 +530,22 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    if (split_out) {   // ctx rows in the split-f16 GEMM operand format (split_f16.hpp) for the output projection
+    // 32 query rows x 64 features leave in 16-byte pieces (the store tail of a row-per-lane epilogue is bound by store
+    // issue, not bandwidth): lane l takes features 4 (l % 16) .. + 3 of rows l / 16 + 4 k
+    {
+        const int d4 = (lane & 15) * 4;
         float* ob = ctx + ((int64_t)seg * T + i0) * D;
-        for (int il = 0; il < 32 && i0 + il < T; ++il)
-            split_store(reinterpret_cast<_Float16*>(ob + (int64_t)il * D), head * DK + lane, lds[il * OLD + lane]);
-    } else {
-        float* ob = ctx + ((int64_t)seg * T + i0) * D + head * DK;
-        for (int il = 0; il < 32 && i0 + il < T; ++il) ob[(int64_t)il * D + lane] = lds[il * OLD + lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int il = (lane >> 4) + 4 * k;
+            if (i0 + il >= T) continue;
+            const float* src = lds + il * OLD + d4;
+            const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            if (split_out)   // ctx rows in the split-f16 GEMM operand format (split_f16.hpp) for the output projection
+                split_store4(reinterpret_cast<_Float16*>(ob + (int64_t)il * D), head * DK + d4, v0, v1, v2, v3);
+            else
+                *reinterpret_cast<float4*>(ob + (int64_t)il * D + head * DK + d4) = make_float4(v0, v1, v2, v3);
+        }
     }
 }
 
