@@ -312,14 +312,21 @@ __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __re
         for (int j = (p - (TAPS - 1) > 0 ? p - (TAPS - 1) : 0); j <= (p < RUN - 1 ? p : RUN - 1); ++j)
             acc[j] = fmaf(wk[p - j], zv, acc[j]);
     }
-    float* ys = x_out + (int64_t)seg * T * D + ch;
+    // the RUN x D outputs go back through LDS (the GLU tile is dead once every thread has finished its taps) and leave
+    // as 16-byte row pieces: one 4-byte store per lane and frame made the kernel's tail store-issue bound
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < RUN; ++j) {
-        const int t = t0 + j;
-        if (t < T) {
-            const float y = fmaxf((acc[j] + bb) * al + be_, 0.f);
-            ys[(int64_t)t * D] = xres[j] + (w2 * y + c2);
-        }
+        const float y = fmaxf((acc[j] + bb) * al + be_, 0.f);
+        tile[j * D + ch] = xres[j] + (w2 * y + c2);
+    }
+    __syncthreads();
+    float* ys = x_out + ((int64_t)seg * T + t0) * D;
+    constexpr int Q = D / 4;   // float4 pieces per frame
+    for (int idx = threadIdx.x; idx < RUN * Q; idx += 256 * NV) {
+        const int j = idx / Q, c4 = idx - j * Q;
+        if (t0 + j < T)
+            *reinterpret_cast<float4*>(ys + (int64_t)j * D + 4 * c4) = *reinterpret_cast<const float4*>(tile + j * D + 4 * c4);
     }
 }
 
