@@ -146,6 +146,20 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
     const int mrow = m0 + wm * (BM / WM) + 4 * h, ncol = n0 + wn * 64 + c;
+    // 16-byte stores through a wave-private LDS patch when the output rows allow it (gemm_common.hpp)
+    const bool wide = (ldc % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    if (wide) {
+        __syncthreads();   // the slab buffers are free once every wave has left the K loop
+        float* patch = lds + wave * (32 * LDS_LD);
+        const int mt = m0 + wm * (BM / WM), nt = n0 + wn * 64;
+        emit_tile_wide(acc00, mt, h, c, nt, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0, patch);
+        emit_tile_wide(acc01, mt, h, c, nt + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0, patch);
+        if constexpr (TM == 2) {
+            emit_tile_wide(acc10, mt + 32, h, c, nt, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0, patch);
+            emit_tile_wide(acc11, mt + 32, h, c, nt + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0, patch);
+        }
+        return;
+    }
     emit_tile(acc00, mrow, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
     emit_tile(acc01, mrow, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, 0);
     if constexpr (TM == 2) {

@@ -52,6 +52,46 @@ __device__ __forceinline__ void emit_tile(const f32x16& acc, int mb, int n, int 
     }
 }
 
+// emit_tile with 16-byte stores (see emit_tile_pre_wide below for why): the finished tile takes a turn through a
+// wave-private LDS patch [32][LDS_LD] and leaves as float4 row pieces.  The caller guarantees ldc % 4 == 0, a
+// 16-byte aligned C and N % 4 == 0 (else it uses emit_tile).  mb0 / nb = first row / column of the tile.
+__device__ __forceinline__ void emit_tile_wide(const f32x16& acc, int mb0, int h, int c, int nb, int M, int N,
+                                               float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                               int bias_m, int act, const float* __restrict__ res, int64_t ldr,
+                                               float alpha, int split_out, float* __restrict__ patch) {
+    const int n = nb + c, mb = mb0 + 4 * h;
+    const int nc = n < N ? n : N - 1;
+    const float bn = (bias && !bias_m) ? bias[nc] : 0.f;
+    float rv[16], bm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const int mc = m < M ? m : M - 1;
+        rv[r] = res ? res[(int64_t)mc * ldr + nc] : 0.f;
+        bm[r] = (bias && bias_m) ? bias[mc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + bn + bm[r];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+        if (res) v = rv[r] + alpha * v;
+        patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_LD + c] = v;
+    }
+    const int lane = c + 32 * h;
+    const int col4 = (lane & 7) * 4, n4 = nb + col4;
+    if (n4 >= N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, m = mb0 + row;
+        const float4 v = *reinterpret_cast<const float4*>(patch + row * LDS_LD + col4);
+        if (m >= M) continue;
+        float* dst = C + (int64_t)m * ldc;
+        if (n4 < split_out) split_store4(reinterpret_cast<_Float16*>(dst), n4, v.x, v.y, v.z, v.w);
+        else *reinterpret_cast<float4*>(dst + n4) = v;
+    }
+}
+
 // The same epilogue with its memory operands requested EARLY: tile_prefetch before the K loop (the bias and the 16
 // residual values of a tile are loop invariant -- an in-place residual C = x + alpha*(...) reads x before anyone
 // writes it), emit_tile_pre after it.  Saves the dependent global-load round trip(s) that otherwise sit between the
