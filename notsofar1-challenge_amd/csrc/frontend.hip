@@ -136,13 +136,33 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float invT = 1.0f / (float)T;
     constexpr int NT = FEAT_TMAX / 64;
+    // plane values of bin b + 1 are requested while bin b is being computed (the atan2 / sincos work of a bin is long
+    // enough to cover the round trip; without this every one of a wave's 8 bins started with an exposed load)
+    float n_r0[NT], n_i0[NT], n_rm[NT], n_im[NT];
+    auto fetch = [&](int b_) {
+        const int f_ = min(f0 + wave * 8 + b_, F - 1);
+        const float* re0 = X + (int64_t)(f_)*T_ld + st;            // mic 0, Re row f
+        const float* im0 = X + (int64_t)(F + f_) * T_ld + st;      // mic 0, Im row f
+        const float* rem = re0 + (int64_t)m * 2 * F * T_ld;        // mic m
+        const float* imm = im0 + (int64_t)m * 2 * F * T_ld;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = lane + 64 * i;
+            const bool ok = t < tv;   // (tv <= T)
+            n_r0[i] = ok ? re0[t] : 0.f;
+            n_i0[i] = ok ? im0[t] : 0.f;
+            n_rm[i] = (ok && m != 0) ? rem[t] : 0.f;
+            n_im[i] = (ok && m != 0) ? imm[t] : 0.f;
+        }
+    };
+    fetch(0);
     for (int b = 0; b < 8; ++b) {
         const int fl = wave * 8 + b, f = f0 + fl;
         if (f >= F) break;
-        const float* re0 = X + (int64_t)(f)*T_ld + st;            // mic 0, Re row f
-        const float* im0 = X + (int64_t)(F + f) * T_ld + st;      // mic 0, Im row f
-        const float* rem = re0 + (int64_t)m * 2 * F * T_ld;       // mic m
-        const float* imm = im0 + (int64_t)m * 2 * F * T_ld;
+        float c_r0[NT], c_i0[NT], c_rm[NT], c_im[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { c_r0[i] = n_r0[i]; c_i0[i] = n_i0[i]; c_rm[i] = n_rm[i]; c_im[i] = n_im[i]; }
+        if (b + 1 < 8) fetch(b + 1);
         float a[NT], bq[NT];
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -150,13 +170,12 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
             const int t = lane + 64 * i;
             a[i] = 0.f; bq[i] = 0.f;
             if (t < T) {
-                const bool ok = t < tv;
-                const float r0 = ok ? re0[t] : 0.f, i0 = ok ? im0[t] : 0.f;
+                const float r0 = c_r0[i], i0 = c_i0[i];
                 if (m == 0) {
                     a[i] = fmaxf(sqrtf(r0 * r0 + i0 * i0), CSS_EPS32);
                     s0 += a[i];
                 } else {
-                    const float rm = ok ? rem[t] : 0.f, imv = ok ? imm[t] : 0.f;
+                    const float rm = c_rm[i], imv = c_im[i];
                     const float d = phase_of(rm, imv) - phase_of(r0, i0);
                     a[i] = cosf(d);
                     bq[i] = sinf(d);
