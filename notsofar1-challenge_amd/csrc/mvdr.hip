@@ -64,22 +64,41 @@ __global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
     const float* mrow = a.masks + (int64_t)f * a.mask_ld + seg * (int64_t)T;
     const int64_t mstride = (int64_t)F * a.mask_ld;
     const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
-    for (int t = l16; t < tv; t += 16) {
-        // masks of this TF point: S speakers, then the noise mask (sum over noise outputs; one here)
-        float mk = 0.f, mx = -INFINITY;
-        for (int j = 0; j < nm; ++j) {
-            const float v = mrow[j * mstride + t];
-            mx = fmaxf(mx, v);
-            if (j == k) mk = v;
-        }
-        const bool win = ov ? (ov[t] == k) : (mk == mx);  // ties keep every tied mask, like mask == mask_max
-        const double w = win ? (double)mk : 1e-10;
-        float xr[NC], xi[NC];
+    // the operands of frame t + 16 are requested before frame t is accumulated (49 x 3 float64 operations per frame are
+    // long enough to cover the round trip; the loads of a frame used to start only when the previous one was done)
+    float n_m[4], n_xr[NC], n_xi[NC];
+    int n_ov = 0;
+    auto fetch = [&](int t_) {
+        const bool ok = t_ < tv;
+        const int tc = ok ? t_ : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n_m[j] = (ok && j < nm) ? mrow[j * mstride + tc] : 0.f;
+        n_ov = (ok && ov) ? ov[tc] : 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            xr[c] = a.X[((int64_t)c * 2 * F + f) * a.T_ld + st + t];
-            xi[c] = a.X[((int64_t)c * 2 * F + F + f) * a.T_ld + st + t];
+            n_xr[c] = ok ? a.X[((int64_t)c * 2 * F + f) * a.T_ld + st + tc] : 0.f;
+            n_xi[c] = ok ? a.X[((int64_t)c * 2 * F + F + f) * a.T_ld + st + tc] : 0.f;
         }
+    };
+    fetch(l16);
+    for (int t = l16; t < tv; t += 16) {
+        float mv[4], xr[NC], xi[NC];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mv[j] = n_m[j];
+        const int ovv = n_ov;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { xr[c] = n_xr[c]; xi[c] = n_xi[c]; }
+        fetch(t + 16);
+        // masks of this TF point: S speakers, then the noise mask (sum over noise outputs; one here)
+        float mk = 0.f, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nm) {
+                mx = fmaxf(mx, mv[j]);
+                if (j == k) mk = mv[j];
+            }
+        const bool win = ov ? (ovv == k) : (mk == mx);  // ties keep every tied mask, like mask == mask_max
+        const double w = win ? (double)mk : 1e-10;
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] += w * ((double)xr[c] * xr[c] + (double)xi[c] * xi[c]);
         int p = NC;
