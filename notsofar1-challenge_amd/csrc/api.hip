@@ -638,14 +638,17 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         // conv module (conformer.py:113-127): one kernel, x -> cb (the attention context buffer is free again; the
         // kernel must not write where neighbouring blocks still read), and the second feed-forward takes cb as its
         // input and residual and writes x.  Uncovered (D, taps): LayerNorm+GLU -> u, depthwise conv in place.
+        // The LayerNorm of the second feed-forward (conformer.py:139) rides on the conv module's output pass.
         const float* xc = cb;
-        if (!launch_conv_module(x, cb, b.conv_ln_w, b.conv_ln_b, b.pw, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, nb, T, D,
-                                d.kernel_size, st)) {
+        bool ffo_ln = false;
+        if (!launch_conv_module(x, cb, b.conv_ln_w, b.conv_ln_b, b.pw, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.ffo_ln_w,
+                                b.ffo_ln_b, sp ? nullptr : u, sp ? u : nullptr, nb, T, D, d.kernel_size, st)) {
             launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
             launch_dwconv(u, x, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.pw, nb, T, D, d.kernel_size, st);
             xc = x;
+            ffo_ln = true;
         }
-        ffn(true, xc, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
+        ffn(ffo_ln, xc, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
         if (!last) {
             // conformer.py:184 and the next block's feed-forward LayerNorm (conformer.py:139) in one pass over x
             const BlockWeights& nb_ = W.blocks[l + 1];

@@ -230,14 +230,17 @@ void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw
 // the GLU outputs in LDS (63 frames x 512 channels = 126 KB); phase 2 is dwconv_kernel's arithmetic reading LDS
 // instead of global memory.  Saves the write + read of the GLU tensor and one launch per block of the network
 // (27.5 -> 14 us per layer for 40 segments); each frame's LayerNorm is computed by two blocks, which is noise.
-// x_out must not alias x_in: neighbouring runs read each other's input frames.
+// x_out must not alias x_in: neighbouring runs read each other's input frames.  The LayerNorm of the module that
+// FOLLOWS (ln2_*, z / z_split; optional) is applied to the outgoing rows in the same pass.
 // ------------------------------------------------------------------------------------------------
 template <int NV, int TAPS, int RUN>
 __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __restrict__ x_in, float* __restrict__ x_out,
                                                               const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                               const float* __restrict__ pw, const float* __restrict__ wt,
                                                               const float* __restrict__ dwb, const float* __restrict__ alpha,
-                                                              const float* __restrict__ beta, int T, int runs_per_seg) {
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                                                              float* __restrict__ z, float* __restrict__ zs, int T, int runs_per_seg) {
     constexpr int D = 256 * NV, PAD = (TAPS - 1) / 2, ROWS = RUN + TAPS - 1, NW = 4 * NV;
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [ROWS][D]
     const int seg = blockIdx.x / runs_per_seg, run = blockIdx.x % runs_per_seg;
@@ -321,18 +324,44 @@ __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __re
         tile[j * D + ch] = xres[j] + (w2 * y + c2);
     }
     __syncthreads();
-    float* ys = x_out + ((int64_t)seg * T + t0) * D;
-    constexpr int Q = D / 4;   // float4 pieces per frame
-    for (int idx = threadIdx.x; idx < RUN * Q; idx += 256 * NV) {
-        const int j = idx / Q, c4 = idx - j * Q;
-        if (t0 + j < T)
-            *reinterpret_cast<float4*>(ys + (int64_t)j * D + 4 * c4) = *reinterpret_cast<const float4*>(tile + j * D + 4 * c4);
+    // One wave per frame: the frame leaves as 16-byte pieces, and -- the whole row being in the wave's registers -- the
+    // LayerNorm of the feed-forward module that follows (conformer.py:139) is applied on the way out, value for value
+    // what layernorm_kernel computes from the stored row (z: float32 rows, zs: split-f16 operand rows; either may be null).
+    for (int j = wave; j < RUN && t0 + j < T; j += NW) {
+        const int64_t row = (int64_t)seg * T + t0 + j;
+        float4 r[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i] = reinterpret_cast<const float4*>(tile + j * D)[lane + 64 * i];
+            reinterpret_cast<float4*>(x_out + row * D)[lane + 64 * i] = r[i];
+            s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+        }
+        if (!z && !zs) continue;
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i].x -= mean; r[i].y -= mean; r[i].z -= mean; r[i].w -= mean;
+            q += (r[i].x * r[i].x + r[i].y * r[i].y) + (r[i].z * r[i].z + r[i].w * r[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 g = reinterpret_cast<const float4*>(ln2w)[lane + 64 * i];
+            const float4 be = reinterpret_cast<const float4*>(ln2b)[lane + 64 * i];
+            const float4 o = make_float4(r[i].x * rstd * g.x + be.x, r[i].y * rstd * g.y + be.y, r[i].z * rstd * g.z + be.z,
+                                         r[i].w * rstd * g.w + be.w);
+            if (z) reinterpret_cast<float4*>(z + row * D)[lane + 64 * i] = o;
+            if (zs) split_store4(reinterpret_cast<_Float16*>(zs + row * D), 4 * (lane + 64 * i), o.x, o.y, o.z, o.w);
+        }
     }
 }
 
 // false: this (D, taps) is not covered (the caller falls back to launch_ln_glu + launch_dwconv)
 bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, const float* ln_b, const float* pw,
-                        const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta, int nseg, int T,
+                        const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta,
+                        const float* ln2_w, const float* ln2_b, float* z, float* z_split, int nseg, int T,
                         int D, int taps, hipStream_t s) {
     constexpr int RUN = 31;
     if (taps != 33 || (D != 256 && D != 512)) return false;
@@ -346,10 +375,10 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
     }
     if (D == 512)
         hipLaunchKernelGGL((conv_module_kernel<2, 33, RUN>), dim3(nseg * runs), dim3(512), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
-                           dw_b, bn_alpha, bn_beta, T, runs);
+                           dw_b, bn_alpha, bn_beta, ln2_w, ln2_b, z, z_split, T, runs);
     else
         hipLaunchKernelGGL((conv_module_kernel<1, 33, RUN>), dim3(nseg * runs), dim3(256), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
-                           dw_b, bn_alpha, bn_beta, T, runs);
+                           dw_b, bn_alpha, bn_beta, ln2_w, ln2_b, z, z_split, T, runs);
     return true;
 }
 

@@ -38,7 +38,7 @@ constexpr int WD_BM = 128;
 // of slab kt (sched_group_barrier pattern): an MFMA leaves ~5 issue slots free while it runs, and with one or two
 // waves per SIMD nothing else would hide those instructions.
 template <int BM, int WMV>
-__global__ __launch_bounds__(WMV * 256, (BM / WMV) == 128 ? 1 : 2) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : 2) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WMV * 256;
     constexpr int TM = BM / 32 / WMV;           // 32-row tiles per wave
     constexpr int LROWS = THREADS / 8;          // rows per staging pass
@@ -270,9 +270,13 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     if (nt_env >= 0) g.nt_store = nt_env;
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WD_WAVES"); return e ? std::atoi(e) : 0; }();
-    if (forced == 4) {
+    const int pick = g.tile_rows ? g.tile_rows : forced;
+    if (pick == 96) {
+        const int tm96 = (g.M + 95) / 96;
+        hipLaunchKernelGGL((gemm_split_wd_kernel<96, 1>), dim3(tm96 * tiles_n), dim3(256), 0, s, g, tm96, tiles_n);
+    } else if (pick == 4) {
         hipLaunchKernelGGL((gemm_split_wd_kernel<128, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g, tiles_m, tiles_n);
-    } else if (forced == 64 || (!forced && g.concurrent)) {
+    } else if (pick == 64 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
     } else {

@@ -36,6 +36,7 @@ struct GemmArgs {
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
     int nt_store;   // epilogue stores bypass the caches (nontemporal)
+    int tile_rows;         // weights-direct kernel: 0 = choose, else 64 / 96 / 128 (8 waves) / 4 (128 rows, 4 waves)
     int narrow_epilogue;   // tools: keep the 4-byte-per-lane epilogue of the weights-direct kernel (A/B timing)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
@@ -64,9 +65,11 @@ void launch_ln_glu(const float* x, float* z, const float* w, const float* b, con
 void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw_b, const float* bn_alpha,
                    const float* bn_beta, const float* pw, int nseg, int T, int D, int taps, hipStream_t s);
 // the whole conv module in one kernel: x_out = x_in + conv_module(x_in); x_out must not alias x_in.  Returns false when
-// (D, taps) is not covered and nothing was launched (use launch_ln_glu + launch_dwconv).
+// (D, taps) is not covered and nothing was launched (use launch_ln_glu + launch_dwconv).  z / z_split (either may be
+// null) = LayerNorm(x_out; ln2_w, ln2_b) as float32 / split-f16 rows: the LayerNorm of the module that follows.
 bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, const float* ln_b, const float* pw,
-                        const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta, int nseg, int T,
+                        const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta,
+                        const float* ln2_w, const float* ln2_b, float* z, float* z_split, int nseg, int T,
                         int D, int taps, hipStream_t s);
 // relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows).
 // qk_split: the q and k columns of qkv and the rows of pe_k are split-f16 (scores on the f16 matrix cores with

@@ -1,0 +1,58 @@
+// Row-tile height of the weights-direct split GEMM vs the shapes of the CSS path (tools only, not shipped): one launch
+// alone and two launches side by side on two streams (what the two lanes of the mask estimator do).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_tile_bench.hip notsofar1-challenge_amd/csrc/gemm.hip \
+//       notsofar1-challenge_amd/csrc/gemm_split.hip notsofar1-challenge_amd/csrc/gemm_split_wd.hip -Inotsofar1-challenge_amd/csrc -o /tmp/gemm_tile_bench
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+using namespace css;
+int main(int argc, char** argv) {
+    struct Shape { int N, K; const char* name; int res; };
+    Shape shapes[] = {{1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 512, "attn-out", 1}};
+    int Ms[] = {5022, 2604, 11904, 5952, 23808};
+    int tiles[] = {64, 96, 128, 4};
+    size_t maxe = 24000ull * 1536;
+    float *A, *B, *Bt, *As, *C[2], *R;
+    hipMalloc(&A, maxe * 4); hipMalloc(&As, maxe * 4); hipMalloc(&B, 1536 * 1024 * 4); hipMalloc(&Bt, 1536 * 1024 * 4);
+    hipMalloc(&C[0], maxe * 4); hipMalloc(&C[1], maxe * 4); hipMalloc(&R, maxe * 4);
+    std::vector<float> h(maxe);
+    unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    hipMemcpy(A, h.data(), maxe * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), 1536 * 1024 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(R, h.data(), maxe * 4, hipMemcpyHostToDevice);
+    hipStream_t st[2]; hipStreamCreate(&st[0]); hipStreamCreate(&st[1]);
+    hipEvent_t e0, e1, ej; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&ej);
+    for (int M : Ms) for (auto& sh : shapes) {
+        launch_split_convert(A, sh.K, As, M, sh.K, sh.K, st[0]);
+        launch_split_convert_tiled(B, sh.K, Bt, sh.N, sh.K, st[0]);
+        hipStreamSynchronize(st[0]);
+        printf("M=%5d %-9s N=%4d K=%4d :", M, sh.name, sh.N, sh.K);
+        for (int dual = 0; dual < 2; ++dual) {
+            printf(dual ? "  | two streams:" : "  one stream:");
+            for (int t : tiles) {
+                GemmArgs g{};
+                g.A = As; g.lda = sh.K; g.B = Bt; g.ldb = sh.K; g.ldc = sh.N; g.M = M; g.N = sh.N; g.K = sh.K; g.batch = 1; g.alpha = 1.f;
+                g.split_in = 1; g.b_tiled = 1; g.split_out = sh.res ? 0 : sh.N; g.tile_rows = t; g.bias = A;
+                if (sh.res) { g.residual = R; g.ldr = sh.N; g.alpha = 0.5f; }
+                const int it = 20;
+                float ms;
+                auto go = [&](int n) {
+                    for (int i = 0; i < n; ++i)
+                        for (int l = 0; l <= dual; ++l) { GemmArgs q = g; q.C = C[l]; launch_gemm(q, st[l]); }
+                };
+                go(3); hipDeviceSynchronize();
+                hipEventRecord(e0, st[0]);
+                if (dual) hipStreamWaitEvent(st[1], e0, 0);
+                go(it);
+                if (dual) { hipEventRecord(ej, st[1]); hipStreamWaitEvent(st[0], ej, 0); }
+                hipEventRecord(e1, st[0]); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                const double fl = 2.0 * M * sh.N * sh.K * (dual + 1);
+                printf(" %3d:%6.2fus %5.0fTF", t, 1e3 * ms / it, fl / (ms / it * 1e-3) / 1e12);
+            }
+        }
+        printf("\n");
+    }
+    return 0;
+}
