@@ -38,13 +38,14 @@ constexpr int WD_BM = 128;
 // of slab kt (sched_group_barrier pattern): an MFMA leaves ~5 issue slots free while it runs, and with one or two
 // waves per SIMD nothing else would hide those instructions.
 template <int BM, int WMV>
-__global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : 2) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 ? 2 : 4) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WMV * 256;
     constexpr int TM = BM / 32 / WMV;           // 32-row tiles per wave
     constexpr int LROWS = THREADS / 8;          // rows per staging pass
     constexpr int NLA = BM / LROWS;             // staging passes (4 or 2)
     constexpr int STAGE = BM * LDS_LD;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int PATCHES = WMV * 4 * 32 * LDS_LD;   // the epilogue's wave-private patches reuse the slab buffers
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > PATCHES ? 2 * STAGE : PATCHES];
     const int n_tiles = tiles_m * tiles_n;
     const int tile = xcd_tile(blockIdx.x, n_tiles);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : 2) void gemm_spli
     // wide epilogue (gemm_common.hpp): each wave's finished tiles pass through its own [32][LDS_LD] patch of the slab
     // buffers, which nobody reads any more after the loop's last barrier
     float* patch = lds + wave * (32 * LDS_LD);
-    static_assert(2 * STAGE >= (WMV * 4) * 32 * LDS_LD, "epilogue patches must fit in the slab buffers");
     const int mtile = m0 + wm * (BM / WMV), ntile = n0 + wn * 32;
     const bool wide = early && !g.narrow_epilogue;
 #define CSS_E1(t, ...)                                                                                      \
@@ -271,7 +271,10 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
     static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WD_WAVES"); return e ? std::atoi(e) : 0; }();
     const int pick = g.tile_rows ? g.tile_rows : forced;
-    if (pick == 96) {
+    if (pick == 32) {
+        const int tm32 = (g.M + 31) / 32;
+        hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);
+    } else if (pick == 96) {
         const int tm96 = (g.M + 95) / 96;
         hipLaunchKernelGGL((gemm_split_wd_kernel<96, 1>), dim3(tm96 * tiles_n), dim3(256), 0, s, g, tm96, tiles_n);
     } else if (pick == 4) {

@@ -1,11 +1,12 @@
 // Stand-alone timing of css::launch_relpos_attention (tools only).
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
 using namespace css;
-int main() {
-    const int nseg = 40, T = 186, D = 512, H = 8, maxlen = 1000;
+int main(int argc, char** argv) {
+    const int nseg = argc > 1 ? atoi(argv[1]) : 40, T = 186, D = 512, H = 8, maxlen = 1000;
     const size_t nq = (size_t)nseg * T * 3 * D, npe = 2 * maxlen * 64, nc = (size_t)nseg * T * D;
     float *qkv, *pe, *ctx;
     hipMalloc(&qkv, nq * 4); hipMalloc(&pe, npe * 4); hipMalloc(&ctx, nc * 4);

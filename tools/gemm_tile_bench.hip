@@ -11,8 +11,8 @@ using namespace css;
 int main(int argc, char** argv) {
     struct Shape { int N, K; const char* name; int res; };
     Shape shapes[] = {{1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 512, "attn-out", 1}};
-    int Ms[] = {5022, 2604, 11904, 5952, 23808};
-    int tiles[] = {64, 96, 128, 4};
+    int Ms[] = {5022, 2604, 11904, 5952};
+    int tiles[] = {32, 64, 96, 128};
     size_t maxe = 24000ull * 1536;
     float *A, *B, *Bt, *As, *C[2], *R;
     hipMalloc(&A, maxe * 4); hipMalloc(&As, maxe * 4); hipMalloc(&B, 1536 * 1024 * 4); hipMalloc(&Bt, 1536 * 1024 * 4);
