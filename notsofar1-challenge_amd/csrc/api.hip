@@ -55,6 +55,8 @@ struct css_ctx {
     bool split = true;
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
+    DevBuf pe_frag[2];           // relative-position rows in attention-operand order for segment length pe_frag_T
+    int pe_frag_T[2] = {0, 0};   // ([0] from the float32 table, [1] from the split-f16 one; encoder.hip pe_fragments_kernel)
     float* dft_fwd = nullptr;    // [2F][frame_len]
     float* dft_inv_t = nullptr;  // [frame_len][KIp]
 
@@ -445,6 +447,8 @@ int css_destroy(css_handle_t h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->wsplit) hipFree(h->wsplit);
     if (h->dft_split) hipFree(h->dft_split);
+    for (auto& b : h->pe_frag)
+        if (b.p) hipFree(b.p);
     if (h->dft_fwd) hipFree(h->dft_fwd);
     if (h->dft_inv_t) hipFree(h->dft_inv_t);
     for (auto& e : h->ev)
@@ -629,7 +633,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
         // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
         gemm(h, lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D), st);
-        launch_relpos_attention(qkv, WS(W.pe_k), cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
+        launch_relpos_attention(qkv, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
         {
             GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;
@@ -678,6 +682,14 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
 // (see css_ctx::lanes) unless the per-launch GEMM profile is on, which needs one ordered stream.
 static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
     const int L = h->d.num_blocks;
+    const int sp = h->split ? 1 : 0;
+    if (h->pe_frag_T[sp] != io.T) {   // the attention kernel's position operands depend on the segment length only
+        int rc = ensure(h, h->pe_frag[sp], (size_t)pe_fragment_tiles(io.T) * 2048 * sizeof(float));
+        if (rc) return rc;
+        launch_pe_fragments(sp ? h->wsplit + (h->w.pe_k - h->blob) : h->w.pe_k, (float*)h->pe_frag[sp].p, io.T, h->d.maxlen,
+                            sp, h->stream);
+        h->pe_frag_T[sp] = io.T;
+    }
     if (h->lanes < 2 || h->profile_gemm || nb < 4 * h->lanes) return masknet_lane(h, io, s0, nb, 0, -1, L + 1);
     const int nl = h->lanes, per = (nb + nl - 1) / nl;   // lane l takes segments [l * per, min((l + 1) * per, nb))
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));    // everything the estimator reads is ordered before this

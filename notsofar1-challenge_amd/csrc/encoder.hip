@@ -447,12 +447,12 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         }                                                                                         \
     }
     const int rel0 = i0 - (T - 1);
-    auto pe_row = [&](int rt) {
-        int prow = rel0 + rt * 32 + c;
-        prow = max(-maxlen, min(prow, maxlen - 1)) + maxlen;  // clamp_ of conformer.py:24
-        return pe + (int64_t)prow * DK;
-    };
+    // Offset tile rt of query tile qt holds the position rows 32 (qt + rt) - (T - 1) + c, c = 0..31: a function of
+    // qt + rt only.  `pe` is the fragment-major table pe_fragments_kernel builds for this T: tile m, chunk ch, lane l
+    // at float4 index (8 m + ch) 64 + l, so an operand load is 1 KiB contiguous instead of 32 rows x 32 bytes.
+    auto pe_tile = [&](int rt) { return pe + ((int64_t)(qt + rt) * 8 * 64 + lane) * 4; };
     auto k_row = [&](int jt) { return kb + (int64_t)min(jt * 32 + c, T - 1) * ld; };
+    (void)rel0; (void)maxlen;
 
     // ---- position term R^T[r][i] = pe[rel0 + r] . q_i (offset tiles, descending) interleaved with the
     //      content term S^T[j][i] = k_j . q_i (key tiles, ascending); skew B[i][j] = R[i][i - j - rel0]
@@ -466,18 +466,31 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // the wave wait for a tile one step after requesting it, and with one wave per SIMD the L2 latency of every one
     // of the 2 NJT + 1 tiles was exposed).
     constexpr int NS = 2 * NJT + 1;
-    auto step_row = [&](int s_) {
-        if (s_ < 3) return pe_row(RT0 - s_);
+    // step s_ (a compile-time constant wherever it is used): offset tile (first) or key tile (second), -1 = not that kind
+    auto step_rt = [](int s_) {
+        if (s_ < 3) return RT0 - s_;
         const int u_ = s_ - 3;
-        if (u_ < 2 * (NJT - 2)) return (u_ & 1) ? pe_row(RT0 - 3 - (u_ >> 1)) : k_row(u_ >> 1);
-        return k_row(NJT - 2 + (u_ - 2 * (NJT - 2)));
+        return (u_ < 2 * (NJT - 2) && (u_ & 1)) ? RT0 - 3 - (u_ >> 1) : -1;
     };
+    auto step_jt = [](int s_) {
+        const int u_ = s_ - 3;
+        return u_ < 2 * (NJT - 2) ? (u_ >> 1) : NJT - 2 + (u_ - 2 * (NJT - 2));
+    };
+#define CSS_ATT_LOAD_STEP(dst, s_)                                                                         \
+    {                                                                                                      \
+        if (step_rt(s_) >= 0) {                                                                            \
+            const float4* pt_ = reinterpret_cast<const float4*>(pe_tile(step_rt(s_)));                     \
+            _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) dst[ch] = pt_[ch * 64];                       \
+        } else {                                                                                           \
+            CSS_ATT_LOAD8(dst, k_row(step_jt(s_)))                                                         \
+        }                                                                                                  \
+    }
     float4 tb[3][8];
     f32x16 S[NJT];
     int step = 0;
 #define CSS_ATT_STEP(acc)                                                                                  \
     {                                                                                                      \
-        if (step + 2 < NS) { CSS_ATT_LOAD8(tb[(step + 2) % 3], step_row(min(step + 2, NS - 1))) }          \
+        if (step + 2 < NS) { CSS_ATT_LOAD_STEP(tb[(step + 2) % 3], min(step + 2, NS - 1)) }                \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the MFMAs (the scheduler sinks it) */ \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                       \
         CSS_ATT_MFMA32(acc, tb[step % 3])                                                                  \
@@ -490,8 +503,8 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
             lds[c * LDR + slot_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];             \
     }
-    CSS_ATT_LOAD8(tb[0], step_row(0))
-    CSS_ATT_LOAD8(tb[1], step_row(1))
+    CSS_ATT_LOAD_STEP(tb[0], 0)
+    CSS_ATT_LOAD_STEP(tb[1], 1)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int rt = RT0 - u;
@@ -612,15 +625,36 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     }
 }
 
-void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
+// Position rows in the order the attention kernel's MFMA operands want them (see pe_tile there): tile m holds rows
+// 32 m - (T - 1) + c of the relative-position table (clamped to [-maxlen, maxlen - 1] as conformer.py:24 clamps them),
+// float4 index (8 m + ch) 64 + l = the 16 bytes lane l = c + 32 h reads for chunk ch of row c.  `pe` is the table as the
+// kernel used to read it row by row: float32 rows (split = 0) or split-f16 rows (split = 1), d_k = 64.
+__global__ __launch_bounds__(256) void pe_fragments_kernel(const float* __restrict__ pe, float* __restrict__ frag, int T,
+                                                           int maxlen, int ntiles, int split) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles * 8 * 64) return;
+    const int lane = i & 63, ch = (i >> 6) & 7, m = i >> 9;
+    const int c = lane & 31, h = lane >> 5;
+    int prow = 32 * m - (T - 1) + c;
+    prow = max(-maxlen, min(prow, maxlen - 1)) + maxlen;
+    const int off = (split ? ((ch >> 2) * 32 + ((ch >> 1) & 1) * 8 + (ch & 1) * 16) : 8 * ch) + 4 * h;
+    reinterpret_cast<float4*>(frag)[i] = *reinterpret_cast<const float4*>(pe + (int64_t)prow * 64 + off);
+}
+
+void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int split, hipStream_t s) {
+    const int ntiles = pe_fragment_tiles(T);
+    hipLaunchKernelGGL(pe_fragments_kernel, dim3((ntiles * 8 * 64 + 255) / 256), dim3(256), 0, s, pe, frag, T, maxlen, ntiles, split);
+}
+
+void launch_relpos_attention(const float* qkv, const float* pe_frag, float* ctx, int nseg, int T, int D, int H,
                              int maxlen, int qk_split, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
     const dim3 grid(qtiles, H, nseg), block(64);
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
 #define CSS_ATT_CASE(n)                                                                                                      \
     case n:                                                                                                                  \
-        if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out);  \
-        else hipLaunchKernelGGL((relpos_attn_kernel<n, false>), grid, block, 0, s, qkv, pe_k, ctx, T, D, maxlen, split_out);          \
+        if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true>), grid, block, 0, s, qkv, pe_frag, ctx, T, D, maxlen, split_out);  \
+        else hipLaunchKernelGGL((relpos_attn_kernel<n, false>), grid, block, 0, s, qkv, pe_frag, ctx, T, D, maxlen, split_out);          \
         break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)

@@ -72,9 +72,13 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
                         const float* ln2_w, const float* ln2_b, float* z, float* z_split, int nseg, int T,
                         int D, int taps, hipStream_t s);
 // relative-position multi-head attention: qkv [tokens][3D] -> ctx [tokens][D] (float32, or split-f16 rows).
-// qk_split: the q and k columns of qkv and the rows of pe_k are split-f16 (scores on the f16 matrix cores with
-// float32-grade accuracy); v is float32 either way.
-void launch_relpos_attention(const float* qkv, const float* pe_k, float* ctx, int nseg, int T, int D, int H,
+// qk_split: the q and k columns of qkv and the position rows are split-f16 (scores on the f16 matrix cores with
+// float32-grade accuracy); v is float32 either way.  pe_frag: the relative-position table rearranged for this T by
+// launch_pe_fragments from the row-major table of the same arithmetic (float32 or split-f16 rows of d_k = 64):
+// pe_fragment_tiles(T) tiles of 32 rows x 64, 2048 floats each.
+inline int pe_fragment_tiles(int T) { return 2 * ((T + 31) / 32); }
+void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int split, hipStream_t s);
+void launch_relpos_attention(const float* qkv, const float* pe_frag, float* ctx, int nseg, int T, int D, int H,
                              int maxlen, int qk_split, int split_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
