@@ -68,7 +68,7 @@ struct css_ctx {
     int64_t n_pad = 0, T_ld = 0;
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host;
-    DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
+    DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, qkf, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
         act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
@@ -80,7 +80,7 @@ struct css_ctx {
     int lanes = 2;
     hipStream_t lane_stream[MAX_LANES] = {};   // [0] unused
     hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
-    DevBuf lfeat[MAX_LANES], lhx[MAX_LANES], lhu[MAX_LANES], lht[MAX_LANES], lqkv[MAX_LANES], lctx[MAX_LANES];   // [0] unused
+    DevBuf lfeat[MAX_LANES], lhx[MAX_LANES], lhu[MAX_LANES], lht[MAX_LANES], lqkv[MAX_LANES], lqkf[MAX_LANES], lctx[MAX_LANES];   // [0] unused
     int64_t last_batch_tokens = 0;
     const float* pcm_src = nullptr;  // sample-major PCM on the device for the current session
 
@@ -287,6 +287,8 @@ int ensure_activations(css_ctx* h, int64_t nb, int T) {
     if ((rc = ensure(h, h->hu, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
     if ((rc = ensure(h, h->ht, (size_t)Mb * FF * sizeof(float))) != CSS_OK) return rc;
     if ((rc = ensure(h, h->qkv, (size_t)Mb * 3 * D * sizeof(float))) != CSS_OK) return rc;
+    // q and k in the attention kernel's operand order (split mode); zeroed once: rows past T of a last tile are never written
+    if ((rc = ensure(h, h->qkf, (size_t)qk_fragment_floats(nb, T, h->d.attention_heads) * sizeof(float), true)) != CSS_OK) return rc;
     if ((rc = ensure(h, h->ctxb, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
     for (int l = 1; l < h->lanes; ++l) {   // lanes 1.. hold at most ceil(nb / lanes) segments
         const int64_t M2 = ((nb + h->lanes - 1) / h->lanes) * T;
@@ -295,6 +297,7 @@ int ensure_activations(css_ctx* h, int64_t nb, int T) {
         if ((rc = ensure(h, h->lhu[l], (size_t)M2 * D * sizeof(float))) != CSS_OK) return rc;
         if ((rc = ensure(h, h->lht[l], (size_t)M2 * FF * sizeof(float))) != CSS_OK) return rc;
         if ((rc = ensure(h, h->lqkv[l], (size_t)M2 * 3 * D * sizeof(float))) != CSS_OK) return rc;
+        if ((rc = ensure(h, h->lqkf[l], (size_t)qk_fragment_floats(M2 / T, T, h->d.attention_heads) * sizeof(float), true)) != CSS_OK) return rc;
         if ((rc = ensure(h, h->lctx[l], (size_t)M2 * D * sizeof(float))) != CSS_OK) return rc;
     }
     return CSS_OK;
@@ -431,12 +434,12 @@ int css_destroy(css_handle_t h) {
     if (!h) return CSS_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->ctxb, &h->masks,
+    DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->qkf, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
                       &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
                       &h->in16, &h->pcm_f, &h->enc};
     for (int l = 1; l < css_ctx::MAX_LANES; ++l) {
-        for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lctx[l]})
+        for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lqkf[l], &h->lctx[l]})
             if (b->p) hipFree(b->p);
         if (h->lane_stream[l]) { hipStreamSynchronize(h->lane_stream[l]); hipStreamDestroy(h->lane_stream[l]); }
         if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]);
@@ -596,6 +599,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     hipStream_t st = lane ? h->lane_stream[lane] : h->stream;
     float* feat = (float*)(lane ? h->lfeat[lane].p : h->feat.p); float* x = (float*)(lane ? h->lhx[lane].p : h->hx.p);
     float* u = (float*)(lane ? h->lhu[lane].p : h->hu.p); float* t1 = (float*)(lane ? h->lht[lane].p : h->ht.p);
+    float* qkf = (float*)(lane ? h->lqkf[lane].p : h->qkf.p);
     float* qkv = (float*)(lane ? h->lqkv[lane].p : h->qkv.p); float* cb = (float*)(lane ? h->lctx[lane].p : h->ctxb.p);
     const Weights& W = h->w;
     // Linear layers: split-f16 operands (h->split) -- every producer of a GEMM input writes the split format
@@ -632,8 +636,12 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         // self attention (conformer.py:65-92)
         launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
         // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
-        gemm(h, lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D), st);
-        launch_relpos_attention(qkv, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
+        {
+            GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D);
+            if (sp) { g.frag_out = qkf; g.frag_D = D; g.frag_T = T; g.frag_heads = d.attention_heads; g.frag_invT = 1.0f / T; }
+            gemm(h, g, st);
+        }
+        launch_relpos_attention(qkv, sp ? qkf : nullptr, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
         {
             GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;

@@ -393,8 +393,9 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
 // offsets a 32-query tile can see (never the reference's [T,T,64] gather), staged through LDS to
 // apply the per-row skew B[i][j] = R[i][i - j - r0].
 // ------------------------------------------------------------------------------------------------
-template <int NJT, bool QKS>
-__global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
+template <int NJT, bool QKS, bool FRAG>
+__global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
+                                                         const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen,
                                                          int split_out) {
     constexpr int DK = 64;
@@ -420,7 +421,17 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
 #define CSS_ATT_LOAD8(dst, rowptr)                                                                      \
     _Pragma("unroll") for (int ch = 0; ch < 8; ++ch)                                                    \
         dst[ch] = *reinterpret_cast<const float4*>((rowptr) + (QKS ? ((ch >> 2) * 32 + ((ch >> 1) & 1) * 8 + (ch & 1) * 16) : 8 * ch) + 4 * h);
-    CSS_ATT_LOAD8(q, qb + (int64_t)iq * ld)
+    // FRAG: q and k tiles arrive in operand order from the QKV GEMM (kernels.hpp qk_fragment_floats): like the position
+    // tiles, 1 KiB contiguous per load.  Rows past T of the last tile were never written (zero or stale, finite): those
+    // keys are masked and those query columns never stored.
+    const float4* qkt = reinterpret_cast<const float4*>(qkf) +
+                        ((int64_t)(seg * (int)gridDim.y + head) * NJT) * (2 * 8 * 64) + lane;
+    if constexpr (FRAG) {
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) q[ch] = qkt[(qt * 2 + 0) * 512 + ch * 64];
+    } else {
+        CSS_ATT_LOAD8(q, qb + (int64_t)iq * ld)
+    }
 
     // Operand tiles are prefetched a whole tile (8 x 16 B per lane) ahead of the 32 MFMAs that consume
     // them: the compiler's own schedule kept one load in flight (vmcnt(1) every 4 MFMAs) and exposed the
@@ -481,6 +492,8 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         if (step_rt(s_) >= 0) {                                                                            \
             const float4* pt_ = reinterpret_cast<const float4*>(pe_tile(step_rt(s_)));                     \
             _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) dst[ch] = pt_[ch * 64];                       \
+        } else if constexpr (FRAG) {                                                                       \
+            _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) dst[ch] = qkt[(step_jt(s_) * 2 + 1) * 512 + ch * 64]; \
         } else {                                                                                           \
             CSS_ATT_LOAD8(dst, k_row(step_jt(s_)))                                                         \
         }                                                                                                  \
@@ -646,15 +659,16 @@ void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int sp
     hipLaunchKernelGGL(pe_fragments_kernel, dim3((ntiles * 8 * 64 + 255) / 256), dim3(256), 0, s, pe, frag, T, maxlen, ntiles, split);
 }
 
-void launch_relpos_attention(const float* qkv, const float* pe_frag, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, int qk_split, int split_out, hipStream_t s) {
+void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
+                             int H, int maxlen, int qk_split, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
     const dim3 grid(qtiles, H, nseg), block(64);
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
 #define CSS_ATT_CASE(n)                                                                                                      \
     case n:                                                                                                                  \
-        if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true>), grid, block, 0, s, qkv, pe_frag, ctx, T, D, maxlen, split_out);  \
-        else hipLaunchKernelGGL((relpos_attn_kernel<n, false>), grid, block, 0, s, qkv, pe_frag, ctx, T, D, maxlen, split_out);          \
+        if (qk_split && qk_frag) hipLaunchKernelGGL((relpos_attn_kernel<n, true, true>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);  \
+        else if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);  \
+        else hipLaunchKernelGGL((relpos_attn_kernel<n, false, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);          \
         break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)

@@ -194,4 +194,40 @@ __device__ __forceinline__ void emit_tile_pre_wide(const f32x16& acc, const Tile
     }
 }
 
+// Epilogue of a 32 x 32 tile of the attention's q / k projections (bias only) in the ATTENTION kernel's operand order
+// (encoder.hip): the tile is one 32-k group `grp` of one head; token m = segment * T + j lands in row tile j / 32, lane
+// (j % 32) + 32 h', chunk 4 grp + 2 sub + part (part 0 = hi halves, 1 = lo halves of k = 32 grp + 16 sub + 8 h' .. + 7).
+// Through the wave-private patch as above; a lane handles one token row: two (sub, h') items, each 8 values -> one
+// 16-byte hi store and one 16-byte lo store; consecutive lanes = consecutive tokens = consecutive 16-byte pieces.
+__device__ __forceinline__ void emit_tile_frag(const f32x16& acc, float bn, int mb0, int h, int c, int M, float* __restrict__ frag,
+                                               int T, float invT, int heads, int head, int which, int grp,
+                                               float* __restrict__ patch) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_LD + c] = acc[r] + bn;
+    const int m = mb0 + c;
+    if (m >= M) return;
+    const int seg = (int)(((float)m + 0.5f) * invT);   // exact for m < 2^16, T <= 256
+    const int j = m - seg * T;
+    const int njt = (T + 31) >> 5;
+    float4* dst = reinterpret_cast<float4*>(frag) +
+                  ((((int64_t)(seg * heads + head) * njt + (j >> 5)) * 2 + which) * 8 + grp * 4) * 64 + (j & 31);
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int sub = pass, hp = h;   // this lane's items: (sub = 0, h' = h) and (sub = 1, h' = h)
+        const float* src = patch + c * LDS_LD + 16 * sub + 8 * hp;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        f16x8v hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 x, y;
+            split_f16(v[e], x, y);
+            hi[e] = x; lo[e] = y;
+        }
+        dst[(sub * 2 + 0) * 64 + 32 * hp] = __builtin_bit_cast(float4, hi);
+        dst[(sub * 2 + 1) * 64 + 32 * hp] = __builtin_bit_cast(float4, lo);
+    }
+}
+
 }  // namespace css

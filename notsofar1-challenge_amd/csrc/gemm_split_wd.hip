@@ -205,10 +205,13 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     float* patch = lds + wave * (32 * LDS_LD);
     const int mtile = m0 + wm * (BM / WMV), ntile = n0 + wn * 32;
     const bool wide = early && !g.narrow_epilogue;
+    const bool fragq = g.frag_out != nullptr && ntile < 2 * g.frag_D;   // wave-uniform: a wave owns 32 columns
 #define CSS_E1(t, ...)                                                                                      \
     if constexpr (t < TM) {                                                                                 \
         acc##t += cor##t * SPLIT_LO_INV;                                                                    \
-        if (wide) emit_tile_pre_wide(acc##t, pre##t, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, res != nullptr, alpha, so, \
+        if (fragq) emit_tile_frag(acc##t, pre##t.bn, mtile + 32 * t, h, c, M, g.frag_out, g.frag_T, g.frag_invT, g.frag_heads, \
+                                  (ntile % g.frag_D) >> 6, ntile / g.frag_D, (ntile >> 5) & 1, patch);          \
+        else if (wide) emit_tile_pre_wide(acc##t, pre##t, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, res != nullptr, alpha, so, \
                                      g.nt_store, patch);                                                    \
         else if (early) emit_tile_pre(acc##t, pre##t, mrow + 32 * t, ncol, M, N, C, ldc, act, res != nullptr, alpha, so, g.nt_store); \
         else emit_tile(acc##t, mrow + 32 * t, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);  \

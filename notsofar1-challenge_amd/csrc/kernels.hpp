@@ -36,6 +36,12 @@ struct GemmArgs {
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
     int nt_store;   // epilogue stores bypass the caches (nontemporal)
+    // weights-direct kernel only: columns n < 2 * frag_D (the q and k projections of the attention, D = heads * 64) leave
+    // in the attention kernel's operand order instead of row-major C (encoder.hip qk fragment layout); rows are tokens
+    // of segments of frag_T frames, frag_invT = 1.0f / frag_T
+    float* frag_out;
+    int frag_D, frag_T, frag_heads;
+    float frag_invT;
     int tile_rows;         // weights-direct kernel: 0 = choose, else 64 / 96 / 128 (8 waves) / 4 (128 rows, 4 waves)
     int narrow_epilogue;   // tools: keep the 4-byte-per-lane epilogue of the weights-direct kernel (A/B timing)
 };
@@ -78,8 +84,12 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
 // pe_fragment_tiles(T) tiles of 32 rows x 64, 2048 floats each.
 inline int pe_fragment_tiles(int T) { return 2 * ((T + 31) / 32); }
 void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int split, hipStream_t s);
-void launch_relpos_attention(const float* qkv, const float* pe_frag, float* ctx, int nseg, int T, int D, int H,
-                             int maxlen, int qk_split, int split_out, hipStream_t s);
+// qk_frag (split mode only, may be null): q and k in operand order, written by the QKV GEMM (GemmArgs::frag_out):
+// float4 index ((((seg * H + head) * ceil(T / 32) + tile) * 2 + which) * 8 + chunk) * 64 + lane, which = 0 q / 1 k;
+// qk_fragment_floats(nseg, T, H) floats.  The q and k columns of qkv are then not read.
+inline int64_t qk_fragment_floats(int64_t nseg, int T, int H) { return nseg * H * ((T + 31) / 32) * 2 * 8 * 64 * 4; }
+void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
+                             int H, int maxlen, int qk_split, int split_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add

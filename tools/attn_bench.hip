@@ -18,10 +18,10 @@ int main(int argc, char** argv) {
     // qk_split = 0: q, k, pe read as float32 (exact mode); 1: the same bits interpreted as split-f16 operands --
     // timing only, the values are then not a split of anything
     for (int qks = 0; qks < 2; ++qks) {
-        for (int i = 0; i < 3; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
+        for (int i = 0; i < 3; ++i) launch_relpos_attention(qkv, qks ? qkv : nullptr, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
         hipEventRecord(e0, st);
         const int it = 50;
-        for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
+        for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, qks ? qkv : nullptr, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<float> o(64); hipMemcpy(o.data(), ctx + 12345, 64 * 4, hipMemcpyDeviceToHost);
