@@ -72,12 +72,12 @@ struct css_ctx {
         act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
-    // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two chains drift out of
-    // phase and fill each other's bubbles (measured: 6.9 -> 6.4 ms per 60 s meeting).  Results do not change: every
+    // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two or three chains drift out of
+    // phase and fill each other's bubbles (measured: 6.9 -> 6.4 ms per 60 s meeting with two).  Results do not change: every
     // kernel is batch invariant.  CSS_MASKNET_LANES=1 in the environment at css_create turns it off.
-    // (CSS_MASKNET_LANES=n, 1..4, default 2; lane 0 is `stream` with the buffers above)
+    // (CSS_MASKNET_LANES=n, 1..4, default 3; lane 0 is `stream` with the buffers above)
     static constexpr int MAX_LANES = 4;
-    int lanes = 2;
+    int lanes = 3;
     hipStream_t lane_stream[MAX_LANES] = {};   // [0] unused
     hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     DevBuf lfeat[MAX_LANES], lhx[MAX_LANES], lhu[MAX_LANES], lht[MAX_LANES], lqkv[MAX_LANES], lqkf[MAX_LANES], lctx[MAX_LANES];   // [0] unused
