@@ -101,7 +101,12 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
 #define CSS_GLOAD(st, k0) CSS_I4(CSS_G1, st, k0)
 #define CSS_L1(i, st, buf) \
     if constexpr (i < NLA) *reinterpret_cast<float4*>(lds + (buf) * STAGE + (lr + i * LROWS) * LDS_LD + lc) = stg##st##_##i;
+#ifdef CSS_ABL_NO_LSTORE   /* ablation (tools only): one LDS store per step keeps the loads alive */
+#define CSS_LSTORE(st, buf) { float4 k_ = stg##st##_0; if constexpr (NLA > 1) { k_.x += stg##st##_1.x; } if constexpr (NLA > 2) { k_.y += stg##st##_2.x + stg##st##_3.x; } \
+        *reinterpret_cast<float4*>(lds + (buf) * STAGE + lr * LDS_LD + lc) = k_; }
+#else
 #define CSS_LSTORE(st, buf) CSS_I4(CSS_L1, st, buf)
+#endif
 #define CSS_W1(i, st, q_) wr##st##_##i = (q_)[i * 64];
 #define CSS_WLOAD(st, kt_) { const float4* q_ = pw + (int64_t)(kt_) * 4 * 64; CSS_I4(CSS_W1, st, q_) }
     const float* as0 = lds + (wm * (BM / WMV) + c) * LDS_LD + 4 * h;
@@ -109,11 +114,34 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
 #define CSS_A1(o, st, buf)                                                                                    \
     if constexpr ((o & 3) < TM) {                                                                             \
         ah##st##_##o = CSS_LDH(as0 + (buf) * STAGE + (o & 3) * 32 * LDS_LD + (o >> 2) * 8);                   \
-        al##st##_##o = CSS_LDH(as0 + (buf) * STAGE + (o & 3) * 32 * LDS_LD + (o >> 2) * 8 + 16);              \
+        CSS_A1_LO(o, st, buf)                                                                                 \
     }
+#ifdef CSS_ABL_HALF_AREAD   /* ablation (tools only): half of the LDS operand reads (lo = hi) */
+#define CSS_A1_LO(o, st, buf) al##st##_##o = ah##st##_##o;
+#else
+#define CSS_A1_LO(o, st, buf) al##st##_##o = CSS_LDH(as0 + (buf) * STAGE + (o & 3) * 32 * LDS_LD + (o >> 2) * 8 + 16);
+#endif
 #define CSS_AREAD(st, buf) CSS_I8(CSS_A1, st, buf)
+#ifdef CSS_ABL_NO_AREAD   /* ablation (tools only): operands are read once, before the loop */
+#define CSS_AREAD_LOOP(st, buf)
+#else
+#define CSS_AREAD_LOOP(st, buf) CSS_AREAD(st, buf)
+#endif
     // the 6 * TM MFMAs of one slab; each accumulator is touched every TM-th MFMA
 #define CSS_M1(t, st, kk, part, w_, dst) if constexpr (t < TM) CSS_MFMA16(part##st##_##kk##t, w_, dst##t);
+#ifdef CSS_ABL_MFMA_THIRD   /* ablation (tools only): the hi*hi MFMAs alone, a third of the matrix work */
+#define CSS_SLAB_COR(st, o0, o1, o2, o3) cor0[0] += wl_[0];
+#else
+#define CSS_SLAB_COR(st, o0, o1, o2, o3)                                                              \
+        if constexpr (0 < TM) CSS_MFMA16(ah##st##_##o0, wl_, cor0);                                   \
+        if constexpr (1 < TM) CSS_MFMA16(ah##st##_##o1, wl_, cor1);                                   \
+        if constexpr (2 < TM) CSS_MFMA16(ah##st##_##o2, wl_, cor2);                                   \
+        if constexpr (3 < TM) CSS_MFMA16(ah##st##_##o3, wl_, cor3);                                   \
+        if constexpr (0 < TM) CSS_MFMA16(al##st##_##o0, wh_, cor0);                                   \
+        if constexpr (1 < TM) CSS_MFMA16(al##st##_##o1, wh_, cor1);                                   \
+        if constexpr (2 < TM) CSS_MFMA16(al##st##_##o2, wh_, cor2);                                   \
+        if constexpr (3 < TM) CSS_MFMA16(al##st##_##o3, wh_, cor3);
+#endif
 #define CSS_SLAB_KK(st, kk, o0, o1, o2, o3, wi0, wi1)                                                \
     {                                                                                                 \
         const f16x8 wh_ = __builtin_bit_cast(f16x8, wr##st##_##wi0);                                  \
@@ -122,14 +150,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
         if constexpr (1 < TM) CSS_MFMA16(ah##st##_##o1, wh_, acc1);                                   \
         if constexpr (2 < TM) CSS_MFMA16(ah##st##_##o2, wh_, acc2);                                   \
         if constexpr (3 < TM) CSS_MFMA16(ah##st##_##o3, wh_, acc3);                                   \
-        if constexpr (0 < TM) CSS_MFMA16(ah##st##_##o0, wl_, cor0);                                   \
-        if constexpr (1 < TM) CSS_MFMA16(ah##st##_##o1, wl_, cor1);                                   \
-        if constexpr (2 < TM) CSS_MFMA16(ah##st##_##o2, wl_, cor2);                                   \
-        if constexpr (3 < TM) CSS_MFMA16(ah##st##_##o3, wl_, cor3);                                   \
-        if constexpr (0 < TM) CSS_MFMA16(al##st##_##o0, wh_, cor0);                                   \
-        if constexpr (1 < TM) CSS_MFMA16(al##st##_##o1, wh_, cor1);                                   \
-        if constexpr (2 < TM) CSS_MFMA16(al##st##_##o2, wh_, cor2);                                   \
-        if constexpr (3 < TM) CSS_MFMA16(al##st##_##o3, wh_, cor3);                                   \
+        CSS_SLAB_COR(st, o0, o1, o2, o3)                                                                  \
     }
 #define CSS_SLAB(st) CSS_SLAB_KK(st, 0, 0, 1, 2, 3, 0, 1) CSS_SLAB_KK(st, 1, 4, 5, 6, 7, 2, 3)
     // issue order inside a step: 2*TM x {MFMA, 2 LDS reads, 1 global load}, NLA x {MFMA, 1 LDS store}, the rest MFMAs
@@ -146,6 +167,11 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM - 2 * TM - NLA, 0); \
     __builtin_amdgcn_sched_barrier(0);   /* the barrier stays behind the last MFMA: the pipe drains while waiting */
 
+#ifdef CSS_ABL_NO_BARRIER   /* ablation (tools only; results are then wrong) */
+#define CSS_LOOP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CSS_LOOP_BARRIER() __syncthreads()
+#endif
     // epilogue operands (column bias, residual) are requested now and used after the K loop (gemm_common.hpp)
     const int mrow = m0 + wm * (BM / WMV) + 4 * h, ncol = n0 + wn * 32 + c;
     TilePre pre0, pre1, pre2, pre3;
@@ -165,25 +191,28 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     CSS_LSTORE(1, 1)
     __syncthreads();
     CSS_AREAD(0, 0)
+#ifdef CSS_ABL_NO_AREAD
+    CSS_AREAD(1, 0)
+#endif
     __syncthreads();   // every wave holds slab 0 in registers before slab 2 overwrites LDS[0]
     // invariant at the top of step kt (even): operand set 0 = slab kt, LDS[1] = slab kt + 1, stage 0 = slab kt + 2,
     // weight set 0 = weights kt
     for (int kt = 0;;) {
         CSS_GLOAD(1, CSS_KOFF(kt + 3))
         CSS_WLOAD(1, CSS_KT(kt + 1))
-        CSS_AREAD(1, 1)
+        CSS_AREAD_LOOP(1, 1)
         CSS_SLAB(0)
         CSS_LSTORE(0, 0)
         CSS_INTERLEAVE()
-        __syncthreads();
+        CSS_LOOP_BARRIER();
         if (++kt >= nk) break;
         CSS_GLOAD(0, CSS_KOFF(kt + 3))
         CSS_WLOAD(0, CSS_KT(kt + 1))
-        CSS_AREAD(0, 0)
+        CSS_AREAD_LOOP(0, 0)
         CSS_SLAB(1)
         CSS_LSTORE(1, 1)
         CSS_INTERLEAVE()
-        __syncthreads();
+        CSS_LOOP_BARRIER();
         if (++kt >= nk) break;
     }
 
@@ -219,10 +248,14 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     CSS_I4(CSS_E1, 0)
 #undef CSS_E1
 #undef CSS_AREAD
+#undef CSS_AREAD_LOOP
+#undef CSS_LOOP_BARRIER
 #undef CSS_A1
+#undef CSS_A1_LO
 #undef CSS_INTERLEAVE
 #undef CSS_SLAB
 #undef CSS_SLAB_KK
+#undef CSS_SLAB_COR
 #undef CSS_M1
 #undef CSS_KOFF
 #undef CSS_KT
