@@ -38,7 +38,7 @@ constexpr int WD_BM = 128;
 // of slab kt (sched_group_barrier pattern): an MFMA leaves ~5 issue slots free while it runs, and with one or two
 // waves per SIMD nothing else would hide those instructions.
 template <int BM, int WMV>
-__global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 ? 2 : 4) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 ? 2 : 3) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WMV * 256;
     constexpr int TM = BM / 32 / WMV;           // 32-row tiles per wave
     constexpr int LROWS = THREADS / 8;          // rows per staging pass
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     const float4* __restrict__ pw = reinterpret_cast<const float4*>(g.B) + (int64_t)jt * (g.K / 16) * 2 * 64 + lane;
 
     float4 stg0_0, stg0_1, stg0_2, stg0_3, stg1_0, stg1_1, stg1_2, stg1_3;   // activation staging, two register stages
-    float4 wr0_0, wr0_1, wr0_2, wr0_3, wr1_0, wr1_1, wr1_2, wr1_3;           // weight operands of two K slabs
+    float4 wr0_0, wr0_1, wr0_2, wr0_3, wr1_0, wr1_1, wr1_2, wr1_3, wr2_0, wr2_1, wr2_2, wr2_3;   // weight operands of three K slabs
     // A operands of two K slabs: index = row tile + 4 * kk
     f16x8 ah0_0, ah0_1, ah0_2, ah0_3, ah0_4, ah0_5, ah0_6, ah0_7, al0_0, al0_1, al0_2, al0_3, al0_4, al0_5, al0_6, al0_7;
     f16x8 ah1_0, ah1_1, ah1_2, ah1_3, ah1_4, ah1_5, ah1_6, ah1_7, al1_0, al1_1, al1_2, al1_3, al1_4, al1_5, al1_6, al1_7;
@@ -142,17 +142,17 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
         if constexpr (2 < TM) CSS_MFMA16(al##st##_##o2, wh_, cor2);                                   \
         if constexpr (3 < TM) CSS_MFMA16(al##st##_##o3, wh_, cor3);
 #endif
-#define CSS_SLAB_KK(st, kk, o0, o1, o2, o3, wi0, wi1)                                                \
+#define CSS_SLAB_KK(st, ws, kk, o0, o1, o2, o3, wi0, wi1)                                                \
     {                                                                                                 \
-        const f16x8 wh_ = __builtin_bit_cast(f16x8, wr##st##_##wi0);                                  \
-        const f16x8 wl_ = __builtin_bit_cast(f16x8, wr##st##_##wi1);                                  \
+        const f16x8 wh_ = __builtin_bit_cast(f16x8, wr##ws##_##wi0);                                  \
+        const f16x8 wl_ = __builtin_bit_cast(f16x8, wr##ws##_##wi1);                                  \
         if constexpr (0 < TM) CSS_MFMA16(ah##st##_##o0, wh_, acc0);                                   \
         if constexpr (1 < TM) CSS_MFMA16(ah##st##_##o1, wh_, acc1);                                   \
         if constexpr (2 < TM) CSS_MFMA16(ah##st##_##o2, wh_, acc2);                                   \
         if constexpr (3 < TM) CSS_MFMA16(ah##st##_##o3, wh_, acc3);                                   \
         CSS_SLAB_COR(st, o0, o1, o2, o3)                                                                  \
     }
-#define CSS_SLAB(st) CSS_SLAB_KK(st, 0, 0, 1, 2, 3, 0, 1) CSS_SLAB_KK(st, 1, 4, 5, 6, 7, 2, 3)
+#define CSS_SLAB(st, ws) CSS_SLAB_KK(st, ws, 0, 0, 1, 2, 3, 0, 1) CSS_SLAB_KK(st, ws, 1, 4, 5, 6, 7, 2, 3)
     // issue order inside a step: 2*TM x {MFMA, 2 LDS reads, 1 global load}, NLA x {MFMA, 1 LDS store}, the rest MFMAs
 #define CSS_INTERLEAVE()                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2 * TM; ++i_) {                \
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
 
     CSS_GLOAD(0, 0)
     CSS_WLOAD(0, 0)
+    CSS_WLOAD(1, CSS_KT(1))
     CSS_GLOAD(1, CSS_KOFF(1))
     CSS_LSTORE(0, 0)
     CSS_GLOAD(0, CSS_KOFF(2))
@@ -195,26 +196,29 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     CSS_AREAD(1, 0)
 #endif
     __syncthreads();   // every wave holds slab 0 in registers before slab 2 overwrites LDS[0]
-    // invariant at the top of step kt (even): operand set 0 = slab kt, LDS[1] = slab kt + 1, stage 0 = slab kt + 2,
-    // weight set 0 = weights kt
+    // invariant at the top of step kt: operand set kt % 2 = slab kt, LDS[(kt + 1) % 2] = slab kt + 1, stage kt % 2 =
+    // slab kt + 2, weight sets kt % 3 and (kt + 1) % 3 = weights kt, kt + 1.  The weights are requested TWO slabs ahead
+    // (a third register set): a CU's 8 waves keep 48 KB of operands per slab on the 64 B/clk L1 return path, a load
+    // lands 0.4-0.6 us after it was issued, and with one slab of lead every wave sat at the top of each slab waiting
+    // for its weights while the matrix core idled.  Periods 2 (operands, LDS) and 3 (weights) -> six steps per round.
+#define CSS_STEP(a, an, w, wn)                     \
+        CSS_GLOAD(an, CSS_KOFF(kt + 3))            \
+        CSS_WLOAD(wn, CSS_KT(kt + 2))              \
+        CSS_AREAD_LOOP(an, an)                     \
+        CSS_SLAB(a, w)                             \
+        CSS_LSTORE(a, a)                           \
+        CSS_INTERLEAVE()                           \
+        CSS_LOOP_BARRIER();                        \
+        if (++kt >= nk) break;
     for (int kt = 0;;) {
-        CSS_GLOAD(1, CSS_KOFF(kt + 3))
-        CSS_WLOAD(1, CSS_KT(kt + 1))
-        CSS_AREAD_LOOP(1, 1)
-        CSS_SLAB(0)
-        CSS_LSTORE(0, 0)
-        CSS_INTERLEAVE()
-        CSS_LOOP_BARRIER();
-        if (++kt >= nk) break;
-        CSS_GLOAD(0, CSS_KOFF(kt + 3))
-        CSS_WLOAD(0, CSS_KT(kt + 1))
-        CSS_AREAD_LOOP(0, 0)
-        CSS_SLAB(1)
-        CSS_LSTORE(1, 1)
-        CSS_INTERLEAVE()
-        CSS_LOOP_BARRIER();
-        if (++kt >= nk) break;
+        CSS_STEP(0, 1, 0, 2)
+        CSS_STEP(1, 0, 1, 0)
+        CSS_STEP(0, 1, 2, 1)
+        CSS_STEP(1, 0, 0, 2)
+        CSS_STEP(0, 1, 1, 0)
+        CSS_STEP(1, 0, 2, 1)
     }
+#undef CSS_STEP
 
     const float* bias = g.bias;
     const float* res = g.residual;
