@@ -363,7 +363,10 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
                         const float* dw_wt, const float* dw_b, const float* bn_alpha, const float* bn_beta,
                         const float* ln2_w, const float* ln2_b, float* z, float* z_split, int nseg, int T,
                         int D, int taps, hipStream_t s) {
-    constexpr int RUN = 31;
+#ifndef CSS_CONV_RUN
+#define CSS_CONV_RUN 31   /* output frames per block; 186 = 6 x 31 (tools: -DCSS_CONV_RUN=n for A/B builds) */
+#endif
+    constexpr int RUN = CSS_CONV_RUN;
     if (taps != 33 || (D != 256 && D != 512)) return false;
     const int runs = (T + RUN - 1) / RUN;
     const size_t lds = (size_t)(RUN + 32) * D * sizeof(float);
