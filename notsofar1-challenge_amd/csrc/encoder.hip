@@ -299,7 +299,13 @@ __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __re
             float o[4] = {v[i][j].x * rstd * g.x + be.x, v[i][j].y * rstd * g.y + be.y, v[i][j].z * rstd * g.z + be.z,
                           v[i][j].w * rstd * g.w + be.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (p0 * o[e] + p1) * (1.0f / (1.0f + expf(-(p2 * o[e] + p3))));
+            for (int e = 0; e < 4; ++e) {
+                // GLU gate sigmoid(z) = 1 / (1 + 2^(-z log2 e)) as v_exp_f32 + v_rcp_f32 (1 ulp each; the argument's
+                // rounding adds |z| * 6e-8): the library expf and the IEEE division were 25 of the ~40 instructions this
+                // phase spends per element, and the phase is the kernel's critical path
+                const float z = p2 * o[e] + p3;
+                o[e] = (p0 * o[e] + p1) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+            }
             dst[lane + 64 * j] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
