@@ -193,7 +193,7 @@ def main():
             # float32-grade products on the f16 pipes is the dense f16 peak / 3, and achieved / that ceiling
             # equals executed-MFMA-flops / dense f16 peak (the matrix-core utilisation).
             peak = PEAK_F16_MATRIX_TFLOPS / 3.0
-            kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, 128x128x32 tiles, weights direct)"
+            kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, 64x128x32 tiles, weights direct)"
             extra = {"mfma_executed_tflops": round(3 * achieved, 2), "mfma_dense_peak_tflops": PEAK_F16_MATRIX_TFLOPS,
                      "vs_f32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
         else:
