@@ -233,15 +233,18 @@ void launch_dwconv(const float* z, float* h, const float* dw_wt, const float* dw
 // x_out must not alias x_in: neighbouring runs read each other's input frames.  The LayerNorm of the module that
 // FOLLOWS (ln2_*, z / z_split; optional) is applied to the outgoing rows in the same pass.
 // ------------------------------------------------------------------------------------------------
-template <int NV, int TAPS, int RUN>
-__global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __restrict__ x_in, float* __restrict__ x_out,
+template <int NV, int TAPS, int RUN, int HV>
+__global__ __launch_bounds__(256 * NV * HV) void conv_module_kernel(const float* __restrict__ x_in, float* __restrict__ x_out,
                                                               const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                               const float* __restrict__ pw, const float* __restrict__ wt,
                                                               const float* __restrict__ dwb, const float* __restrict__ alpha,
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ ln2w, const float* __restrict__ ln2b,
                                                               float* __restrict__ z, float* __restrict__ zs, int T, int runs_per_seg) {
-    constexpr int D = 256 * NV, PAD = (TAPS - 1) / 2, ROWS = RUN + TAPS - 1, NW = 4 * NV;
+    // HV thread groups of D threads share a block: phase 1 and the output pass simply have HV times the waves, phase 2
+    // gives group g the output frames g * JH .. g * JH + JH - 1 of the run.  The kernel is a latency chain (54 blocks per
+    // launch on 256 CUs), so the block is made wide, not numerous.
+    constexpr int D = 256 * NV, PAD = (TAPS - 1) / 2, ROWS = RUN + TAPS - 1, NW = 4 * NV * HV, JH = (RUN + HV - 1) / HV;
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [ROWS][D]
     const int seg = blockIdx.x / runs_per_seg, run = blockIdx.x % runs_per_seg;
     const int t0 = run * RUN;
@@ -249,15 +252,15 @@ __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __re
     const float p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3];
     // phase 2's per-channel operands (taps, BatchNorm, the residual values of the run) are requested now, so that
     // their latency runs under phase 1 instead of after the barrier
-    const int ch = threadIdx.x;
+    const int ch = threadIdx.x % D, j0 = (threadIdx.x / D) * JH;   // the group index is wave-uniform (D % 64 == 0)
     float wk[TAPS];
 #pragma clang loop unroll(full)
     for (int k = 0; k < TAPS; ++k) wk[k] = wt[k * D + ch];
     const float bb = dwb[ch], al = alpha[ch], be_ = beta[ch], w2 = pw[4], c2 = pw[5];
     const float* xs = x_in + (int64_t)seg * T * D + ch;
-    float xres[RUN];
+    float xres[JH];
 #pragma clang loop unroll(full)
-    for (int j = 0; j < RUN; ++j) xres[j] = xs[(int64_t)min(t0 + j, T - 1) * D];
+    for (int j = 0; j < JH; ++j) xres[j] = xs[(int64_t)min(t0 + j0 + j, T - 1) * D];
     // ---- phase 1: LayerNorm + GLU of frames t0 - PAD .. t0 + RUN + PAD - 1 (one wave per frame, as layernorm_kernel).
     // A wave owns frames wave, wave + NW, ...; ALL of them are requested before the first is reduced, so the wave
     // pays one memory round trip, not one per frame.
@@ -311,23 +314,23 @@ __global__ __launch_bounds__(256 * NV) void conv_module_kernel(const float* __re
     }
     __syncthreads();
     // ---- phase 2: depthwise conv of this thread's channel over the run (tap order as dwconv_kernel)
-    float acc[RUN];
+    float acc[JH];
 #pragma clang loop unroll(full)
-    for (int j = 0; j < RUN; ++j) acc[j] = 0.f;
+    for (int j = 0; j < JH; ++j) acc[j] = 0.f;
 #pragma clang loop unroll(full)
-    for (int p = 0; p < ROWS; ++p) {
-        const float zv = tile[p * D + ch];
+    for (int pp = 0; pp < JH + TAPS - 1; ++pp) {   // LDS row j0 + pp feeds output j0 + j with tap pp - j
+        const float zv = tile[min(j0 + pp, ROWS - 1) * D + ch];
 #pragma clang loop unroll(full)
-        for (int j = (p - (TAPS - 1) > 0 ? p - (TAPS - 1) : 0); j <= (p < RUN - 1 ? p : RUN - 1); ++j)
-            acc[j] = fmaf(wk[p - j], zv, acc[j]);
+        for (int j = (pp - (TAPS - 1) > 0 ? pp - (TAPS - 1) : 0); j <= (pp < JH - 1 ? pp : JH - 1); ++j)
+            acc[j] = fmaf(wk[pp - j], zv, acc[j]);
     }
     // the RUN x D outputs go back through LDS (the GLU tile is dead once every thread has finished its taps) and leave
     // as 16-byte row pieces: one 4-byte store per lane and frame made the kernel's tail store-issue bound
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RUN; ++j) {
+    for (int j = 0; j < JH; ++j) {
         const float y = fmaxf((acc[j] + bb) * al + be_, 0.f);
-        tile[j * D + ch] = xres[j] + (w2 * y + c2);
+        if (j0 + j < RUN) tile[(j0 + j) * D + ch] = xres[j] + (w2 * y + c2);
     }
     __syncthreads();
     // One wave per frame: the frame leaves as 16-byte pieces, and -- the whole row being in the wave's registers -- the
@@ -378,15 +381,15 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
     const size_t lds = (size_t)(RUN + 32) * D * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (D == 512)
-        hipLaunchKernelGGL((conv_module_kernel<2, 33, RUN>), dim3(nseg * runs), dim3(512), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
+        hipLaunchKernelGGL((conv_module_kernel<2, 33, RUN, 2>), dim3(nseg * runs), dim3(1024), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
                            dw_b, bn_alpha, bn_beta, ln2_w, ln2_b, z, z_split, T, runs);
     else
-        hipLaunchKernelGGL((conv_module_kernel<1, 33, RUN>), dim3(nseg * runs), dim3(256), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
+        hipLaunchKernelGGL((conv_module_kernel<1, 33, RUN, 2>), dim3(nseg * runs), dim3(512), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
                            dw_b, bn_alpha, bn_beta, ln2_w, ln2_b, z, z_split, T, runs);
     return true;
 }
