@@ -88,3 +88,26 @@ def test_long_meeting_multi_batch_is_lane_invariant(mc_state):
         assert nseg >= 200 and np.isfinite(wav).all()
     for wav, perms in out[1:]:
         assert np.array_equal(perms, out[0][1]) and np.array_equal(wav, out[0][0])
+
+
+@pytest.mark.parametrize("seg_hop", [(4.0, 2.0), (2.0, 1.0)])
+def test_lanes_with_other_segment_lengths(mc_state, mix60, seg_hop):
+    """249- and 124-frame segments (8 and 4 attention key tiles, other position-operand tables and q/k fragment
+    layouts, conv runs with a ragged tail) through one, three and four lanes: bit for bit the same."""
+    CSS, L = pkg("css"), pkg("_lib")
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False, segment_size_sec=seg_hop[0], hop_size_sec=seg_hop[1])
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    mix = np.ascontiguousarray(mix60[0, :int(44.3 * 16000)])
+    out = []
+    for lanes, mb in [(1, 64), (3, 64), (4, 17)]:
+        sep = _separator(mc_state, lanes, mb)
+        try:
+            wav = sep.handle.run(mix, run_cfg)
+            nseg = sep.handle.get_plan().num_segments
+            masks = sep.handle.read(L.BUF_MASKS)
+        finally:
+            sep.close()
+        assert nseg >= 16 and np.isfinite(wav).all()
+        out.append((wav, masks))
+    for wav, masks in out[1:]:
+        assert np.array_equal(masks, out[0][1]) and np.array_equal(wav, out[0][0])
