@@ -70,7 +70,7 @@ typedef struct CssModelDesc {
     int32_t num_nois;        /* 1                                                       */
     int32_t frame_len;       /* 512                                                     */
     int32_t frame_hop;       /* 256                                                     */
-    int32_t maxlen;          /* relative-position table half size, 1000 (conformer.py:213) */
+    int32_t maxlen;          /* relative-position table half size, 1000 (conformer.py:213); offsets past it are clamped (:24) */
 } CssModelDesc;
 
 /* Run-time knobs.  Mirrors the arithmetic-relevant fields of CssCfg (css/css.py:24-48) after the

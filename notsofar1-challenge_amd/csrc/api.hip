@@ -169,7 +169,7 @@ const char* validate_desc(const CssModelDesc& d) {
     if (d.linear_units % 32 || d.linear_units <= 0) return "linear_units must be a multiple of 32";
     if (d.kernel_size != 33 && d.kernel_size != 31 && d.kernel_size != 17) return "kernel_size must be 33, 31 or 17";
     if (d.num_spks < 1 || d.num_spks > 3 || d.num_nois != 1) return "num_spks must be 1..3 and num_nois 1";
-    if (d.num_blocks < 1 || d.maxlen < 256) return "num_blocks >= 1 and maxlen >= 256 required";
+    if (d.num_blocks < 1 || d.maxlen < 1) return "num_blocks >= 1 and maxlen >= 1 required";
     return nullptr;
 }
 
@@ -483,7 +483,6 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
     if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256]");
     if (hop <= 0 || 4 * hop < T || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/4 <= hop < T (at most four segments overlap; at least one frame of overlap for the stitching cost)");
-    if (T - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "segment longer than the relative-position table");
     HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};
     if (plan_impl(h->d, *cfg, n_samples, &p) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "bad segment configuration");
@@ -1021,7 +1020,6 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
 int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks) {
     if (!h || !x_planes || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     if (t_frames < 2 || t_frames > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 256] frames");
-    if (t_frames - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "segment longer than the relative-position table");
     HIPCHK(h, hipSetDevice(h->device));
     const int F = h->d.num_bins, C = h->d.num_mics, T = t_frames, nm = h->d.num_spks + h->d.num_nois;
     const int64_t TT = (int64_t)batch * T;
@@ -1053,7 +1051,6 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
     if (n_samples < N) return fail(h, CSS_ERR_INVALID_ARG, "clip shorter than one frame");
     const int64_t T64 = (n_samples - N) / hop + 1;
     if (T64 < 2 || T64 > 256) return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2..256 frames");
-    if (T64 - 1 > h->d.maxlen) return fail(h, CSS_ERR_INVALID_ARG, "clip longer than the relative-position table");
     const int T = (int)T64;
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t TT = (int64_t)batch * T;

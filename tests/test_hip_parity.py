@@ -399,15 +399,18 @@ def test_batched_forward_is_stft_then_separate(L, sep_mc, sep_sc, mix60):
         sep_mc.forward(torch.from_numpy(short))                                                       # 1 channel into the MC model
 
 
-@pytest.mark.parametrize("dims", [(256, 4, 512, 33), (768, 12, 1536, 33), (512, 8, 1024, 17), (512, 8, 1056, 31)])
+@pytest.mark.parametrize("dims", [(256, 4, 512, 33), (768, 12, 1536, 33), (512, 8, 1024, 17), (512, 8, 1056, 31),
+                                  (512, 8, 1024, 33, 100)])
 def test_other_model_widths_vs_oracle(L, mix_stage, dims):
     """Narrower / wider models and another depthwise kernel size exercise the other template instantiations
-    (LayerNorm NV = 1 / 3, the fused conv module for D = 256 and its two-kernel fallback, GEMM tails): masks of a
-    2-block model against the oracle in both arithmetic modes."""
+    (LayerNorm NV = 1 / 3, the fused conv module for D = 256 and its two-kernel fallback, GEMM tails), and a
+    relative-position table SHORTER than the segment (maxlen 100 < 186 frames: the clamp of conformer.py:24, baked into
+    the attention kernel's position operands): masks of a 2-block model against the oracle in both arithmetic modes."""
     import torch
     w = pkg("weights")
-    D, H, FFu, ks = dims
-    desc = w.ModelDesc(attention_dim=D, attention_heads=H, linear_units=FFu, num_blocks=2, kernel_size=ks)
+    D, H, FFu, ks = dims[:4]
+    extra = dict(maxlen=dims[4]) if len(dims) > 4 else {}
+    desc = w.ModelDesc(attention_dim=D, attention_heads=H, linear_units=FFu, num_blocks=2, kernel_size=ks, **extra)
     st = w.apply_golden_recipe(w.portable_state_dict(desc, 31))
     params = O.ConformerParams(st)
     sep = pkg("separator").HipSeparator(st, None, device=0)
