@@ -381,8 +381,8 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
     const size_t lds = (size_t)(RUN + 32) * D * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (D == 512)
