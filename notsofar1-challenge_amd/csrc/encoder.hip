@@ -34,13 +34,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 // MODE 2: u = LN(x); y = (pw0*u + pw1) * sigmoid(pw2*u + pw3)   (scalar Conv2d(1,2,1) + GLU,
 //         conformer.py:100,116-117)
 // ------------------------------------------------------------------------------------------------
+#ifndef CSS_LN_ROWS
+#define CSS_LN_ROWS 4
+#endif
+constexpr int LN_ROWS = CSS_LN_ROWS;   // rows (waves) per LayerNorm block
 template <int NV, int MODE>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(64 * LN_ROWS) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         float* __restrict__ ys, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ pw,
                                                         int rows) {
     constexpr int D = 256 * NV;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * LN_ROWS + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
@@ -85,13 +89,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // l+1's feed-forward LayerNorm (conformer.py:139) read the same row; the arithmetic is that of the two separate
 // kernels, value for value.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(64 * LN_ROWS) void layernorm2_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          float* __restrict__ z, float* __restrict__ zs,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          int rows) {
     constexpr int D = 256 * NV;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * LN_ROWS + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
 
 void launch_layernorm2(const float* x, float* y, const float* w1, const float* b1, float* z, float* z_split,
                        const float* w2, const float* b2, int rows, int D, hipStream_t s) {
-    const dim3 grid((rows + 3) / 4), block(256);
+    const dim3 grid((rows + LN_ROWS - 1) / LN_ROWS), block(64 * LN_ROWS);
     switch (D) {
         case 256: hipLaunchKernelGGL((layernorm2_kernel<1>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
         case 512: hipLaunchKernelGGL((layernorm2_kernel<2>), grid, block, 0, s, x, y, w1, b1, z, z_split, w2, b2, rows); break;
@@ -142,7 +146,7 @@ void launch_layernorm2(const float* x, float* y, const float* w1, const float* b
 template <int MODE>
 static void launch_ln_mode(const float* x, float* y, float* ys, const float* w, const float* b, const float* pw,
                            int rows, int D, hipStream_t s) {
-    const dim3 grid((rows + 3) / 4), block(256);
+    const dim3 grid((rows + LN_ROWS - 1) / LN_ROWS), block(64 * LN_ROWS);
     switch (D) {
         case 256: hipLaunchKernelGGL((layernorm_kernel<1, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
         case 512: hipLaunchKernelGGL((layernorm_kernel<2, MODE>), grid, block, 0, s, x, y, ys, w, b, pw, rows); break;
