@@ -67,7 +67,7 @@ struct css_ctx {
     int n_ch = 0;
     int64_t n_pad = 0, T_ld = 0;
     bool stft_done = false, perms_done = false, have_override = false;
-    std::vector<float> w_host;
+    std::vector<float> w_host, w_on_device;   // segment weights of the session / what segw holds (uploaded when they change)
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, qkf, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
         act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
@@ -531,7 +531,11 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     ENS(wav, (size_t)S * p.n_out * sizeof(float))
     ENS(pnorm, (size_t)nseg * sizeof(double))
     ENS(segw, (size_t)3 * T * sizeof(float))
-    HIPCHK(h, hipMemcpyAsync(h->segw.p, h->w_host.data(), 3 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // (a copy from pageable memory makes the host wait for the stream: paid only when the windows change)
+    if (h->w_on_device != h->w_host) {
+        HIPCHK(h, hipMemcpyAsync(h->segw.p, h->w_host.data(), 3 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        h->w_on_device = h->w_host;
+    }
     const float* pcm_dev = pcm;
     if (!pcm_is_device) {
         ENS(pcm_in, (size_t)n_samples * n_ch * sizeof(float))
