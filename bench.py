@@ -5,12 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the CSS hot path (css/css.py::separate_and_stitch equivalent: STFT ->
-Conformer mask estimator -> WTA/SCM/MVDR -> PIT stitch -> activity gate -> iSTFT) over one synthetic
-7-channel 16 kHz meeting whose PCM is already resident in HBM.  N = 1: the 60 s meeting of
-BASELINE.json configs[1].  N > 1: ONE meeting of N x 60 s, sharded by sliding-window segment across the
-ranks with the RCCL all-gather stitch of notsofar1-challenge_amd/parallel.py (weak scaling: 40 segments
-per GPU).  `value` = audio seconds separated per wall second over the whole job.
+One "step" = one pass of the CSS hot path (css/css.py::separate_and_stitch equivalent: STFT -> Conformer mask
+estimator -> WTA/SCM/MVDR -> PIT stitch -> activity gate -> iSTFT) over one synthetic 7-channel 16 kHz meeting,
+timed from the PCM in (page-locked) HOST memory to the separated waveforms in host memory: both PCIe legs are
+inside the timed region (SURVEY.md 8(d) "Metric").  `value` = audio seconds separated per wall second.
+
+  N = 1   BASELINE.json configs[1]: the 60 s meeting (40 segments).  The same line also carries the 30-min meeting of
+          configs[3] on this one GPU (`meeting_1800s`), the device-resident figure, the exact-float32 arithmetic mode,
+          the roofline of the dominant kernel, the memory-bound kernels' GB/s, and the CPU baseline.
+  N > 1   BASELINE.json configs[3]: ONE fixed 1800 s meeting (1209 segments), strong-scaled: sharded by sliding-window
+          segment across the N ranks with the RCCL all-gather stitch of notsofar1-challenge_amd/parallel.py.  Every rank
+          uploads only the samples of its own segments and downloads only its own range of the result (the stitched
+          streams are complete in every rank's HBM after the all-gather).  Rank 0 also times the same meeting alone on
+          its GPU after the timed region (`single_gpu_same_workload`), so that every line compares like with like.
 
 Weights: v1.0-MC architecture (D=512, H=8, 18 blocks, 1799 inputs), seeded portable random init with the
 conditioning recipe of the golden tests (no pretrained checkpoint exists offline) -- arithmetic and
@@ -30,10 +37,15 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # same guide: dense f16 / bf16 MFMA peak (v_mfma_f32_32x32x16_f16)
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E spec (6.3 TB/s is what a float4 copy reaches)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def pkg(name):
+    return importlib.import_module("notsofar1_challenge_amd." + name)
 
 
 def cpu_baseline(mix, state, seconds, cfg_kwargs, threads=16):
@@ -64,15 +76,41 @@ def cpu_baseline(mix, state, seconds, cfg_kwargs, threads=16):
                                       f"{threads} threads, {dt:.1f} s wall"}
 
 
+def hbm_kernel_bytes(plan, desc, T, hop, n):
+    """ALGORITHMIC bytes per pass of the memory-bound kernel families (compulsory traffic with the path's
+    materialisation points kept; DESIGN.md section 3 states each formula)."""
+    C, F, S = desc.num_mics, desc.num_bins, desc.num_spks
+    nseg, TL = int(plan.num_segments), int(plan.mix_frames)
+    Kp = (desc.in_features + 31) // 32 * 32
+    KIp = (2 * F + 31) // 32 * 32
+    planes_seg = C * 2 * F * T * 4
+    masks_seg = (S + 1) * F * T * 4
+    return {
+        "deinterleave": 2 * n * C * 4,
+        "stft": n * C * 4 + C * 2 * F * TL * 4,
+        "features": nseg * (planes_seg + T * Kp * 4),
+        "scm": nseg * (planes_seg + masks_seg + (S + 1) * F * 49 * 8),
+        "mvdr_solve": nseg * ((S + 1) * F * 49 * 8 + S * F * C * 16),
+        "beamform": nseg * (planes_seg + S * F * C * 16 + S * F * T * 4 + S * F * T * 8),
+        "pit": max(nseg - 1, 0) * 2 * S * F * (T - hop) * 4,
+        "ola_masks": TL * (2 * S * F * 4 + S * F * 4),
+        "ola_stft": TL * (2 * S * F * 8 + S * KIp * 4),
+        "istft_gemm": S * TL * KIp * 4 + S * TL * desc.frame_len * 4,
+        "wave_ola": S * TL * desc.frame_len * 4 + S * int(plan.n_out) * 4,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seconds", type=float, default=60.0, help="meeting seconds per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0, help="N = 1: length of the headline meeting (configs[1])")
+    ap.add_argument("--long-seconds", type=float, default=1800.0, help="the strong-scaling meeting (configs[3])")
     ap.add_argument("--max-batch", type=int, default=128, help="segments per batched mask-estimator pass")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long", action="store_true", help="N = 1: skip the 30-min meeting")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +126,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     # functional-test knobs (never used by the driver): CSS_BENCH_BACKEND=gloo exchanges through host memory,
-    # CSS_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (a 1-GPU box can then exercise the N > 1 code path)
+    # CSS_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (RCCL refuses two ranks on one device, gloo does not: a 1-GPU box
+    # can then exercise the N > 1 code path); CSS_BENCH_CHECK=1 compares the sharded result with the fused run
     backend = os.environ.get("CSS_BENCH_BACKEND", "nccl")
     if os.environ.get("CSS_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
@@ -101,152 +140,250 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    W = importlib.import_module("notsofar1_challenge_amd.weights")
-    SYN = importlib.import_module("notsofar1_challenge_amd.synth")
-    CSS = importlib.import_module("notsofar1_challenge_amd.css")
-    SEP = importlib.import_module("notsofar1_challenge_amd.separator")
-    PAR = importlib.import_module("notsofar1_challenge_amd.parallel")
-
+    W, SYN, CSS, SEP, PAR, L = pkg("weights"), pkg("synth"), pkg("css"), pkg("separator"), pkg("parallel"), pkg("_lib")
     desc = W.ModelDesc.mc_v1()
     cal = np.load(os.path.join(ROOT, "tests", "golden", "calib_mc.npz"))
     state = W.apply_golden_recipe(W.portable_state_dict(desc, 0), head_bias=cal["head_bias"])
-    total_seconds = args.seconds * world
-    t0 = time.time()
-    mix = SYN.synth_meeting(total_seconds, 7, seed=1)  # [1, n, 7]; identical on every rank
-    n = mix.shape[1]
-    log(f"[rank {rank}] synthetic meeting {total_seconds:g} s generated in {time.time() - t0:.1f} s")
-
     cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)  # configs/inference/inference_v1.yaml
     run_cfg = CSS.make_run_cfg(cfg, 16000, 7, desc.frame_len, desc.frame_hop)
+    T, hop = int(run_cfg.c.segment_frames), int(run_cfg.c.hop_frames)
+    S = desc.num_spks
+
+    def meeting(seconds):
+        t0 = time.time()
+        m = SYN.synth_meeting(seconds, 7, seed=1)  # [1, n, 7]; identical on every rank
+        log(f"[rank {rank}] synthetic meeting {seconds:g} s generated in {time.time() - t0:.1f} s")
+        return m
+
+    def fused_host_to_host(h, pcm_pinned, out_pinned, steps, warmup):
+        """css_run: page-locked host PCM -> page-locked host waveforms (both PCIe legs timed); ms per step"""
+        for _ in range(warmup):
+            h.run(pcm_pinned, run_cfg, out=out_pinned)
+        h.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.run(pcm_pinned, run_cfg, out=out_pinned)
+        h.sync()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    dtype_of = {"split_f16": "f32 (Linear layers: f32 products as 3 f16 MFMAs on split operands, f32 accumulate; MVDR f64)",
+                "exact_f32": "f32 (MVDR covariance/solve f64)"}
+    result = {"metric": "CSS real-time-factor (sep. audio sec/wall sec) on 7-ch 16 kHz", "unit": "x real-time (audio s / wall s)",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+              "data": "synthetic"}
+
+    # ================================================================================================ N > 1
+    if world > 1:
+        seconds = args.long_seconds
+        mix = meeting(seconds)
+        n = mix.shape[1]
+        plan = L.plan(desc, run_cfg, n)
+        nseg = int(plan.num_segments)
+        per_rank = -(-nseg // world) + 1
+        sep = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=max(args.max_batch, per_rank))
+        h = sep.handle
+        be = PAR.HipShardBackend(h, dev, comm_dev)
+        me = PAR.make_shard_plan(nseg, int(plan.mix_frames), int(plan.stft_frames), T, hop, desc.frame_hop, rank, world)
+        s_lo, s_hi = me.pcm_range(desc.frame_len, n)
+        # this rank's samples and its range of the result, in page-locked host memory
+        pcm_slice = L.pinned_copy(np.ascontiguousarray(mix[0, s_lo:s_hi]))
+        o_lo = me.sample_lo
+        o_hi = int(plan.n_out) if rank == world - 1 else me.t_hi * desc.frame_hop
+        out_host = torch.empty((S, max(o_hi - o_lo, 1)), dtype=torch.float32, pin_memory=True)
+        out_dev = torch.empty((S, int(plan.n_out)), dtype=torch.float32, device=dev)
+
+        def step():
+            be.begin(pcm_slice, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True)
+            out = PAR.sharded_separate_and_stitch(be, S, T, hop, desc.frame_hop, rank, world, dist, out=out_dev)
+            with be.on_stream():
+                if o_hi > o_lo:
+                    out_host[:, :o_hi - o_lo].copy_(out[:, o_lo:o_hi], non_blocking=True)
+            return out
+
+        def barrier():
+            h.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        assert torch.isfinite(out_host).all()
+        if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
+            ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
+            same = bool(np.array_equal(ref, out.cpu().numpy())) and \
+                bool(np.array_equal(ref[:, o_lo:o_hi], out_host[:, :o_hi - o_lo].numpy()))
+            log(f"[rank {rank}] sharded == fused single-GPU result, bit for bit: {same}")
+            assert same
+        result.update({
+            "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "scaling": "strong", "dtype": dtype_of[h.linear_mode()],
+            "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({nseg} segments of 3 s / 1.5 s hop), "
+                                   f"Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR, host PCM -> host waveforms",
+                       "segments": nseg, "segments_per_rank": me.seg_hi - me.seg_lo,
+                       "sharding": f"{world} ranks x segment ranges (one halo segment per seam), three all-gathers over "
+                                   f"{'RCCL' if backend == 'nccl' else backend}: PIT costs, activity bits, waveform shards"},
+        })
+        if rank == 0:
+            # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)
+            pcm_all = L.pinned_copy(np.ascontiguousarray(mix[0]))
+            out_all = L.pinned_empty((S, int(plan.n_out)), np.float32)
+            ms1 = fused_host_to_host(h, pcm_all, out_all, 3, 1)
+            result["single_gpu_same_workload"] = {"ms_per_step": round(ms1, 3), "value": round(seconds / (ms1 * 1e-3), 2),
+                                                  "speedup": round(ms1 / (1e3 * elapsed / args.steps), 3)}
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        sep.close()
+        dist.destroy_process_group()
+        return
+
+    # ================================================================================================ N = 1
+    seconds = args.seconds
+    mix = meeting(seconds)
+    n = mix.shape[1]
+    plan = L.plan(desc, run_cfg, n)
     sep = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=args.max_batch)
     h = sep.handle
-    pcm_dev = torch.from_numpy(np.ascontiguousarray(mix[0])).to(dev)  # resident in HBM before timing
-    S = desc.num_spks
-    L = importlib.import_module("notsofar1_challenge_amd._lib")
-    plan = L.plan(desc, run_cfg, n)
-    wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
+    pcm_pin = L.pinned_copy(np.ascontiguousarray(mix[0]))
+    out_pin = L.pinned_empty((S, int(plan.n_out)), np.float32)
     torch.cuda.synchronize()
 
-    be = PAR.HipShardBackend(h, dev, comm_dev)
-
-    def step():
-        if world == 1:
-            h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
-            return wav_dev
-        be.begin(pcm_dev, n, 7, run_cfg)
-        return PAR.sharded_separate_and_stitch(be, S, run_cfg.c.segment_frames, run_cfg.c.hop_frames,
-                                               desc.frame_hop, rank, world, dist)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        h.sync()
-        torch.cuda.synchronize()
-
+    # ---- headline: host -> host, exactly K steps after W warm-up steps, synchronised on both sides
     for _ in range(args.warmup):
-        out = step()
-    barrier()
+        h.run(pcm_pin, run_cfg, out=out_pin)
+    h.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
-    barrier()
+        h.run(pcm_pin, run_cfg, out=out_pin)
+    h.sync(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
-    if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
-        ref = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
-        h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, ref.data_ptr(), plan.n_out)
-        same = bool(torch.equal(ref.cpu(), out.cpu()))
-        log(f"[rank {rank}] sharded == fused single-GPU result: {same}")
-        assert same
+    assert np.isfinite(out_pin).all()
+    result.update({
+        "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "scaling": "strong", "dtype": dtype_of[h.linear_mode()],
+        "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({plan.num_segments} segments of 3 s / 1.5 s "
+                               f"hop), Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR, host PCM -> host waveforms "
+                               f"(css_run, page-locked buffers, both PCIe legs timed)",
+                   "segments": int(plan.num_segments), "sharding": "single GPU"},
+    })
+    stage = h.timings()
+    result["stage_ms"] = {k: round(v, 3) for k, v in stage.items()
+                          if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total")}
 
-    result = {
-        "metric": "CSS real-time-factor (sep. audio sec/wall sec) on 7-ch 16 kHz",
-        "value": round(total_seconds * args.steps / elapsed, 2),
-        "unit": "x real-time (audio s / wall s)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (Linear layers: f32 products as 3 f16 MFMAs on split operands, f32 accumulate; MVDR f64)"
-                  if h.linear_mode() == "split_f16" else "f32 (MVDR covariance/solve f64)"), "data": "synthetic",
-        "config": {"workload": f"synthetic 7-ch 16 kHz {total_seconds:g} s meeting "
-                               f"({plan.num_segments} segments of 3 s / 1.5 s hop), Conformer-CSS v1.0-MC "
-                               f"(18 blocks, D=512) + MVDR, PCM resident in HBM",
-                   "seconds_per_gpu": args.seconds, "segments": int(plan.num_segments),
-                   "sharding": "single GPU" if world == 1 else f"{world} ranks x segment ranges, RCCL all-gather stitch"},
-    }
+    # ---- the same pass with input and output resident in HBM (what the PCIe legs cost), and from pageable memory
+    pcm_dev = torch.from_numpy(np.ascontiguousarray(mix[0])).to(dev)
+    wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
 
-    if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel (the fp32 MFMA GEMM): live HIP-event timing of every launch
+    def timed(fn, steps=args.steps, warmup=2):
+        for _ in range(warmup):
+            fn()
+        h.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        h.sync(); torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    def rec(ms, note):
+        return {"ms_per_step": round(ms, 3), "value": round(seconds / (ms * 1e-3), 2), "note": note}
+
+    ms_dev = timed(lambda: h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out))
+    result["device_resident"] = rec(ms_dev, "css_run_device: PCM and waveforms in HBM (no PCIe leg)")
+    result["host_vs_device_resident"] = round((1e3 * elapsed / args.steps) / ms_dev, 4)
+    pageable = np.ascontiguousarray(mix[0])
+    result["pageable_host"] = rec(timed(lambda: h.run(pageable, run_cfg), steps=5, warmup=1),
+                                  "css_run from/to ordinary (pageable) host memory: the driver's staged copies")
+    planes = [np.ascontiguousarray(np.clip(np.rint(mix[0, :, c] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)) for c in range(7)]
+    result["pcm16_edges"] = rec(timed(lambda: h.run_pcm16(planes, run_cfg), steps=5, warmup=1),
+                                "css_run_pcm16: 7 int16 planes in host memory -> 3 peak-normalised PCM16 streams in host memory")
+
+    # ---- roofline of the dominant kernel (the Linear-layer GEMM): live HIP-event timing of every launch, one lane
+    def profiled_pass():
         h.set_profile(True)
         h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
         h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
-        t = h.timings()
+        t, ks = h.timings(), h.kernel_stats()
         h.set_profile(False)
+        return t, ks
+
+    def gemm_roofline(t, mode):
         # `achieved` counts ALGORITHMIC flops (2*M*N*K of the float32 products the network defines).
         achieved = t["gemm_flops"] / (t["gemm_ms"] * 1e-3) / 1e12 if t["gemm_ms"] > 0 else 0.0
-        if h.linear_mode() == "split_f16":
-            # every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi, f32 accumulate): the ceiling for
-            # float32-grade products on the f16 pipes is the dense f16 peak / 3, and achieved / that ceiling
-            # equals executed-MFMA-flops / dense f16 peak (the matrix-core utilisation).
+        if mode == "split_f16":
+            # every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi, f32 accumulate): the ceiling for float32-grade
+            # products on the f16 pipes is the dense f16 peak / 3, and achieved / that ceiling equals
+            # executed-MFMA-flops / dense f16 peak (the matrix-core utilisation).
             peak = PEAK_F16_MATRIX_TFLOPS / 3.0
-            kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, 64x128x32 tiles, weights direct)"
+            kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, weights direct)"
             extra = {"mfma_executed_tflops": round(3 * achieved, 2), "mfma_dense_peak_tflops": PEAK_F16_MATRIX_TFLOPS,
                      "vs_f32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
         else:
             peak = PEAK_FP32_MATRIX_TFLOPS
             kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
             extra = {}
-        # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes
-        # from the committed PMC passes of the same command (profiles/README.md), when present
-        traffic = None
-        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
-            tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic.json")
-            if os.path.exists(tj):
-                with open(tj) as f:
-                    traffic = round(json.load(f)["traffic_bytes_per_launch"])
-                extra["traffic_source"] = f"profiles/{tag}_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-                break
-        result["roofline"] = {
-            "bound": "mfma", "kernel": kernel,
-            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "launches_per_step": int(t["gemm_launches"]),
-            "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
-            "flops_per_step": t["gemm_flops"], **extra,
-        }
-        h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
-        result["stage_ms"] = {k: round(v, 3) for k, v in h.timings().items()
-                              if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total")}
-        # the same pass through the host-buffer entry point (css_run: PCIe upload of the PCM, download of the
-        # waveforms) -- reported beside `value`, never as `value`
-        h.run(mix[0], run_cfg)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            h.run(mix[0], run_cfg)
-        host_ms = 1e3 * (time.perf_counter() - t0) / 5
-        result["host_buffers"] = {"ms_per_step": round(host_ms, 3), "value": round(total_seconds / (host_ms * 1e-3), 2),
-                                  "note": "css_run from/to pageable host memory (PCIe-inclusive)"}
-        # ... and between the wav edges (css_run_pcm16: int16 planes up, peak-normalised PCM16 down, converted on the GPU)
-        planes = [np.ascontiguousarray(np.clip(np.rint(mix[0, :, c] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)) for c in range(7)]
-        h.run_pcm16(planes, run_cfg)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            h.run_pcm16(planes, run_cfg)
-        p16_ms = 1e3 * (time.perf_counter() - t0) / 5
-        result["pcm16_edges"] = {"ms_per_step": round(p16_ms, 3), "value": round(total_seconds / (p16_ms * 1e-3), 2),
-                                 "note": "css_run_pcm16: 7 int16 planes from host memory -> 3 PCM16 streams in host memory"}
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, total_seconds),
-                                                  {"activity_th": 0.3})
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": int(t["gemm_launches"]),
+                "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
+                "flops_per_step": t["gemm_flops"], **extra}
+
+    t, ks = profiled_pass()
+    roof = gemm_roofline(t, h.linear_mode())
+    # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes from
+    # the committed PMC passes of the same command (profiles/README.md), when present
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+        tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic.json")
+        if os.path.exists(tj):
+            with open(tj) as f:
+                roof["traffic"] = round(json.load(f)["traffic_bytes_per_launch"])
+            roof["traffic_source"] = f"profiles/{tag}_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+            break
+    result["roofline"] = roof
+    # ---- the memory-bound kernel families of the same profiled pass: algorithmic bytes / live HIP-event time
+    alg = hbm_kernel_bytes(plan, desc, T, hop, n)
+    result["roofline_hbm"] = [
+        {"kernel": k, "bytes": int(alg[k]), "us": round(1e3 * ks[k][0], 2), "launches": ks[k][1],
+         "GBps": round(alg[k] / (ks[k][0] * 1e-3) / 1e9, 1), "frac": round(alg[k] / (ks[k][0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        for k in alg if k in ks and ks[k][0] > 0]
+    result["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks.items()}
+
+    # ---- the strictly-float32 arithmetic mode, same workload, same timing rules
+    h.set_linear_mode("exact_f32")
+    ms_x = fused_host_to_host(h, pcm_pin, out_pin, max(args.steps // 2, 5), 2)
+    tx, _ = profiled_pass()
+    result["exact_f32"] = {**rec(ms_x, "css_set_linear_mode(CSS_LINEAR_EXACT_F32): every Linear layer on the exact float32 MFMA chain; host -> host"),
+                           "dtype": dtype_of["exact_f32"], "roofline": gemm_roofline(tx, "exact_f32")}
+    h.set_linear_mode("split_f16")
+
+    # ---- BASELINE.json configs[3] on this one GPU: the fixed 30-min meeting every N > 1 line runs
+    if not args.no_long:
+        del pcm_dev, wav_dev
+        long_mix = meeting(args.long_seconds)
+        n_long = long_mix.shape[1]
+        plan_long = L.plan(desc, run_cfg, n_long)
+        pcm_long = L.pinned_copy(np.ascontiguousarray(long_mix[0]))
+        del long_mix
+        out_long = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
+        ms_long = fused_host_to_host(h, pcm_long, out_long, 3, 1)
+        assert np.isfinite(out_long[:, ::4096]).all()
+        result["meeting_1800s"] = {**rec(ms_long, "the strong-scaling workload of the N > 1 lines on ONE GPU, host -> host"),
+                                   "value": round(args.long_seconds / (ms_long * 1e-3), 2),
+                                   "segments": int(plan_long.num_segments), "seconds": args.long_seconds}
+        del pcm_long, out_long
+
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, seconds), {"activity_th": 0.3})
+    print(json.dumps(result), flush=True)
     sep.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -159,6 +159,20 @@ int64_t css_blob_num_floats(const CssModelDesc* desc);
 int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_floats, int device,
                void* stream, int32_t max_batch_segments, css_handle_t* out);
 int css_destroy(css_handle_t h);
+/* The hipStream_t every kernel of `h` is ordered on (the one passed to css_create, or the one it created): a caller
+ * that enqueues its own work -- torch.distributed collectives between the stages of a sharded meeting, say -- wraps it
+ * (torch.cuda.ExternalStream) and needs no host synchronisation between its work and the handle's. */
+int css_get_stream(css_handle_t h, void** stream_out);
+/* Number of independent kernel chains ("lanes", 1..4, default 3) a batch of segments is cut into inside the mask
+ * estimator (segments are independent through the network, css.py:182-250 carries no state between them).  Results do
+ * not depend on it, bit for bit. */
+int css_set_lanes(css_handle_t h, int lanes);
+int css_get_lanes(css_handle_t h);
+/* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,
+ * asynchronously, in pieces that overlap the first and last kernels of the pass; pageable memory works too, at the
+ * driver's staged-copy rate.  (hipHostMalloc / hipHostFree; no handle needed.) */
+int css_host_alloc(size_t bytes, void** out);
+int css_host_free(void* p);
 
 /* ---- planning (pure host arithmetic, no GPU needed) ---------------------------------------- */
 /* css/css.py:155-171 + css.py:297: frames, segments, output length for an input of n_samples. */
@@ -187,6 +201,11 @@ int css_get_timings(css_handle_t h, CssTimings* out);
 /* enable != 0: bracket every MFMA GEMM launch of the mask estimator with HIP events on the handle's
  * stream, so that CssTimings.gemm_ms / gemm_launches report the live average launch duration. */
 int css_set_profile(css_handle_t h, int enable);
+/* With the profile on, the same event pairs bracket EVERY kernel launch of a css_run* pass; their durations summed per
+ * kernel family ("stft", "features", "linear_gemm", "attention", "scm", "mvdr_solve", "beamform", "ola_stft", ...), for
+ * the roofline figures of the memory-bound stages.  out[cap]; *count = families that ran in the last profiled pass. */
+typedef struct CssKernelStat { char name[32]; float ms; int32_t launches; } CssKernelStat;
+int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_t* count);
 /* Arithmetic of the Conformer's Linear layers (torch.nn.Linear in conformer.py:49-53,139-142,206,285):
  *   CSS_LINEAR_SPLIT_F16 (default)  operands carried as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product,
  *                                   float32 accumulation: float32-grade accuracy at 5.3x the float32 matrix rate;
@@ -201,6 +220,11 @@ int css_get_plan(css_handle_t h, CssPlan* out);
 /* ---- stages (each replaces one reference function; state lives in the handle) -------------- */
 /* Begin a session: upload + deinterleave PCM, fix the plan.  (css.py:141-171) */
 int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device);
+/* css_begin for a rank that owns a slice of a long meeting held in host memory: the plan is that of the whole
+ * recording, but only samples [s_lo, s_hi) of pcm_host (which still points at sample 0) cross PCIe -- the samples of
+ * the frames this rank will pass to css_stage_stft_range. */
+int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                    int64_t s_lo, int64_t s_hi);
 /* ConformerCssWrapper.stft (conformer_wrapper.py:106, feature.py:88) over the whole recording. */
 int css_stage_stft(css_handle_t h);
 /* Same for frames [t_lo, t_hi) only (a rank that owns a slice of the meeting transforms just the

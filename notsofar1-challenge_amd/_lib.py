@@ -58,6 +58,10 @@ class CssPlan(C.Structure):
                 ("zero_weight", C.c_int32)]
 
 
+class CssKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_float), ("launches", C.c_int32)]
+
+
 class CssTimings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("upload", "stft", "features", "masknet", "mvdr", "stitch", "istft",
                                           "download", "total", "gemm_ms")] + \
@@ -74,6 +78,11 @@ SIGNATURES = {
     "css_blob_num_floats": (C.c_int64, [C.POINTER(CssModelDesc)]),
     "css_create": (C.c_int, [C.POINTER(CssModelDesc), _P, C.c_int64, C.c_int, _P, C.c_int32, C.POINTER(_P)]),
     "css_destroy": (C.c_int, [_P]),
+    "css_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "css_set_lanes": (C.c_int, [_P, C.c_int]),
+    "css_get_lanes": (C.c_int, [_P]),
+    "css_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "css_host_free": (C.c_int, [_P]),
     "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
     "css_pit_scan": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
@@ -81,10 +90,12 @@ SIGNATURES = {
     "css_run_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
     "css_get_timings": (C.c_int, [_P, C.POINTER(CssTimings)]),
     "css_set_profile": (C.c_int, [_P, C.c_int]),
+    "css_get_kernel_stats": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "css_set_linear_mode": (C.c_int, [_P, C.c_int]),
     "css_get_linear_mode": (C.c_int, [_P]),
     "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
     "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
+    "css_begin_range": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int64, C.c_int64]),
     "css_stage_stft": (C.c_int, [_P]),
     "css_stage_stft_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_stitch_masks": (C.c_int, [_P, C.c_int64, C.c_int64]),
@@ -205,6 +216,40 @@ def pit_scan(costs: np.ndarray, num_spks: int) -> np.ndarray:
     return perms
 
 
+class _PinnedBlock:
+    """Owner of one css_host_alloc block (page-locked host memory), freed when the last array over it dies."""
+
+    def __init__(self, nbytes: int):
+        self.lib = load()
+        p = C.c_void_p()
+        rc = self.lib.css_host_alloc(max(int(nbytes), 1), C.byref(p))
+        if rc != CSS_OK or not p.value:
+            raise CssError(rc, "css_host_alloc failed")
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.__array_interface__ = {"shape": (max(int(nbytes), 1),), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.lib.css_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array in page-locked host memory (css_host_alloc): css_run* on such buffers moves the samples by DMA,
+    asynchronously, overlapped with the first and last kernels of the pass."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    block = _PinnedBlock(n)
+    return np.asarray(block)[:n].view(dt).reshape(shape)   # the view chain keeps `block` alive
+
+
+def pinned_copy(a: np.ndarray) -> np.ndarray:
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
 class Handle:
     """One model resident on one GPU (css_create .. css_destroy)."""
 
@@ -236,15 +281,31 @@ class Handle:
         except Exception:
             pass
 
+    def stream_ptr(self) -> int:
+        """hipStream_t of the handle (wrap with torch.cuda.ExternalStream to order torch work with its kernels)."""
+        p = C.c_void_p()
+        check(self.h, self.lib.css_get_stream(self.h, C.byref(p)))
+        return int(p.value or 0)
+
+    def set_lanes(self, lanes: int):
+        check(self.h, self.lib.css_set_lanes(self.h, int(lanes)))
+
+    def lanes(self) -> int:
+        return int(self.lib.css_get_lanes(self.h))
+
     # ---- fused path
-    def run(self, pcm: np.ndarray, cfg: RunCfg) -> np.ndarray:
-        """pcm [n, C] float32 host -> wav [S, n_out] float32 host (css/css.py:110)."""
+    def run(self, pcm: np.ndarray, cfg: RunCfg, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """pcm [n, C] float32 host -> wav [S, n_out] float32 host (css/css.py:110).  `out`: an existing [S, >= n_out]
+        float32 array to fill (page-locked buffers from pinned_empty make both PCIe legs asynchronous DMA)."""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         n, c = pcm.shape
         p = plan(self.desc, cfg, n)
-        out = np.empty((self.desc.num_spks, p.n_out), dtype=np.float32)
-        check(self.h, self.lib.css_run(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), p.n_out))
-        return out
+        if out is None:
+            out = np.empty((self.desc.num_spks, p.n_out), dtype=np.float32)
+        assert out.dtype == np.float32 and out.ndim == 2 and out.shape[0] == self.desc.num_spks and out.shape[1] >= p.n_out \
+            and out.strides[1] == 4
+        check(self.h, self.lib.css_run(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), out.strides[0] // 4))
+        return out[:, :p.n_out]
 
     def run_device(self, pcm_ptr: int, n: int, c: int, cfg: RunCfg, wav_ptr: int, cap: int):
         check(self.h, self.lib.css_run_device(self.h, C.c_void_p(pcm_ptr), n, c, C.byref(cfg.c),
@@ -272,6 +333,13 @@ class Handle:
         check(self.h, self.lib.css_get_timings(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in CssTimings._fields_}
 
+    def kernel_stats(self) -> dict:
+        """{family: (ms, launches)} of the last pass run with set_profile(True)"""
+        arr = (CssKernelStat * 32)()
+        cnt = C.c_int32()
+        check(self.h, self.lib.css_get_kernel_stats(self.h, C.cast(arr, C.c_void_p), 32, C.byref(cnt)))
+        return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(min(cnt.value, 32))}
+
     def set_profile(self, enable: bool):
         check(self.h, self.lib.css_set_profile(self.h, int(enable)))
 
@@ -298,6 +366,20 @@ class Handle:
             self._pcm_keep = np.ascontiguousarray(pcm, dtype=np.float32)
             ptr = _np_ptr(self._pcm_keep)
         check(self.h, self.lib.css_begin(self.h, ptr, n, c, C.byref(cfg.c), int(device)))
+
+    def begin_range(self, pcm: np.ndarray, n: int, c: int, cfg: RunCfg, s_lo: int, s_hi: int, slice_only: bool = False):
+        """Session over a host recording of n samples of which only samples [s_lo, s_hi) are uploaded (a rank's slice).
+        slice_only: `pcm` holds just those samples (the library is handed the address sample 0 would have and never
+        reads outside the range)."""
+        assert pcm.dtype == np.float32 and pcm.flags.c_contiguous
+        self._pcm_keep = pcm
+        base = pcm.ctypes.data
+        if slice_only:
+            assert pcm.shape[0] == s_hi - s_lo
+            base -= int(s_lo) * c * 4
+        else:
+            assert pcm.shape[0] == n
+        check(self.h, self.lib.css_begin_range(self.h, C.c_void_p(base), n, c, C.byref(cfg.c), int(s_lo), int(s_hi)))
 
     def stage_stft(self):
         check(self.h, self.lib.css_stage_stft(self.h))

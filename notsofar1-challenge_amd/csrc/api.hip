@@ -6,12 +6,23 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "kernels.hpp"
 
 using namespace css;
+
+// kernel families of the per-launch profile (css_set_profile / css_get_kernel_stats), in the order of the pass
+enum ProfCat : int {
+    CSS_PROF_DEINTERLEAVE = 0, CSS_PROF_STFT, CSS_PROF_FEATURES, CSS_PROF_LINEAR, CSS_PROF_LAYERNORM, CSS_PROF_ATTENTION,
+    CSS_PROF_CONV, CSS_PROF_SCM, CSS_PROF_MVDR_SOLVE, CSS_PROF_BEAMFORM, CSS_PROF_PIT, CSS_PROF_OLA_MASKS, CSS_PROF_GATE,
+    CSS_PROF_OLA_STFT, CSS_PROF_ISTFT_GEMM, CSS_PROF_WAVE_OLA, CSS_PROF_ENCODE, CSS_PROF_COUNT
+};
+static const char* const kProfNames[CSS_PROF_COUNT] = {
+    "deinterleave", "stft", "features", "linear_gemm", "layernorm", "attention", "conv_module", "scm", "mvdr_solve",
+    "beamform", "pit", "ola_masks", "gate", "ola_stft", "istft_gemm", "wave_ola", "encode_pcm16"};
 
 namespace {
 
@@ -51,7 +62,7 @@ struct css_ctx {
     float* blob = nullptr;
     Weights w;
     // Linear-layer arithmetic: split-f16 operands on the f16 matrix cores (float32-grade accuracy, gemm_split.hip) or,
-    // with CSS_EXACT_F32=1 in the environment at css_create, the exact float32 MFMA chain of gemm.hip (A/B tests).
+    // after css_set_linear_mode(h, CSS_LINEAR_EXACT_F32), the exact float32 MFMA chain of gemm.hip.
     bool split = true;
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
@@ -74,8 +85,8 @@ struct css_ctx {
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
     // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two or three chains drift out of
     // phase and fill each other's bubbles (measured: 6.9 -> 6.4 ms per 60 s meeting with two).  Results do not change: every
-    // kernel is batch invariant.  CSS_MASKNET_LANES=1 in the environment at css_create turns it off.
-    // (CSS_MASKNET_LANES=n, 1..4, default 3; lane 0 is `stream` with the buffers above)
+    // kernel is batch invariant.  css_set_lanes(h, 1) turns it off.
+    // (css_set_lanes: 1..4, default 3; lane 0 is `stream` with the buffers above)
     static constexpr int MAX_LANES = 4;
     int lanes = 3;
     hipStream_t lane_stream[MAX_LANES] = {};   // [0] unused
@@ -83,14 +94,25 @@ struct css_ctx {
     DevBuf lfeat[MAX_LANES], lhx[MAX_LANES], lhu[MAX_LANES], lht[MAX_LANES], lqkv[MAX_LANES], lqkf[MAX_LANES], lctx[MAX_LANES];   // [0] unused
     int64_t last_batch_tokens = 0;
     const float* pcm_src = nullptr;  // sample-major PCM on the device for the current session
+    // PCIe pieces of css_run* travel on their own stream, beside the kernels: the upload of the samples a lane's segments
+    // read is followed by that lane's analysis transform and mask-estimator chain while the next piece is in flight, and
+    // finished ranges of the output leave while the last ranges are still being synthesised.
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
+    size_t ev_pool_used = 0;
 
     // timing
     hipEvent_t ev[10]{};
     CssTimings tim{};
+    // css_set_profile: every kernel launch of a pass is bracketed by a pair of HIP events on its stream (one lane, so
+    // that the pairs are ordered); durations are summed per kernel family (css_get_kernel_stats)
     bool profile_gemm = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
-    size_t gemm_events_used = 0;
+    struct ProfEvent { hipEvent_t a, b; int cat; };
+    std::vector<ProfEvent> prof_events;
+    size_t prof_used = 0;
     double gemm_flops = 0.0;
+    float prof_ms[CSS_PROF_COUNT] = {};
+    int32_t prof_launches[CSS_PROF_COUNT] = {};
 
     std::string err;
 };
@@ -214,22 +236,30 @@ int plan_impl(const CssModelDesc& d, const CssRunCfg& cfg, int64_t n, CssPlan* p
     return CSS_OK;
 }
 
-void gemm(css_ctx* h, const GemmArgs& g, hipStream_t st) {
-    if (h->profile_gemm) {
-        if (h->gemm_events_used == h->gemm_events.size()) {
-            hipEvent_t a, b;
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            h->gemm_events.emplace_back(a, b);
+// Scope around one kernel launch: with the profile on, an event pair on the launch's stream, tagged with its family.
+struct Prof {
+    css_ctx* h; hipStream_t st; hipEvent_t stop = nullptr;
+    Prof(css_ctx* h_, int cat, hipStream_t st_) : h(h_), st(st_) {
+        if (!h->profile_gemm) return;
+        if (h->prof_used == h->prof_events.size()) {
+            css_ctx::ProfEvent e{};
+            hipEventCreate(&e.a);
+            hipEventCreate(&e.b);
+            h->prof_events.push_back(e);
         }
-        auto& ev = h->gemm_events[h->gemm_events_used++];
-        hipEventRecord(ev.first, st);
-        launch_gemm(g, st);
-        hipEventRecord(ev.second, st);
-        h->gemm_flops += 2.0 * g.M * (double)g.N * g.K * g.batch;
-    } else {
-        launch_gemm(g, st);
+        css_ctx::ProfEvent& e = h->prof_events[h->prof_used++];
+        e.cat = cat;
+        hipEventRecord(e.a, st);
+        stop = e.b;
     }
+    ~Prof() { if (stop) hipEventRecord(stop, st); }
+};
+#define CSS_PROF(cat, st) Prof prof_scope_(h, cat, st)
+
+void gemm(css_ctx* h, const GemmArgs& g, hipStream_t st) {
+    CSS_PROF(CSS_PROF_LINEAR, st);
+    if (h->profile_gemm) h->gemm_flops += 2.0 * g.M * (double)g.N * g.K * g.batch;
+    launch_gemm(g, st);
 }
 
 GemmArgs linear(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
@@ -390,18 +420,18 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     }
     for (auto& e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(CSS_ERR_HIP, "hipEventCreate failed");
-    if (const char* e = std::getenv("CSS_MASKNET_LANES")) h->lanes = std::min(std::max(std::atoi(e), 1), (int)css_ctx::MAX_LANES);
-    if (h->lanes > 1 && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return bail(CSS_ERR_HIP, "hipEventCreate failed");
-    for (int l = 1; l < h->lanes; ++l)
+    for (int l = 1; l < css_ctx::MAX_LANES; ++l)
         if (hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
             return bail(CSS_ERR_HIP, "lane stream / event could not be created");
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(CSS_ERR_HIP, "copy stream could not be created");
     if (hipMalloc((void**)&h->blob, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(weights) failed");
     if (hipMemcpy(h->blob, blob_host, need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "weight upload failed");
     bind_weights(*desc, h->blob, &h->w);
-    if (const char* e = std::getenv("CSS_EXACT_F32")) h->split = !(e[0] == '1');
     // transform matrices (feature.py:19-45): analysis = Hann * DFT, S = 1; synthesis = sqrt-Hann * DFT / 16
     const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
     std::vector<float> fwd((size_t)2 * F * N), inv((size_t)N * KI, 0.f);
@@ -448,6 +478,8 @@ int css_destroy(css_handle_t h) {
         if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    for (auto& e : h->ev_pool) hipEventDestroy(e);
     if (h->wsplit) hipFree(h->wsplit);
     if (h->dft_split) hipFree(h->dft_split);
     for (auto& b : h->pe_frag)
@@ -456,7 +488,7 @@ int css_destroy(css_handle_t h) {
     if (h->dft_inv_t) hipFree(h->dft_inv_t);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
-    for (auto& pr : h->gemm_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : h->prof_events) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return CSS_OK;
@@ -474,14 +506,15 @@ int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, in
 }
 
 // -------------------------------------------------------------------------------------------------
-int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device) {
-    if (!h || !pcm || !cfg) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+// Opens a session: validates the configuration, fixes the plan, sizes the workspace.  No sample moves here.
+static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg) {
+    if (!h || !cfg) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (n_ch != h->d.num_mics)
         return fail(h, CSS_ERR_SHAPE, "input has " + std::to_string(n_ch) + " channels, the model expects " + std::to_string(h->d.num_mics));
     if (!cfg->w_first || !cfg->w_mid || !cfg->w_last) return fail(h, CSS_ERR_INVALID_ARG, "segment weights missing");
     if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
-    if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256]");
+    if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256] (at most 4 s segments)");
     if (hop <= 0 || 4 * hop < T || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/4 <= hop < T (at most four segments overlap; at least one frame of overlap for the stitching cost)");
     HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};
@@ -502,8 +535,9 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     h->stft_done = h->perms_done = h->have_override = false;
     h->has_session = true;
     h->tim = CssTimings{};
-    h->gemm_events_used = 0;
+    h->prof_used = 0;
     h->gemm_flops = 0.0;
+    h->pcm_src = nullptr;
 
     const int F = h->d.num_bins, S = h->d.num_spks;
     const int64_t nseg = p.num_segments, TL = p.mix_frames;
@@ -531,49 +565,85 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     ENS(wav, (size_t)S * p.n_out * sizeof(float))
     ENS(pnorm, (size_t)nseg * sizeof(double))
     ENS(segw, (size_t)3 * T * sizeof(float))
+#undef ENS
     // (a copy from pageable memory makes the host wait for the stream: paid only when the windows change)
     if (h->w_on_device != h->w_host) {
         HIPCHK(h, hipMemcpyAsync(h->segw.p, h->w_host.data(), 3 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
         h->w_on_device = h->w_host;
     }
-    const float* pcm_dev = pcm;
-    if (!pcm_is_device) {
-        ENS(pcm_in, (size_t)n_samples * n_ch * sizeof(float))
-        HIPCHK(h, hipMemcpyAsync(h->pcm_in.p, pcm, (size_t)n_samples * n_ch * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        pcm_dev = (const float*)h->pcm_in.p;
-    }
-#undef ENS
-    h->pcm_src = pcm_dev;
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+// samples [s_lo, s_hi) of a host recording -> their place in the device copy (pcm_in), on `st`
+static int upload_pcm(css_handle_t h, const float* pcm_host, int64_t s_lo, int64_t s_hi, hipStream_t st) {
+    if (s_hi <= s_lo) return CSS_OK;
+    const size_t row = (size_t)h->n_ch * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync((char*)h->pcm_in.p + (size_t)s_lo * row, (const char*)pcm_host + (size_t)s_lo * row,
+                             (size_t)(s_hi - s_lo) * row, hipMemcpyHostToDevice, st));
+    return CSS_OK;
+}
+
+int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device) {
+    if (!h || !pcm) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (!pcm_is_device) return css_begin_range(h, pcm, n_samples, n_ch, cfg, 0, n_samples);
+    const int rc = begin_impl(h, n_samples, n_ch, cfg);
+    if (rc != CSS_OK) return rc;
+    h->pcm_src = pcm;
+    hipEventRecord(h->ev[1], h->stream);
+    return CSS_OK;
+}
+
+int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                    int64_t s_lo, int64_t s_hi) {
+    if (!h || !pcm_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (s_lo < 0 || s_hi > n_samples || s_lo > s_hi) return fail(h, CSS_ERR_INVALID_ARG, "sample range out of bounds");
+    int rc = begin_impl(h, n_samples, n_ch, cfg);
+    if (rc != CSS_OK) return rc;
+    if ((rc = ensure(h, h->pcm_in, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->stream)) != CSS_OK) return rc;
+    h->pcm_src = (const float*)h->pcm_in.p;
     hipEventRecord(h->ev[1], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
+}
+
+// Analysis transform of frames [t_lo, t_hi) on stream `st`: channel-major copy of exactly the samples these frames read
+// (from the sample-major float PCM, or straight from the session's PCM16 planes), then DFT-matrix x frames.
+// The analysis transform stays on the exact float32 MFMA path in either mode: the 7x7 MVDR solve amplifies
+// rounding noise of X by the condition number of the noise covariance (~200x on the test meetings), and
+// split-f16 operands (22 significant bits) tripled that noise -- measured: waveform distance to the reference
+// on identical decisions 4e-5 -> 1.1e-4.  The synthesis transform has no such amplifier and does use it.
+static void stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* planes16, hipStream_t st) {
+    const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop;
+    const int64_t f_hi = std::min<int64_t>(t_hi, h->plan.stft_frames);
+    if (f_hi <= t_lo) return;
+    const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
+    {
+        CSS_PROF(CSS_PROF_DEINTERLEAVE, st);
+        if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, st);
+        else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
+    }
+    GemmArgs g{};
+    g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
+    g.B = (const float*)h->pcm_cm.p + t_lo * hop; g.ldb = hop; g.strideB = h->n_pad;
+    g.C = (float*)h->X.p + t_lo; g.ldc = h->T_ld; g.strideC = (int64_t)2 * F * h->T_ld;
+    g.M = 2 * F; g.N = (int)(f_hi - t_lo); g.K = N; g.batch = h->n_ch;
+    g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
+    CSS_PROF(CSS_PROF_STFT, st);
+    launch_gemm(g, st);
 }
 
 int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     int rc = check_session(h);
     if (rc) return rc;
     if (t_lo < 0 || t_hi > h->plan.mix_frames || t_lo > t_hi) return fail(h, CSS_ERR_INVALID_ARG, "frame range out of bounds");
+    if (!h->pcm_src) return fail(h, CSS_ERR_STATE, "the session holds no samples");
     HIPCHK(h, hipSetDevice(h->device));
-    const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop;
+    const int F = h->d.num_bins;
     if (h->plan.stft_frames < h->plan.mix_frames && !h->stft_done)  // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
-    const int64_t f_hi = std::min<int64_t>(t_hi, h->plan.stft_frames);
-    if (f_hi > t_lo) {
-        // channel-major copy of exactly the samples these frames read, then DFT-matrix x frames
-        const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
-        // The analysis transform stays on the exact float32 MFMA path in either mode: the 7x7 MVDR solve amplifies
-        // rounding noise of X by the condition number of the noise covariance (~200x on the test meetings), and
-        // split-f16 operands (22 significant bits) tripled that noise -- measured: waveform distance to the reference
-        // on identical decisions 4e-5 -> 1.1e-4.  The synthesis transform has no such amplifier and does use it.
-        launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, h->stream);
-        GemmArgs g{};
-        g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
-        g.B = (const float*)h->pcm_cm.p + t_lo * hop; g.ldb = hop; g.strideB = h->n_pad;
-        g.C = (float*)h->X.p + t_lo; g.ldc = h->T_ld; g.strideC = (int64_t)2 * F * h->T_ld;
-        g.M = 2 * F; g.N = (int)(f_hi - t_lo); g.K = N; g.batch = h->n_ch;
-        g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
-        launch_gemm(g, h->stream);
-    }
+    stft_frames(h, t_lo, t_hi, nullptr, h->stream);
     hipEventRecord(h->ev[2], h->stream);
     HIPCHK(h, hipGetLastError());
     h->stft_done = true;
@@ -616,11 +686,14 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         return g;
     };
     if (ph_lo < 0) {
-        launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
-                        io.hop, sp, st);
+        {
+            CSS_PROF(CSS_PROF_FEATURES, st);
+            launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
+                            io.hop, sp, st);
+        }
         // embed: Linear -> LayerNorm -> ReLU (conformer.py:205-210)
         gemm(h, lin(feat, h->Kp, W.embed_w, W.embed_b, u, D, D, h->Kp, ACT_NONE, 0), st);
-        launch_layernorm(u, x, nullptr, W.embed_ln_w, W.embed_ln_b, M, D, 1, st);
+        { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(u, x, nullptr, W.embed_ln_w, W.embed_ln_b, M, D, 1, st); }
     }
     for (int l = std::max(ph_lo, 0); l < std::min(ph_hi, d.num_blocks); ++l) {
         const BlockWeights& b = W.blocks[l];
@@ -629,7 +702,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         // LayerNorm pair that closed the previous block.
         auto ffn = [&](bool with_ln, const float* xin, const float* lnw, const float* lnb, const float* w1, const float* b1,
                        const float* w2, const float* b2) {
-            if (with_ln) launch_layernorm(xin, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st);
+            if (with_ln) { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(xin, sp ? nullptr : u, sp ? u : nullptr, lnw, lnb, M, D, 0, st); }
             gemm(h, lin(u, D, w1, b1, t1, FF, FF, D, ACT_RELU, FF), st);
             GemmArgs g = lin(t1, FF, w2, b2, x, D, D, FF, ACT_NONE, 0);
             g.residual = xin; g.ldr = D; g.alpha = 0.5f;
@@ -637,14 +710,14 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         };
         ffn(l == 0, x, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
-        launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st);
+        { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st); }
         // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
         {
             GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D);
             if (sp) { g.frag_out = qkf; g.frag_D = D; g.frag_T = T; g.frag_heads = d.attention_heads; g.frag_invT = 1.0f / T; }
             gemm(h, g, st);
         }
-        launch_relpos_attention(qkv, sp ? qkf : nullptr, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
+        { CSS_PROF(CSS_PROF_ATTENTION, st); launch_relpos_attention(qkv, sp ? qkf : nullptr, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st); }
         {
             GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;
@@ -656,6 +729,8 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         // The LayerNorm of the second feed-forward (conformer.py:139) rides on the conv module's output pass.
         const float* xc = cb;
         bool ffo_ln = false;
+        {
+        CSS_PROF(CSS_PROF_CONV, st);
         if (!launch_conv_module(x, cb, b.conv_ln_w, b.conv_ln_b, b.pw, b.dw_wt, b.dw_b, b.bn_alpha, b.bn_beta, b.ffo_ln_w,
                                 b.ffo_ln_b, sp ? nullptr : u, sp ? u : nullptr, nb, T, D, d.kernel_size, st)) {
             launch_ln_glu(x, u, b.conv_ln_w, b.conv_ln_b, b.pw, M, D, st);
@@ -663,14 +738,15 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
             xc = x;
             ffo_ln = true;
         }
+        }
         ffn(ffo_ln, xc, b.ffo_ln_w, b.ffo_ln_b, b.ffo_w1, b.ffo_b1, b.ffo_w2, b.ffo_b2);
         if (!last) {
             // conformer.py:184 and the next block's feed-forward LayerNorm (conformer.py:139) in one pass over x
             const BlockWeights& nb_ = W.blocks[l + 1];
-            launch_layernorm2(x, x, b.fin_ln_w, b.fin_ln_b, sp ? nullptr : u, sp ? u : nullptr, nb_.ffi_ln_w, nb_.ffi_ln_b, M, D, st);
+            { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm2(x, x, b.fin_ln_w, b.fin_ln_b, sp ? nullptr : u, sp ? u : nullptr, nb_.ffi_ln_w, nb_.ffi_ln_b, M, D, st); }
         } else {
             // conformer.py:184; the last block's output also feeds the mask head, as a split operand in u
-            launch_layernorm(x, x, sp ? u : nullptr, b.fin_ln_w, b.fin_ln_b, M, D, 0, st);
+            { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(x, x, sp ? u : nullptr, b.fin_ln_w, b.fin_ln_b, M, D, 0, st); }
         }
     }
     if (ph_hi <= d.num_blocks) return CSS_OK;
@@ -689,34 +765,57 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     return CSS_OK;
 }
 
-// One batched pass of the mask estimator over `nb` segments starting at `s0`: two half batches on two streams
-// (see css_ctx::lanes) unless the per-launch GEMM profile is on, which needs one ordered stream.
-static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
+// How a batch of `nb` segments is cut into lanes: `nl` chains of `per` segments (the last one shorter).
+struct LaneSplit { int nl, per; };
+static LaneSplit lane_split(const css_ctx* h, int nb) {
+    if (h->lanes < 2 || h->profile_gemm || nb < 4 * h->lanes) return {1, nb};   // the per-launch profile needs one ordered stream
+    return {h->lanes, (nb + h->lanes - 1) / h->lanes};
+}
+// A recording's segments [seg_lo, seg_hi) in batches of at most `cap`, equally long (9 x 128 + 57 becomes 10 x 121).
+static int64_t batch_len(int64_t n, int64_t cap) {
+    const int64_t nbat = (n + cap - 1) / cap;
+    return nbat ? (n + nbat - 1) / nbat : 0;
+}
+
+// One batched pass of the mask estimator over `nb` segments starting at `s0`: `lanes` part batches on as many streams
+// (see css_ctx::lanes).  prep(first segment, count, stream), when given, is enqueued at the head of each lane's chain:
+// the fused path puts the analysis transform of the frames that lane is the first to read there (run_impl).
+using LanePrep = std::function<int(int64_t, int, hipStream_t)>;
+static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const LanePrep& prep) {
     const int L = h->d.num_blocks;
     const int sp = h->split ? 1 : 0;
+    int rc;
     if (h->pe_frag_T[sp] != io.T) {   // the attention kernel's position operands depend on the segment length only
-        int rc = ensure(h, h->pe_frag[sp], (size_t)pe_fragment_tiles(io.T) * 2048 * sizeof(float));
-        if (rc) return rc;
+        if ((rc = ensure(h, h->pe_frag[sp], (size_t)pe_fragment_tiles(io.T) * 2048 * sizeof(float))) != CSS_OK) return rc;
         launch_pe_fragments(sp ? h->wsplit + (h->w.pe_k - h->blob) : h->w.pe_k, (float*)h->pe_frag[sp].p, io.T, h->d.maxlen,
                             sp, h->stream);
         h->pe_frag_T[sp] = io.T;
     }
-    if (h->lanes < 2 || h->profile_gemm || nb < 4 * h->lanes) return masknet_lane(h, io, s0, nb, 0, -1, L + 1);
-    const int nl = h->lanes, per = (nb + nl - 1) / nl;   // lane l takes segments [l * per, min((l + 1) * per, nb))
+    const LaneSplit ls = lane_split(h, nb);
+    if (ls.nl == 1) {
+        if ((rc = prep(s0, nb, h->stream)) != CSS_OK) return rc;
+        return masknet_lane(h, io, s0, nb, 0, -1, L + 1);
+    }
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));    // everything the estimator reads is ordered before this
-    for (int l = 1; l < nl; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_fork, 0));
-    int rc;
+    for (int l = 1; l < ls.nl; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_fork, 0));
+    for (int l = 0; l < ls.nl; ++l) {
+        const int lo = l * ls.per, n = std::min(ls.per, nb - lo);
+        if (n > 0 && (rc = prep(s0 + lo, n, l ? h->lane_stream[l] : h->stream)) != CSS_OK) return rc;
+    }
     // the chains are enqueued phase by phase, in turn, so that no stream starts far behind the others
     for (int ph = -1; ph <= L; ++ph)
-        for (int l = 0; l < nl; ++l) {
-            const int lo = l * per, n = std::min(per, nb - lo);
+        for (int l = 0; l < ls.nl; ++l) {
+            const int lo = l * ls.per, n = std::min(ls.per, nb - lo);
             if (n > 0 && (rc = masknet_lane(h, io, s0 + lo, n, l, ph, ph + 1, true)) != CSS_OK) return rc;
         }
-    for (int l = 1; l < nl; ++l) {
+    for (int l = 1; l < ls.nl; ++l) {
         HIPCHK(h, hipEventRecord(h->ev_join[l], h->lane_stream[l]));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[l], 0));
     }
     return CSS_OK;
+}
+static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
+    return masknet_batch(h, io, s0, nb, LanePrep([](int64_t, int, hipStream_t) { return (int)CSS_OK; }));
 }
 
 int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
@@ -726,7 +825,7 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
     const int T = h->cfg.segment_frames;
-    const int64_t cap = std::min<int64_t>(h->max_batch, h->plan.num_segments);
+    const int64_t cap = batch_len(seg_hi - seg_lo, std::min<int64_t>(h->max_batch, h->plan.num_segments));
     MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, (float*)h->masks.p,
               h->plan.num_segments * T};
     for (int64_t s0 = seg_lo; s0 < seg_hi; s0 += cap) {
@@ -746,9 +845,10 @@ int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     if (seg_hi > seg_lo) {
         MvdrArgs a = mvdr_args(h, seg_lo, (int)(seg_hi - seg_lo));
         if (a.use_mvdr) {
-            launch_scm(a, h->stream);
-            launch_mvdr_solve(a, h->stream);
+            { CSS_PROF(CSS_PROF_SCM, h->stream); launch_scm(a, h->stream); }
+            { CSS_PROF(CSS_PROF_MVDR_SOLVE, h->stream); launch_mvdr_solve(a, h->stream); }
         }
+        CSS_PROF(CSS_PROF_BEAMFORM, h->stream);
         launch_beamform(a, h->stream);
         if (h->cfg.normalize_segment_power) launch_segment_power_norm(a, (double*)h->pnorm.p, h->stream);
     }
@@ -764,6 +864,7 @@ int css_stage_pit_costs(css_handle_t h, int64_t b_lo, int64_t b_hi) {
     if (h->cfg.stitching_loss < 0 || h->cfg.stitching_loss > 1 || h->cfg.stitching_input < 0 || h->cfg.stitching_input > 1)
         return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     HIPCHK(h, hipSetDevice(h->device));
+    CSS_PROF(CSS_PROF_PIT, h->stream);
     launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->pit_part.p,
                      (double*)h->costs.p, h->stream);
     HIPCHK(h, hipGetLastError());
@@ -774,6 +875,7 @@ int css_stage_pit_scan(css_handle_t h) {
     int rc = check_session(h);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
+    CSS_PROF(CSS_PROF_PIT, h->stream);
     launch_pit_scan((const double*)h->costs.p, h->plan.num_segments - 1, h->d.num_spks, (int32_t*)h->perms.p, h->stream);
     HIPCHK(h, hipGetLastError());
     h->perms_done = true;
@@ -792,7 +894,7 @@ int css_stage_stitch_masks(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
     if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
-    launch_ola_masks(stitch_args(h), t_lo, t_hi, h->stream);
+    { CSS_PROF(CSS_PROF_OLA_MASKS, h->stream); launch_ola_masks(stitch_args(h), t_lo, t_hi, h->stream); }
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
@@ -802,8 +904,8 @@ int css_stage_stitch_gate(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     if (rc) return rc;
     if (!h->perms_done) return fail(h, CSS_ERR_STATE, "permutations missing: run css_stage_pit_scan or write CSS_BUF_PERMS");
     StitchArgs a = stitch_args(h);
-    launch_morphology(a, t_lo, t_hi, h->stream);
-    launch_ola_stft(a, t_lo, t_hi, h->stream);
+    { CSS_PROF(CSS_PROF_GATE, h->stream); launch_morphology(a, t_lo, t_hi, h->stream); }
+    { CSS_PROF(CSS_PROF_OLA_STFT, h->stream); launch_ola_stft(a, t_lo, t_hi, h->stream); }
     hipEventRecord(h->ev[5], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -834,8 +936,8 @@ static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int6
         g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
         g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
-        launch_gemm(g, h->stream);
-        launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->stream);
+        { CSS_PROF(CSS_PROF_ISTFT_GEMM, h->stream); launch_gemm(g, h->stream); }
+        { CSS_PROF(CSS_PROF_WAVE_OLA, h->stream); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->stream); }
     }
     hipEventRecord(h->ev[6], h->stream);
     HIPCHK(h, hipGetLastError());
@@ -864,88 +966,229 @@ int css_sync(css_handle_t h) {
     return CSS_OK;
 }
 
-// wav16 != nullptr: instead of the float32 waveforms, the peak-normalised PCM16 encoding goes to the host (and the
-// peaks, if asked for)
-static int run_impl(css_handle_t h, const float* pcm, int64_t n, int32_t n_ch, const CssRunCfg* cfg, float* wav,
-                    int64_t cap, int device_io, int16_t* wav16 = nullptr, float* peaks = nullptr) {
+// ---- the fused pass --------------------------------------------------------------------------------------------------
+// Where the samples of a pass come from and where its result goes (exactly one source, exactly one sink).
+struct RunIo {
+    const float* pcm_host = nullptr;             // [n][C] float32 in host memory   (css_run)
+    const float* pcm_dev = nullptr;              // [n][C] float32 in HBM           (css_run_device)
+    const int16_t* const* planes_host = nullptr; // C mono PCM16 planes in host memory (css_run_pcm16)
+    float* wav_host = nullptr;                   // [S][cap] float32
+    float* wav_dev = nullptr;
+    int16_t* wav16_host = nullptr;               // [S][cap] peak-normalised PCM16
+    float* peaks_host = nullptr;
+    int64_t cap = 0;
+};
+
+static hipEvent_t pool_event(css_ctx* h) {
+    if (h->ev_pool_used == h->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_pool_used++];
+}
+
+// One pass of css/css.py:110 separate_and_stitch as a pipeline.  The recording's segments go through the mask estimator
+// in batches, each cut into lanes (css_ctx::lanes); a (batch, lane) UNIT owns the frames no earlier unit reads.  Its
+// samples cross PCIe on the copy stream as one piece; the lane's chain waits for that piece only, transforms the unit's
+// frames, and starts the estimator on its segments while the later pieces are still in flight.  Stitching needs every
+// segment (the permutation scan is sequential, css.py:266-285); after it the gate, the inverse transform and the
+// download run over frame ranges, a finished range leaving while the next one is synthesised.
+static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
-    if (!h || (!wav && !wav16)) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
-    if ((rc = css_begin(h, pcm, n, n_ch, cfg, device_io)) != CSS_OK) return rc;
-    if (cap < h->plan.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(h->plan.n_out) + " samples per stream");
-    const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
-    if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
-    if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if ((rc = begin_impl(h, n, n_ch, cfg)) != CSS_OK) return rc;
+    const CssPlan& pl = h->plan;
+    if (io.cap < pl.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(pl.n_out) + " samples per stream");
+    const int64_t nseg = pl.num_segments, TL = pl.mix_frames;
+    const int S = h->d.num_spks, F = h->d.num_bins, N = h->d.frame_len, fhop = h->d.frame_hop;
+    const int T = h->cfg.segment_frames, hop = h->cfg.hop_frames;
+    const bool from_host = io.pcm_host || io.planes_host;
+    h->ev_pool_used = 0;
+    if (io.pcm_host) {
+        if ((rc = ensure(h, h->pcm_in, (size_t)n * n_ch * sizeof(float))) != CSS_OK) return rc;
+        h->pcm_src = (const float*)h->pcm_in.p;
+    } else if (io.planes_host) {
+        if ((rc = ensure(h, h->in16, (size_t)n * n_ch * sizeof(int16_t))) != CSS_OK) return rc;
+        for (int c = 0; c < n_ch; ++c)
+            if (!io.planes_host[c]) return fail(h, CSS_ERR_INVALID_ARG, "null channel plane");
+    } else {
+        h->pcm_src = io.pcm_dev;
+    }
+    const int16_t* planes_dev = io.planes_host ? (const int16_t*)h->in16.p : nullptr;
+    hipEventRecord(h->ev[1], h->stream);
+    hipEventRecord(h->ev[2], h->stream);   // the analysis transform is part of the lanes' chains (CssTimings.stft = 0)
+
+    // ---- units, their frames and samples
+    struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x; int lane; };
+    std::vector<Unit> units;
+    const int64_t cap = batch_len(nseg, std::min<int64_t>(h->max_batch, nseg));
+    int64_t f_prev = 0, s_prev = 0;
+    for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
+        const int nb = (int)std::min<int64_t>(cap, nseg - s0);
+        const LaneSplit ls = lane_split(h, nb);
+        for (int l = 0; l < ls.nl; ++l) {
+            const int lo = l * ls.per, cnt = std::min(ls.per, nb - lo);
+            if (cnt <= 0) continue;
+            Unit u{};
+            u.seg_lo = s0 + lo; u.n = cnt; u.lane = l;
+            const bool last = u.seg_lo + cnt == nseg;
+            u.f_lo = f_prev;
+            u.f_hi = last ? TL : std::min<int64_t>((u.seg_lo + cnt - 1) * hop + T, TL);
+            const int64_t fr = std::min<int64_t>(u.f_hi, pl.stft_frames);   // frames that exist
+            u.s_lo = s_prev;
+            u.s_hi = last ? n : std::max<int64_t>(s_prev, std::min<int64_t>(fr > 0 ? (fr - 1) * fhop + N : 0, n));
+            f_prev = u.f_hi; s_prev = u.s_hi;
+            u.up = from_host ? pool_event(h) : nullptr;
+            u.x = pool_event(h);
+            units.push_back(u);
+        }
+    }
+    // ---- PCIe pieces, in unit order, on the copy stream (after whatever the previous pass still reads there)
+    if (from_host) {
+        hipEvent_t start = pool_event(h);
+        HIPCHK(h, hipEventRecord(start, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, start, 0));
+        for (const Unit& u : units) {
+            if (io.pcm_host) {
+                if ((rc = upload_pcm(h, io.pcm_host, u.s_lo, u.s_hi, h->copy_stream)) != CSS_OK) return rc;
+            } else if (u.s_hi > u.s_lo) {
+                for (int c = 0; c < n_ch; ++c)
+                    HIPCHK(h, hipMemcpyAsync((int16_t*)h->in16.p + (size_t)c * n + u.s_lo, io.planes_host[c] + u.s_lo,
+                                             (size_t)(u.s_hi - u.s_lo) * sizeof(int16_t), hipMemcpyHostToDevice, h->copy_stream));
+            }
+            HIPCHK(h, hipEventRecord(u.up, h->copy_stream));
+        }
+    }
+    if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
+        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+    // ---- the estimator, unit by unit
+    MaskIo mio{(const float*)h->X.p, h->T_ld, pl.stft_frames, hop, T, (float*)h->masks.p, nseg * T};
+    size_t ui = 0;
+    const LanePrep prep = [&](int64_t seg_lo, int cnt, hipStream_t st) -> int {
+        Unit& u = units[ui];
+        if (u.seg_lo != seg_lo || u.n != cnt) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
+        if (u.up) HIPCHK(h, hipStreamWaitEvent(st, u.up, 0));
+        // this unit's segments also read frames (and its transform samples) that the units just before it produced on
+        // other streams: a frame is read by at most four segments, a batch has at most MAX_LANES lanes
+        for (size_t k = ui >= (size_t)css_ctx::MAX_LANES ? ui - css_ctx::MAX_LANES : 0; k < ui; ++k)
+            HIPCHK(h, hipStreamWaitEvent(st, units[k].x, 0));
+        stft_frames(h, u.f_lo, u.f_hi, planes_dev, st);
+        HIPCHK(h, hipEventRecord(u.x, st));
+        ++ui;
+        return CSS_OK;
+    };
+    for (int64_t s0 = 0; s0 < nseg; s0 += cap)
+        if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep)) != CSS_OK) return rc;
+    h->stft_done = true;
+    hipEventRecord(h->ev[3], h->stream);
+    // ---- everything that needs all segments
     if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
     if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
     if ((rc = css_stage_pit_scan(h)) != CSS_OK) return rc;
-    if ((rc = css_stage_stitch(h, 0, TL)) != CSS_OK) return rc;
-    if ((rc = css_stage_istft(h, 0, TL)) != CSS_OK) return rc;
-    const int S = h->d.num_spks;
-    if (wav16) {
-        const int64_t n_out = h->plan.n_out;
-        const size_t need16 = (size_t)S * n_out * sizeof(int16_t) + 64;
-        if ((rc = ensure(h, h->enc, need16)) != CSS_OK) return rc;
+    if ((rc = css_stage_stitch_masks(h, 0, TL)) != CSS_OK) return rc;
+    const StitchArgs sa = stitch_args(h);
+    { CSS_PROF(CSS_PROF_GATE, h->stream); launch_morphology(sa, 0, TL, h->stream); }
+    // ---- gate, inverse transform and download by frame range
+    const int nchunk = (io.wav_host && TL >= 256) ? 4 : 1;
+    hipEvent_t tail = nullptr;
+    for (int c = 0; c < nchunk; ++c) {
+        const int64_t t_lo = TL * c / nchunk, t_hi = TL * (c + 1) / nchunk;
+        { CSS_PROF(CSS_PROF_OLA_STFT, h->stream); launch_ola_stft(sa, t_lo, t_hi, h->stream); }
+        if (c == nchunk - 1) hipEventRecord(h->ev[5], h->stream);
+        if ((rc = css_stage_istft(h, t_lo, t_hi)) != CSS_OK) return rc;   // reads frame t_lo - 1 of the previous range
+        if (io.wav_host) {
+            const int64_t a = t_lo * fhop, b = (t_hi == TL) ? pl.n_out : t_hi * fhop;
+            hipEvent_t done = pool_event(h);
+            HIPCHK(h, hipEventRecord(done, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
+            HIPCHK(h, hipMemcpy2DAsync(io.wav_host + a, (size_t)io.cap * sizeof(float), (const float*)h->wav.p + a,
+                                       (size_t)pl.n_out * sizeof(float), (size_t)(b - a) * sizeof(float), S,
+                                       hipMemcpyDeviceToHost, h->copy_stream));
+            if (c == nchunk - 1) {
+                tail = pool_event(h);
+                HIPCHK(h, hipEventRecord(tail, h->copy_stream));
+            }
+        }
+    }
+    if (io.wav16_host) {
+        const int64_t n_out = pl.n_out;
+        if ((rc = ensure(h, h->enc, (size_t)S * n_out * sizeof(int16_t) + 64)) != CSS_OK) return rc;
         unsigned int* pk = (unsigned int*)h->enc.p;
         int16_t* o16 = (int16_t*)((char*)h->enc.p + 64);
-        launch_encode_pcm16((const float*)h->wav.p, S, n_out, pk, o16, n_out, h->stream);
-        HIPCHK(h, hipMemcpy2DAsync(wav16, (size_t)cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
+        { CSS_PROF(CSS_PROF_ENCODE, h->stream); launch_encode_pcm16((const float*)h->wav.p, S, n_out, pk, o16, n_out, h->stream); }
+        HIPCHK(h, hipMemcpy2DAsync(io.wav16_host, (size_t)io.cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
                                    (size_t)n_out * sizeof(int16_t), S, hipMemcpyDeviceToHost, h->stream));
-        if (peaks) HIPCHK(h, hipMemcpyAsync(peaks, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    } else {
-        HIPCHK(h, hipMemcpy2DAsync(wav, (size_t)cap * sizeof(float), h->wav.p, (size_t)h->plan.n_out * sizeof(float),
-                                   (size_t)h->plan.n_out * sizeof(float), S,
-                                   device_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (io.peaks_host) HIPCHK(h, hipMemcpyAsync(io.peaks_host, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    } else if (io.wav_dev) {
+        HIPCHK(h, hipMemcpy2DAsync(io.wav_dev, (size_t)io.cap * sizeof(float), h->wav.p, (size_t)pl.n_out * sizeof(float),
+                                   (size_t)pl.n_out * sizeof(float), S, hipMemcpyDeviceToDevice, h->stream));
     }
+    if (tail) HIPCHK(h, hipStreamWaitEvent(h->stream, tail, 0));
     hipEventRecord(h->ev[7], h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
     auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
     CssTimings& t = h->tim;
     t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = ms(3, 4); t.stitch = ms(4, 5);
     t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
     t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
+    for (int c = 0; c < CSS_PROF_COUNT; ++c) { h->prof_ms[c] = 0.f; h->prof_launches[c] = 0; }
     if (h->profile_gemm) {
-        for (size_t i = 0; i < h->gemm_events_used; ++i) {
+        for (size_t i = 0; i < h->prof_used; ++i) {
             float v = 0.f;
-            hipEventElapsedTime(&v, h->gemm_events[i].first, h->gemm_events[i].second);
-            t.gemm_ms += v;
+            hipEventElapsedTime(&v, h->prof_events[i].a, h->prof_events[i].b);
+            h->prof_ms[h->prof_events[i].cat] += v;
+            h->prof_launches[h->prof_events[i].cat] += 1;
         }
-        t.gemm_launches = (int64_t)h->gemm_events_used;
+        t.gemm_ms = h->prof_ms[CSS_PROF_LINEAR];
+        t.gemm_launches = h->prof_launches[CSS_PROF_LINEAR];
     }
     return CSS_OK;
 }
 
 int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, float* wav_host,
             int64_t cap) {
-    return run_impl(h, pcm_host, n_samples, n_ch, cfg, wav_host, cap, 0);
+    if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap;
+    return run_impl(h, n_samples, n_ch, cfg, io);
 }
 
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                    float* wav_dev, int64_t cap) {
-    return run_impl(h, pcm_dev, n_samples, n_ch, cfg, wav_dev, cap, 1);
+    if (!h || !pcm_dev || !wav_dev) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    RunIo io; io.pcm_dev = pcm_dev; io.wav_dev = wav_dev; io.cap = cap;
+    return run_impl(h, n_samples, n_ch, cfg, io);
 }
 
 int css_run_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                   int16_t* wav_pcm16_host, int64_t cap, float* peaks_host) {
     if (!h || !planes_host || !wav_pcm16_host || n_samples < 1 || n_ch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
-    HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const size_t plane_b = (size_t)n_samples * sizeof(int16_t);
-    if ((rc = ensure(h, h->in16, plane_b * n_ch)) != CSS_OK) return rc;
-    if ((rc = ensure(h, h->pcm_f, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
-    hipEventRecord(h->ev[8], h->stream);
-    for (int c = 0; c < n_ch; ++c) {
-        if (!planes_host[c]) return fail(h, CSS_ERR_INVALID_ARG, "null channel plane");
-        HIPCHK(h, hipMemcpyAsync((char*)h->in16.p + plane_b * c, planes_host[c], plane_b, hipMemcpyHostToDevice, h->stream));
-    }
-    launch_pcm16_to_float((const int16_t*)h->in16.p, (float*)h->pcm_f.p, n_samples, n_ch, h->stream);
-    rc = run_impl(h, (const float*)h->pcm_f.p, n_samples, n_ch, cfg, nullptr, cap, 1, wav_pcm16_host, peaks_host);
-    if (rc == CSS_OK) {   // the upload of the planes counts as upload time
-        float v = 0.f;
-        hipEventElapsedTime(&v, h->ev[8], h->ev[0]);
-        h->tim.upload += v; h->tim.total += v;
-    }
-    return rc;
+    RunIo io; io.planes_host = planes_host; io.wav16_host = wav_pcm16_host; io.peaks_host = peaks_host; io.cap = cap;
+    return run_impl(h, n_samples, n_ch, cfg, io);
 }
+
+int css_get_stream(css_handle_t h, void** stream_out) {
+    if (!h || !stream_out) return CSS_ERR_INVALID_ARG;
+    *stream_out = (void*)h->stream;
+    return CSS_OK;
+}
+
+int css_set_lanes(css_handle_t h, int lanes) {
+    if (!h || lanes < 1 || lanes > css_ctx::MAX_LANES) return fail(h, CSS_ERR_INVALID_ARG, "lanes must be in [1, 4]");
+    h->lanes = lanes;   // the lanes' activation buffers are sized by the next css_begin / css_run* / css_*_host call
+    return CSS_OK;
+}
+
+int css_get_lanes(css_handle_t h) { return h ? h->lanes : (int)CSS_ERR_INVALID_ARG; }
+
+int css_host_alloc(size_t bytes, void** out) {
+    if (!out) return CSS_ERR_INVALID_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? CSS_OK : CSS_ERR_HIP;
+}
+
+int css_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? CSS_OK : CSS_ERR_HIP; }
 
 int css_set_linear_mode(css_handle_t h, int mode) {
     if (!h || (mode != CSS_LINEAR_SPLIT_F16 && mode != CSS_LINEAR_EXACT_F32)) return fail(h, CSS_ERR_INVALID_ARG, "unknown linear mode");
@@ -972,6 +1215,22 @@ int css_get_linear_mode(css_handle_t h) {
 int css_set_profile(css_handle_t h, int enable) {
     if (!h) return CSS_ERR_INVALID_ARG;
     h->profile_gemm = enable != 0;
+    return CSS_OK;
+}
+
+int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_t* count) {
+    if (!h || !count || (cap > 0 && !out)) return CSS_ERR_INVALID_ARG;
+    int n = 0;
+    for (int c = 0; c < CSS_PROF_COUNT; ++c) {
+        if (!h->prof_launches[c]) continue;
+        if (n < cap) {
+            std::snprintf(out[n].name, sizeof(out[n].name), "%s", kProfNames[c]);
+            out[n].ms = h->prof_ms[c];
+            out[n].launches = h->prof_launches[c];
+        }
+        ++n;
+    }
+    *count = n;
     return CSS_OK;
 }
 

@@ -492,16 +492,21 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // (tb[step % 3]; `step` is a compile-time constant after unrolling, so no copies: the earlier cur = nxt copy made
     // the wave wait for a tile one step after requesting it, and with one wave per SIMD the L2 latency of every one
     // of the 2 NJT + 1 tiles was exposed).
-    constexpr int NS = 2 * NJT + 1;
+    // A one-tile segment (T <= 32, NJT = 1) sees only the offset tiles 1 and 0 (offsets below -(T - 1) belong to masked
+    // keys), so its prologue has two offset tiles, not three: NPRO offset tiles, then NJT key tiles with NI offset tiles
+    // interleaved.
+    constexpr int NPRO = NJT >= 2 ? 3 : 2;
+    constexpr int NI = NJT >= 2 ? NJT - 2 : 0;
+    constexpr int NS = NPRO + NJT + NI;
     // step s_ (a compile-time constant wherever it is used): offset tile (first) or key tile (second), -1 = not that kind
     auto step_rt = [](int s_) {
-        if (s_ < 3) return RT0 - s_;
-        const int u_ = s_ - 3;
-        return (u_ < 2 * (NJT - 2) && (u_ & 1)) ? RT0 - 3 - (u_ >> 1) : -1;
+        if (s_ < NPRO) return RT0 - s_;
+        const int u_ = s_ - NPRO;
+        return (u_ < 2 * NI && (u_ & 1)) ? RT0 - 3 - (u_ >> 1) : -1;
     };
     auto step_jt = [](int s_) {
-        const int u_ = s_ - 3;
-        return u_ < 2 * (NJT - 2) ? (u_ >> 1) : NJT - 2 + (u_ - 2 * (NJT - 2));
+        const int u_ = s_ - NPRO;
+        return u_ < 2 * NI ? (u_ >> 1) : NI + (u_ - 2 * NI);
     };
 #define CSS_ATT_LOAD_STEP(dst, s_)                                                                         \
     {                                                                                                      \
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     CSS_ATT_LOAD_STEP(tb[0], 0)
     CSS_ATT_LOAD_STEP(tb[1], 1)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NPRO; ++u) {
         const int rt = RT0 - u;
         f32x16 acc;
         CSS_ATT_STEP(acc)

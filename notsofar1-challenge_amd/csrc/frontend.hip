@@ -67,6 +67,23 @@ void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, 
     hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes, pcm, n, C);
 }
 
+// the same scaling straight into the channel-major frame buffer [C][n_pad] (zeros past n), samples [i_lo, i_hi): planes
+// are already channel-major, so the wav edge needs no sample-major detour
+__global__ void pcm16_to_cm_kernel(const int16_t* __restrict__ planes, float* __restrict__ out, int64_t n, int64_t n_pad,
+                                   int64_t i_lo, int64_t i_hi) {
+    const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i_hi) return;
+    const int c = blockIdx.y;
+    out[(int64_t)c * n_pad + i] = i < n ? (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f) : 0.f;
+}
+
+void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
+                                   int64_t i_hi, hipStream_t s) {
+    if (i_hi <= i_lo) return;
+    hipLaunchKernelGGL(pcm16_to_cm_kernel, dim3((unsigned)((i_hi - i_lo + 255) / 256), C), dim3(256), 0, s, planes, pcm_cm, n,
+                       n_pad, i_lo, i_hi);
+}
+
 // peak[s] = max |wav[s][:]| (as float bits: non-negative floats order like unsigned integers; peak zeroed by the caller)
 __global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ wav, int64_t n, unsigned int* __restrict__ peak) {
     const int s = blockIdx.y;

@@ -101,6 +101,8 @@ void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int6
 // wav edges on the device: C mono PCM16 planes [C][n] -> sample-major float32 [n][C]; and peak-normalised PCM16
 // encoding of the S output streams (peak_bits: S words of scratch, holds max|x| as float bits afterwards)
 void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s);
+void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
+                                   int64_t i_hi, hipStream_t s);
 void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
                          hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows

@@ -13,16 +13,22 @@ not depend on the number of ranks:
 
 Exchanges (all tiny except the last; `torch.distributed`, backend "nccl" = RCCL on ROCm, "gloo" in CPU tests):
   1. raw 3x3 PIT cost matrices of the boundaries each rank owns (all-gather, 72 B per boundary); every
-     rank then replays the sequential permutation scan of css.py:266-285 identically;
+     rank then replays the sequential permutation scan of css.py:266-285 identically, on its GPU;
   2. thresholded activity bits of the frames each rank owns (all-gather, 3 B per frame), because the
      dilate/erode gate (css.py:305-308) looks 36 frames to either side;
   3. the separated-waveform shards (all-gather, 3 x 4 B per sample): each rank inverse-transforms only
      its own frames, so adjacent shards overlap by one hop (256 samples) where the two-frame
      overlap-add crosses the rank boundary; the stitch adds the two partial blocks (a two-term
      float sum commutes, so the result is bit-identical to the single-GPU run).
+
+Nothing of this touches the host between the upload of a rank's samples and the download of the result: the
+pieces are zero-copy torch views of the handle's own device buffers (costs, activity bits), the collectives and
+the few packing / unpacking copies are enqueued on the handle's HIP stream (wrapped as a torch ExternalStream),
+and the permutation scan runs on the device.  The host only enqueues.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 from typing import List
 
@@ -58,6 +64,12 @@ class ShardPlan:
     def sample_lo(self) -> int:
         return self.t_lo * self.hop_samples
 
+    def pcm_range(self, frame_len: int, n_samples: int):
+        """samples of the recording the frames [f_lo, f_hi) read: what this rank uploads"""
+        if self.f_hi <= self.f_lo:
+            return 0, 0
+        return self.f_lo * self.hop_samples, min((self.f_hi - 1) * self.hop_samples + frame_len, n_samples)
+
 
 def make_shard_plan(num_segments: int, mix_frames: int, stft_frames: int, seg_frames: int, hop_frames: int,
                     hop_samples: int, rank: int, world: int) -> ShardPlan:
@@ -82,8 +94,17 @@ def all_plans(num_segments, mix_frames, stft_frames, seg_frames, hop_frames, hop
             for r in range(world)]
 
 
+class _DeviceArray:
+    """A device buffer of the handle as something torch.as_tensor can wrap without copying."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
 class HipShardBackend:
-    """Stage calls of one rank on its GPU (the C ABI's css_stage_* entry points)."""
+    """Stage calls of one rank on its GPU (the C ABI's css_stage_* entry points), plus torch views of the two device
+    buffers the exchanges read and write.  Everything is enqueued on the handle's own HIP stream."""
 
     def __init__(self, handle, torch_device, comm_device=None):
         """`comm_device`: where the process group exchanges tensors -- the GPU itself for "nccl" (RCCL over
@@ -93,11 +114,21 @@ class HipShardBackend:
         self.dev = torch_device
         self.comm_dev = comm_device if comm_device is not None else torch_device
         self.torch = torch
+        self.stream = torch.cuda.ExternalStream(handle.stream_ptr(), device=torch_device)
+        self._scratch = {}
+        self._keep = None
 
-    def begin(self, pcm, n, c, run_cfg):
+    def on_stream(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def begin(self, pcm, n, c, run_cfg, sample_range=None, slice_only=False):
+        """pcm: a device tensor [n, c] (resident input), or a float32 numpy array in host memory, of which only
+        `sample_range` (default: everything) is uploaded; slice_only: the array holds just that range."""
+        self._keep = pcm
         if hasattr(pcm, "data_ptr"):
-            self._pcm_keep = pcm
             self.h.begin(pcm.data_ptr(), n, c, run_cfg, device=True)
+        elif sample_range is not None:
+            self.h.begin_range(pcm, n, c, run_cfg, sample_range[0], sample_range[1], slice_only)
         else:
             self.h.begin(pcm, n, c, run_cfg, device=False)
 
@@ -108,139 +139,171 @@ class HipShardBackend:
     def masknet(self, lo, hi): self.h.stage_masknet(lo, hi)
     def mvdr(self, lo, hi): self.h.stage_mvdr(lo, hi)
     def pit_costs(self, lo, hi): self.h.stage_pit_costs(lo, hi)
+    def pit_scan(self): self.h.stage_pit_scan()
     def stitch_masks(self, lo, hi): self.h.stage_stitch_masks(lo, hi)
     def stitch_gate(self, lo, hi): self.h.stage_stitch_gate(lo, hi)
 
-    def read_costs(self):
+    def _view(self, which, typestr):
+        dims, _ = self.h.buffer_dims(which)
+        return self.torch.as_tensor(_DeviceArray(self.h.devptr(which), dims, typestr), device=self.dev)
+
+    def costs_view(self):
+        """raw PIT costs [num_segments - 1, S*S] float64, in place on the device"""
         from . import _lib
-        return self.h.read(_lib.BUF_PIT_COST)
+        return self._view(_lib.BUF_PIT_COST, "<f8")
 
-    def write_perms(self, perms):
+    def act_view(self):
+        """thresholded activity [S, T_long] uint8, in place on the device"""
         from . import _lib
-        self.h.write(_lib.BUF_PERMS, perms)
+        return self._view(_lib.BUF_ACT_B, "|u1")
 
-    def read_act_b(self):
-        from . import _lib
-        return self.h.read(_lib.BUF_ACT_B)
+    def istft_partial(self, lo, hi, out):
+        self.h.stage_istft_partial(lo, hi, out.data_ptr(), out.stride(0))
 
-    def write_act_b(self, act):
-        from . import _lib
-        self.h.write(_lib.BUF_ACT_B, act)
+    def scratch(self, name, shape, dtype):
+        """persistent work tensors (send / receive pieces, index maps): allocated once per shape"""
+        key = (name, tuple(shape), dtype)
+        t = self._scratch.get(key)
+        if t is None:
+            t = self._scratch[key] = self.torch.empty(tuple(shape), dtype=dtype, device=self.dev)
+        return t
 
-    def istft_partial(self, lo, hi, num_spks, shard_len):
-        out = self.torch.zeros((num_spks, shard_len), dtype=self.torch.float32, device=self.dev)
-        self.torch.cuda.synchronize(self.dev)  # zeros are written on torch's stream, the kernels on the handle's
-        self.h.stage_istft_partial(lo, hi, out.data_ptr(), shard_len)
-        self.h.sync()
-        return out.to(self.comm_dev)
-
-    def pit_scan(self, costs, num_spks):
-        from . import _lib
-        return _lib.pit_scan(costs, num_spks)
-
-    def to_comm(self, arr):
-        """numpy -> tensor on the device the process group communicates from"""
-        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.comm_dev)
-
-
-def _all_gather(dist, tensor, world):
-    import torch
-    outs = [torch.empty_like(tensor) for _ in range(world)]
-    dist.all_gather(outs, tensor)
-    return outs
+    def index_tensor(self, name, values: np.ndarray):
+        key = (name, values.shape, hash(values.tobytes()))
+        t = self._scratch.get(key)
+        if t is None:
+            t = self._scratch[key] = self.torch.from_numpy(values).to(self.dev)
+        return t
 
 
 class ShardedSession:
-    """One rank's share of a session that `backend.begin(...)` has opened, as three phases separated by
-    the three exchanges.  `sharded_separate_and_stitch` drives them over torch.distributed; tests drive the
-    same phases for several virtual ranks in one process."""
+    """One rank's share of a session that `backend.begin(...)` has opened, as three phases separated by the three
+    exchanges.  A phase returns the piece this rank contributes (padded to the size of the largest rank's, so that the
+    all-gather is regular); the next phase takes the gathered pieces `[world, ...]`.  `sharded_separate_and_stitch`
+    chains them over torch.distributed; tests chain them for several virtual ranks in one process."""
 
     def __init__(self, backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int, rank: int,
                  world: int):
+        import torch
+        self.torch = torch
         self.be, self.S, self.rank, self.world = backend, num_spks, rank, world
         plan = backend.plan()
         self.nseg, self.TL, self.n_out = int(plan.num_segments), int(plan.mix_frames), int(plan.n_out)
         self.plans = all_plans(self.nseg, self.TL, int(plan.stft_frames), seg_frames, hop_frames, hop_samples, world)
         self.me = self.plans[rank]
+        self.hop_samples = hop_samples
+        self.max_b = max(max(p.b_hi - p.b_lo for p in self.plans), 1)
+        self.max_t = max(max(p.num_frames for p in self.plans), 1)
+        self.max_len = max(p.shard_len for p in self.plans)
+
+    def _ctx(self):
+        return self.be.on_stream() if hasattr(self.be, "on_stream") else contextlib.nullcontext()
+
+    def _gather_index(self, name, lo_hi, width, total):
+        """position of element e (owned by the rank whose [lo, hi) holds it) inside the gathered [world, width] pieces"""
+        idx = np.zeros(total, dtype=np.int64)
+        for r, (lo, hi) in enumerate(lo_hi):
+            idx[lo:hi] = r * width + np.arange(hi - lo)
+        return self.be.index_tensor(name, idx)
 
     # phase 1: everything per segment, then the raw PIT costs of the owned boundaries
-    def segments_and_costs(self) -> np.ndarray:
-        me, be = self.me, self.be
-        be.stft_range(me.f_lo, me.f_hi)
-        be.masknet(me.seg_lo, me.seg_hi)
-        be.mvdr(me.seg_lo, me.seg_hi)
-        be.pit_costs(me.b_lo, me.b_hi)
-        costs = np.asarray(be.read_costs(), dtype=np.float64).reshape(-1, self.S * self.S)
-        return costs[me.b_lo:me.b_hi].copy()
-
-    @staticmethod
-    def join_costs(plans, pieces) -> np.ndarray:
-        return np.concatenate([np.asarray(pieces[r])[:plans[r].b_hi - plans[r].b_lo] for r in range(len(plans))], axis=0)
+    def segments_and_costs(self):
+        me, be, torch = self.me, self.be, self.torch
+        with self._ctx():
+            be.stft_range(me.f_lo, me.f_hi)
+            be.masknet(me.seg_lo, me.seg_hi)
+            be.mvdr(me.seg_lo, me.seg_hi)
+            be.pit_costs(me.b_lo, me.b_hi)
+            if self.world == 1:
+                return None
+            send = be.scratch("send_costs", (self.max_b, self.S * self.S), torch.float64)
+            if me.b_hi > me.b_lo:
+                send[:me.b_hi - me.b_lo].copy_(be.costs_view()[me.b_lo:me.b_hi])
+            return send
 
     # phase 2: identical permutation scan on every rank, overlap-add of the masks, activity bits
-    def masks_and_activity(self, all_costs: np.ndarray) -> np.ndarray:
-        assert all_costs.shape[0] == max(self.nseg - 1, 0), (all_costs.shape, self.nseg)
-        self.be.write_perms(self.be.pit_scan(all_costs, self.S))
-        self.be.stitch_masks(self.me.t_lo, self.me.t_hi)
-        act = np.asarray(self.be.read_act_b(), dtype=np.uint8)  # [S, T_long]; only the owned columns are valid
-        return act[:, self.me.t_lo:self.me.t_hi].copy()
-
-    @staticmethod
-    def join_activity(plans, pieces) -> np.ndarray:
-        return np.concatenate([np.asarray(pieces[r])[:, :plans[r].num_frames] for r in range(len(plans))], axis=1)
+    def masks_and_activity(self, all_costs):
+        me, be, torch = self.me, self.be, self.torch
+        with self._ctx():
+            if self.world > 1:
+                assert tuple(all_costs.shape) == (self.world, self.max_b, self.S * self.S), all_costs.shape
+                if self.nseg > 1:
+                    idx = self._gather_index("idx_costs", [(p.b_lo, p.b_hi) for p in self.plans], self.max_b, self.nseg - 1)
+                    be.costs_view()[:self.nseg - 1].copy_(all_costs.reshape(-1, self.S * self.S).index_select(0, idx))
+            be.pit_scan()
+            be.stitch_masks(me.t_lo, me.t_hi)
+            if self.world == 1:
+                return None
+            send = be.scratch("send_act", (self.S, self.max_t), torch.uint8)
+            if me.num_frames:
+                send[:, :me.num_frames].copy_(be.act_view()[:, me.t_lo:me.t_hi])
+            return send
 
     # phase 3: gate + partial inverse transform of the owned frames
-    def gate_and_istft(self, all_act: np.ndarray):
-        assert all_act.shape == (self.S, self.TL), all_act.shape
-        self.be.write_act_b(all_act)
-        self.be.stitch_gate(self.me.t_lo, self.me.t_hi)
-        return self.be.istft_partial(self.me.t_lo, self.me.t_hi, self.S, self.me.shard_len)
+    def gate_and_istft(self, all_act):
+        me, be, torch = self.me, self.be, self.torch
+        with self._ctx():
+            if self.world > 1:
+                assert tuple(all_act.shape) == (self.world, self.S, self.max_t), all_act.shape
+                idx = self._gather_index("idx_act", [(p.t_lo, p.t_hi) for p in self.plans], self.max_t, self.TL)
+                be.act_view().copy_(all_act.permute(1, 0, 2).reshape(self.S, -1).index_select(1, idx))
+            be.stitch_gate(me.t_lo, me.t_hi)
+            shard = be.scratch("send_wav", (self.S, self.max_len), torch.float32)
+            be.istft_partial(me.t_lo, me.t_hi, shard)
+            return shard
 
-    @staticmethod
-    def join_shards(plans, shards, num_spks: int, n_out: int):
-        """Place every rank's shard at its sample offset; the one-hop overlaps at the seams add up."""
-        import torch
-        out = torch.zeros((num_spks, n_out), dtype=shards[0].dtype, device=shards[0].device)
-        for r, p in enumerate(plans):
-            if p.num_frames == 0:
-                continue
-            cut = min(p.shard_len, n_out - p.sample_lo)
-            out[:, p.sample_lo:p.sample_lo + cut] += shards[r][:, :cut]
-        return out
+    def join_shards(self, all_shards, out=None):
+        """Place every rank's shard at its sample offset: a rank's inner output blocks are its own, the block at a seam
+        is the sum of the left rank's last and the right rank's first block (one frame's contribution each)."""
+        torch, hop = self.torch, self.hop_samples
+        with self._ctx():
+            if out is None:
+                out = torch.empty((self.S, self.n_out), dtype=all_shards.dtype, device=all_shards.device)
+            live = [p for p in self.plans if p.num_frames > 0]
+            for k, p in enumerate(live):
+                sh = all_shards[p.rank]
+                lo, ln = p.sample_lo, min(p.shard_len, self.n_out - p.sample_lo)
+                if k == 0:
+                    out[:, lo:lo + hop].copy_(sh[:, :hop])
+                else:
+                    q = live[k - 1]
+                    torch.add(all_shards[q.rank][:, q.shard_len - hop:q.shard_len], sh[:, :hop], out=out[:, lo:lo + hop])
+                out[:, lo + hop:lo + ln].copy_(sh[:, hop:ln])
+            return out
+
+
+def _all_gather(dist, send, world, comm_dev):
+    """[...] on every rank -> [world, ...]; through host memory when the process group lives there (gloo)"""
+    import torch
+    src = send if send.device == comm_dev else send.to(comm_dev)
+    recv = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(recv, src.contiguous())
+    else:
+        dist.all_gather(list(recv.unbind(0)), src.contiguous())
+    return recv if recv.device == send.device else recv.to(send.device)
 
 
 def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int,
-                                rank: int, world: int, dist=None):
+                                rank: int, world: int, dist=None, out=None):
     """Runs one rank's share of a session that `backend.begin(...)` has opened and returns the full
-    separated waveforms [S, n_out] (a tensor on the backend's communication device), identical on every
-    rank and identical to the single-rank result."""
-    import torch
+    separated waveforms [S, n_out] (a tensor on the backend's device), identical on every
+    rank and identical to the single-rank result.  Asynchronous on the backend's stream."""
     ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world)
-    plans, me = ss.plans, ss.me
-    S2 = num_spks * num_spks
-
-    mine = ss.segments_and_costs()
-    if world > 1:
-        send = np.zeros((max(max(p.b_hi - p.b_lo for p in plans), 1), S2), dtype=np.float64)
-        send[:mine.shape[0]] = mine
-        got = _all_gather(dist, backend.to_comm(send), world)
-        all_costs = ss.join_costs(plans, [g.cpu().numpy() for g in got])
-    else:
-        all_costs = mine
-
-    act = ss.masks_and_activity(all_costs)
-    if world > 1:
-        send = np.zeros((num_spks, max(max(p.num_frames for p in plans), 1)), dtype=np.uint8)
-        send[:, :act.shape[1]] = act
-        got = _all_gather(dist, backend.to_comm(send), world)
-        all_act = ss.join_activity(plans, [g.cpu().numpy() for g in got])
-    else:
-        all_act = act
-
-    shard = ss.gate_and_istft(all_act)
-    if world == 1:
-        return shard[:, :ss.n_out]
-    send = torch.zeros((num_spks, max(p.shard_len for p in plans)), dtype=shard.dtype, device=shard.device)
-    send[:, :me.shard_len] = shard
-    got = _all_gather(dist, send, world)
-    return ss.join_shards(plans, got, num_spks, ss.n_out)
+    comm_dev = getattr(backend, "comm_dev", None)
+    ctx = ss._ctx()
+    with ctx:
+        costs = ss.segments_and_costs()
+        if world > 1:
+            costs = _all_gather(dist, costs, world, comm_dev if comm_dev is not None else costs.device)
+        act = ss.masks_and_activity(costs)
+        if world > 1:
+            act = _all_gather(dist, act, world, comm_dev if comm_dev is not None else act.device)
+        shard = ss.gate_and_istft(act)
+        if world == 1:
+            if out is None:
+                return shard[:, :ss.n_out]
+            out.copy_(shard[:, :ss.n_out])
+            return out
+        shards = _all_gather(dist, shard, world, comm_dev if comm_dev is not None else shard.device)
+        return ss.join_shards(shards, out)

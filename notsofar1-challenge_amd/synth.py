@@ -20,6 +20,18 @@ from scipy.signal import lfilter
 FS = 16000
 
 
+def _fir(h: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """``lfilter(h, [1.0], x)``, bit for bit, 20x faster: numpy's direct convolution accumulates the taps in the same
+    order as scipy's transposed direct form.  That is an observation about these library builds, not a contract, so
+    the head of every call is checked against ``lfilter`` and the slow path taken on any difference (a 30-min, 7-mic
+    meeting is 21 filters over 28.8 M samples: 25 s of lfilter against 1.3 s)."""
+    y = np.convolve(x, h)[:x.shape[0]]
+    k = min(x.shape[0], 1 << 14)
+    if not np.array_equal(y[:k], lfilter(h, [1.0], x[:k])):
+        return lfilter(h, [1.0], x)
+    return y
+
+
 def synth_meeting(seconds: float, n_mics: int = 7, seed: int = 1, fs: int = FS, n_src: int = 3,
                   noise_sigma: float = 0.1) -> np.ndarray:
     rs = np.random.RandomState(seed)
@@ -34,6 +46,6 @@ def synth_meeting(seconds: float, n_mics: int = 7, seed: int = 1, fs: int = FS, 
         for m in range(n_mics):
             h = rs.randn(32) * np.exp(-taps / 8.0)
             h[0] += 1.0
-            mix[:, m] += lfilter(h, [1.0], src)
+            mix[:, m] += _fir(h, src)
     mix += noise_sigma * rs.randn(n, n_mics)
     return mix.astype(np.float32)[None]

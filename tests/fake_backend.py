@@ -13,9 +13,11 @@ class OracleStageBackend:
     def __init__(self, params, ocfg, num_spks=3):
         self.params, self.cfg, self.S = params, ocfg, num_spks
         self.calls = {"masknet_segments": 0}
+        self.comm_dev = torch.device("cpu")
+        self._scratch = {}
 
     # ---- session
-    def begin(self, pcm, n, c, run_cfg=None):
+    def begin(self, pcm, n, c, run_cfg=None, sample_range=None):
         x = np.asarray(pcm, dtype=np.float32).reshape(n, c)
         self.x = x
         self.c = c
@@ -86,13 +88,29 @@ class OracleStageBackend:
             _, _, cost = O.pit_perm(self.masks[b][0][:, -ov:], self.masks[b + 1][0][:, :ov], self.cfg.stitching_loss)
             self.costs[b] = cost.reshape(-1)
 
-    def read_costs(self):
-        return self.costs.copy()
+    # views the exchanges read and write in place (the HIP backend hands out zero-copy views of device buffers)
+    def costs_view(self):
+        return torch.from_numpy(self.costs)
 
-    def pit_scan(self, costs, num_spks):
+    def act_view(self):
+        return torch.from_numpy(self.act_b)
+
+    def scratch(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        if key not in self._scratch:
+            self._scratch[key] = torch.zeros(tuple(shape), dtype=dtype)
+        return self._scratch[key]
+
+    def index_tensor(self, name, values):
+        return torch.from_numpy(values)
+
+    def pit_scan(self):
         import itertools
+        num_spks = self.S
+        costs = self.costs[:max(self.nseg - 1, 0)]
+        assert np.isfinite(costs).all(), "a boundary cost was never computed or exchanged"
         perms = [tuple(range(num_spks))]
-        for c in np.asarray(costs).reshape(-1, num_spks, num_spks):
+        for c in costs.reshape(-1, num_spks, num_spks):
             lp = perms[-1]
             best, arg = None, None
             for sig in itertools.permutations(range(num_spks)):
@@ -100,10 +118,7 @@ class OracleStageBackend:
                 if best is None or tot < best:
                     best, arg = tot, sig
             perms.append(arg)
-        return np.array(perms, dtype=np.int32)
-
-    def write_perms(self, perms):
-        self.perms = np.asarray(perms)
+        self.perms = np.array(perms, dtype=np.int32)
 
     def _contrib(self, t):
         out = []
@@ -130,12 +145,6 @@ class OracleStageBackend:
                 a = np.float32(np.mean(self.mask_st[s, :, t], dtype=np.float64))
                 self.act_b[s, t] = 1 if a >= np.float32(self.cfg.activity_th) else 0
 
-    def read_act_b(self):
-        return self.act_b.copy()
-
-    def write_act_b(self, act):
-        self.act_b = np.asarray(act, dtype=np.uint8).copy()
-
     def stitch_gate(self, lo, hi):
         p = self.op
         final = np.stack([O.erode(O.dilate(self.act_b[s].astype(bool), p.dilation_frames), p.erosion_frames)
@@ -153,8 +162,10 @@ class OracleStageBackend:
                     acc = v if acc is None else acc + v
                 self.Y[s, :, t] = (acc / ws) * np.float32(final[s, t])
 
-    def istft_partial(self, lo, hi, num_spks, shard_len):
-        out = np.zeros((num_spks, shard_len), np.float32)
+    def istft_partial(self, lo, hi, out_tensor):
+        num_spks = self.S
+        out = out_tensor.numpy()
+        out[:, :(hi - lo + 1) * 256] = 0
         if hi > lo:
             y = self.Y[:, :, lo:hi]
             assert np.isfinite(y).all()
@@ -169,7 +180,3 @@ class OracleStageBackend:
                     if lo <= q < hi:
                         v = v + g[q - lo, :256]
                     out[s, (q - lo) * 256:(q - lo + 1) * 256] = v
-        return torch.from_numpy(out)
-
-    def to_comm(self, arr):
-        return torch.from_numpy(np.ascontiguousarray(arr))

@@ -11,15 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _separator(mc_state, lanes, max_batch):
-    old = os.environ.get("CSS_MASKNET_LANES")
-    os.environ["CSS_MASKNET_LANES"] = str(lanes)      # read at css_create
-    try:
-        return pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=max_batch)
-    finally:
-        if old is None:
-            del os.environ["CSS_MASKNET_LANES"]
-        else:
-            os.environ["CSS_MASKNET_LANES"] = old
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=max_batch)
+    sep.handle.set_lanes(lanes)
+    assert sep.handle.lanes() == lanes
+    return sep
 
 
 @pytest.mark.parametrize("seconds", [15.0, 21.2])     # 9 and 13 segments (plus a ragged last one)

@@ -1,0 +1,187 @@
+"""BASELINE.json configs[3] at full size: the fixed 1800 s, 7-channel meeting (1209 segments, T_long 112499).
+
+On one MI355X: the fused pass; the sharded driver for 8 virtual ranks (== fused, bit for bit); the decisions
+(permutations, activity bits) of the whole meeting against the oracle's stitching stage driven by the HIP masks; the
+waveforms of a window of segments against the oracle's full chain (float64 MVDR) on the HIP masks; and the real
+multi-process driver (two processes, gloo, both on GPU 0 -- RCCL refuses two ranks on one device; the 8-GPU RCCL run is
+the driver's) on a shorter meeting.  Needs an MI355X; about two minutes, most of it the synthetic meeting's generator
+and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import css_oracle as O
+from conftest import ROOT, pkg, rel_rms
+from test_hip_parity import virtual_rank_run
+
+pytestmark = pytest.mark.gpu
+
+F, T, S, HOP = 257, 186, 3, 93
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = pkg("_lib")
+    if lib.load().css_device_count() < 1:
+        pytest.fail("no HIP device visible: the parity tests must run on the GPU box")
+    return lib
+
+
+@pytest.fixture(scope="module")
+def long_run(L, mc_state):
+    """The 30-min meeting through the fused pass (css_run, page-locked buffers), kept for the tests below."""
+    CSS = pkg("css")
+    mix = pkg("synth").synth_meeting(1800.0, 7, seed=1)          # same weights and biases as the 60 s config, no re-calibration
+    pcm = L.pinned_copy(np.ascontiguousarray(mix[0]))
+    del mix
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=128)
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    h = sep.handle
+    wav = h.run(pcm, run_cfg).copy()
+    yield dict(pcm=pcm, sep=sep, h=h, run_cfg=run_cfg, wav=wav)
+    sep.close()
+
+
+def test_plan_and_determinism(L, long_run):
+    h = long_run["h"]
+    p = h.get_plan()
+    assert (p.n_samples, p.stft_frames, p.mix_frames, p.num_segments) == (28_800_000, 112_499, 112_499, 1209)
+    assert p.n_out == (112_499 - 1) * 256 + 512
+    wav = long_run["wav"]
+    assert wav.shape == (3, p.n_out) and np.isfinite(wav).all()
+    perms = h.read(L.BUF_PERMS)
+    assert np.array_equal(np.sort(perms, axis=1), np.tile(np.arange(3, dtype=np.int32), (1209, 1)))
+    again = h.run(long_run["pcm"], long_run["run_cfg"])
+    assert np.array_equal(again, wav)                                                     # deterministic
+
+
+def test_eight_virtual_ranks_equal_the_fused_pass(L, long_run):
+    """The segment-sharded driver, 8 ranks played one after the other on this GPU (every rank replays its own session;
+    exchanges by stacking the pieces): the stitched streams are the fused pass's, bit for bit."""
+    PAR = pkg("parallel")
+    plans = PAR.all_plans(1209, 112_499, 112_499, T, HOP, 256, 8)
+    assert sum(p.seg_hi - p.seg_lo for p in plans) == 1209 + 7                            # one halo segment per seam
+    assert all(151 <= p.own_seg_hi - p.own_seg_lo <= 152 for p in plans)
+    out = virtual_rank_run(PAR, L, long_run["h"], long_run["pcm"], long_run["run_cfg"], 8)
+    assert np.array_equal(out, long_run["wav"])
+
+
+def test_decisions_and_window_vs_oracle(L, long_run, mc_state):
+    """Whole-meeting decisions against the oracle's stitching stage fed with the HIP masks (permutations and
+    thresholded / dilated / eroded activity depend on the masks only: stitching_input = 'mask'), then a window of 12
+    segments through the oracle's full chain (float64 MVDR) on the same masks: waveforms <= 1e-4 relative RMS."""
+    h, run_cfg = long_run["h"], long_run["run_cfg"]
+    h.run(long_run["pcm"], run_cfg)
+    nseg = 1209
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
+    perms = h.read(L.BUF_PERMS)
+    act_b = h.read(L.BUF_ACT_B).astype(bool)          # [S, T_long]
+    act_f = h.read(L.BUF_ACT_FINAL).astype(bool)
+    mix = long_run["pcm"][None]
+
+    def hip_masks(i, seg=None):
+        return (np.ascontiguousarray(np.moveaxis(m[:S, :, i], 0, 2)), np.ascontiguousarray(np.moveaxis(m[S:, :, i], 0, 2)))
+
+    # (a) decisions of all 1209 segments: the oracle without the beamformer (it does not enter these decisions)
+    ocfg = O.OracleCssCfg(activity_th=0.3, mc_mvdr=False)
+    _, side = O.separate_and_stitch(mix, None, 16000, ocfg, separate_fn=hip_masks)
+    assert side["plan"].num_segments == nseg and side["plan"].mix_frames == 112_499
+    assert np.array_equal(np.array(side["perms"], dtype=np.int32), perms)
+    th = np.float32(0.3)
+    diff = np.argwhere(side["activity_b"].T != act_b)
+    for s_, t_ in diff:   # a bit may differ only where the mean mask sits on the threshold to float32 rounding
+        assert abs(float(side["activity"][t_, s_]) - float(th)) < 2e-6, (s_, t_, side["activity"][t_, s_])
+    assert len(diff) <= 4
+    if len(diff) == 0:
+        assert np.array_equal(side["activity_final"][0].T, act_f)
+
+    # (b) a window of 12 segments (global 600..611) through the oracle's full chain on the HIP masks
+    s0, ns = 600, 12
+    a = s0 * HOP * 256
+    nsub = ((ns - 1) * HOP + T - 1) * 256 + 512
+    sub = mix[:, a:a + nsub]
+    ow, oside = O.separate_and_stitch(sub, None, 16000, O.OracleCssCfg(activity_th=0.3),
+                                      separate_fn=lambda i, seg: hip_masks(s0 + i), mvdr_cplx=np.complex128)
+    assert oside["plan"].num_segments == ns
+    # interior frames: only window segments contribute, and the dilate / erode halo (36 frames) stays inside the window
+    f_lo, f_hi = HOP + 40, (ns - 1) * HOP - 40
+    lo, hi = (f_lo + 1) * 256, (f_hi - 1) * 256
+    wav = long_run["wav"]
+    for j in range(S):
+        k = int(perms[s0][j])        # the window's run starts from the identity, the meeting's from perms[s0]
+        ref = ow[k][lo:hi]
+        got = wav[j][a + lo:a + hi]
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+        assert rel_rms(got, ref) < 1e-4, (j, k, rel_rms(got, ref))
+
+
+def _two_rank_worker(rank, world, port, seconds, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, SYN, CSS, SEP, PAR, Lm = (pkg(x) for x in ("weights", "synth", "css", "separator", "parallel", "_lib"))
+        desc = W.ModelDesc.mc_v1()
+        cal = np.load(os.path.join(ROOT, "tests", "golden", "calib_mc.npz"))
+        state = W.apply_golden_recipe(W.portable_state_dict(desc, 0), head_bias=cal["head_bias"])
+        mix = SYN.synth_meeting(seconds, 7, seed=1)
+        n = mix.shape[1]
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+        sep = SEP.HipSeparator(state, None, device=0, max_batch_segments=64)
+        h = sep.handle
+        dev = torch.device("cuda", 0)
+        be = PAR.HipShardBackend(h, dev, torch.device("cpu"))
+        plan = Lm.plan(desc, run_cfg, n)
+        me = PAR.make_shard_plan(int(plan.num_segments), int(plan.mix_frames), int(plan.stft_frames), 186, 93, 256, rank, world)
+        s_lo, s_hi = me.pcm_range(512, n)
+        piece = Lm.pinned_copy(np.ascontiguousarray(mix[0, s_lo:s_hi]))
+        for _ in range(2):   # twice: the second pass reuses every persistent buffer
+            be.begin(piece, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True)
+            out = PAR.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist)
+        with be.on_stream():
+            got = out.cpu().numpy()
+        ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
+        np.save(os.path.join(out_dir, f"same_{rank}.npy"), np.array([np.array_equal(ref, got)]))
+        sep.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_sharded_run_on_one_gpu(tmp_path):
+    """parallel.sharded_separate_and_stitch over a real process group: two processes, each with its own handle on GPU 0
+    and only its own slice of the recording in host memory, exchanging through gloo; both end with the fused result."""
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_two_rank_worker, args=(2, port, 45.0, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert bool(np.load(tmp_path / f"same_{r}.npy")[0]), f"rank {r}: sharded result differs from the fused pass"
+
+
+def test_rccl_takes_the_exchange_tensors():
+    """The three all-gathers through RCCL itself (backend "nccl") in a one-rank group: the dtypes (float64 costs, uint8
+    activity bits, float32 shards), the regular [world, ...] receive layout and the ordering on the handle's external
+    stream are what the 8-GPU run uses."""
+    import torch
+    import torch.distributed as dist
+    PAR = pkg("parallel")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29900 + (os.getpid() % 90))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(torch.cuda.ExternalStream(st.cuda_stream, device=dev)):
+            for t in (torch.arange(18, dtype=torch.float64, device=dev).reshape(2, 9),
+                      (torch.arange(300, device=dev) % 2).to(torch.uint8).reshape(3, 100),
+                      torch.linspace(-1, 1, 3 * 1024, device=dev).reshape(3, 1024)):
+                got = PAR._all_gather(dist, t, 1, dev)
+                assert tuple(got.shape) == (1,) + tuple(t.shape) and torch.equal(got[0], t)
+    finally:
+        dist.destroy_process_group()

@@ -60,6 +60,39 @@ def hip_masks_per_segment(h, L, nseg):
             for i in range(nseg)], m
 
 
+def virtual_rank_run(PAR, L, h, pcm, run_cfg, world, poison=False):
+    """The sharded driver's phases for `world` virtual ranks on ONE GPU: every virtual rank replays its own session from
+    scratch up to the current phase (nothing a previous virtual rank computed may be needed), the exchanges are played by
+    stacking the pieces.  Returns the joined waveforms [S, n_out] (numpy)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    be = PAR.HipShardBackend(h, dev)
+    n, c = pcm.shape
+    T, hop = int(run_cfg.c.segment_frames), int(run_cfg.c.hop_frames)
+    pieces = {0: [], 1: [], 2: []}
+    ss = None
+    for phase in range(3):
+        for r in range(world):
+            h.begin(pcm, n, c, run_cfg)
+            if poison and world > 1:   # nothing a previous virtual rank left behind may be readable
+                nseg = h.get_plan().num_segments
+                h.write(L.BUF_MASKS, np.full(((S + 1) * F, nseg * T), np.nan, np.float32))
+                h.write(L.BUF_SEP, np.full((nseg, S, F, T * 2), np.nan, np.float32))
+                h.write(L.BUF_X, np.full((c, 2 * F, h.buffer_dims(L.BUF_X)[0][2]), np.nan, np.float32))
+            ss = PAR.ShardedSession(be, S, T, hop, 256, r, world)
+            piece = ss.segments_and_costs()
+            if phase >= 1:
+                piece = ss.masks_and_activity(torch.stack(pieces[0]) if world > 1 else None)
+            if phase >= 2:
+                piece = ss.gate_and_istft(torch.stack(pieces[1]) if world > 1 else None)
+            with be.on_stream():
+                pieces[phase].append(piece.clone() if piece is not None else None)
+    with be.on_stream():
+        out = ss.join_shards(torch.stack(pieces[2])) if world > 1 else pieces[2][0][:, :ss.n_out]
+        out = out.cpu()
+    return out.numpy()
+
+
 def _unpack(bits, shape):
     return np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape).astype(bool)
 
@@ -344,33 +377,8 @@ def test_full_size_60s_properties(L, CSS, sep_mc, mix60):
     perms = h.read(L.BUF_PERMS)
     assert sorted(map(tuple, np.sort(perms, axis=1))) == [(0, 1, 2)] * 40        # every row is a permutation
 
-    # two virtual ranks on the same GPU (fresh sessions, buffers poisoned in between)
-    dev = torch.device("cuda", 0)
-    be = PAR.HipShardBackend(h, dev)
-    sessions, costs, acts, shards = [], [], [], []
-    results = {}
-    for world in (1, 2, 3):
-        costs, acts, shards = [], [], []
-        for phase in range(3):
-            for r in range(world):
-                # each virtual rank replays its own session up to the current phase from scratch
-                h.begin(mix60[0], mix60.shape[1], 7, run_cfg)
-                if world > 1:   # nothing a previous virtual rank left behind may be readable
-                    h.write(L.BUF_MASKS, np.full(((S + 1) * F, 40 * T), np.nan, np.float32))
-                    h.write(L.BUF_SEP, np.full((40, S, F, T * 2), np.nan, np.float32))
-                    h.write(L.BUF_X, np.full((7, 2 * F, h.buffer_dims(L.BUF_X)[0][2]), np.nan, np.float32))
-                ss = PAR.ShardedSession(be, S, T, 93, 256, r, world)
-                c = ss.segments_and_costs()
-                if phase == 0:
-                    costs.append(c)
-                    continue
-                a = ss.masks_and_activity(PAR.ShardedSession.join_costs(ss.plans, costs))
-                if phase == 1:
-                    acts.append(a)
-                    continue
-                shards.append(ss.gate_and_istft(PAR.ShardedSession.join_activity(ss.plans, acts)))
-        out = PAR.ShardedSession.join_shards(ss.plans, shards, S, plan.n_out)
-        results[world] = out.cpu().numpy()
+    # virtual ranks on the same GPU (fresh sessions, buffers poisoned in between)
+    results = {world: virtual_rank_run(PAR, L, h, mix60[0], run_cfg, world, poison=True) for world in (1, 2, 3)}
     assert np.array_equal(results[1], w1)
     assert np.array_equal(results[2], w1)
     assert np.array_equal(results[3], w1)
@@ -422,5 +430,31 @@ def test_other_model_widths_vs_oracle(L, mix_stage, dims):
             out = sep.forward(torch.from_numpy(mix_stage[:, :48000]))
             m = np.concatenate([out["spk_masks"].numpy()[0], out["noise_masks"].numpy()[0]], axis=-1)   # [F, T, 4]
             assert np.abs(np.moveaxis(m, 2, 0) - om).max() < 5e-5, (dims, mode)
+    finally:
+        sep.close()
+
+
+@pytest.mark.parametrize("frames", [2, 8, 24, 32, 33, 48, 64, 65, 97, 256])
+def test_short_and_odd_segment_lengths_vs_oracle(L, mix_stage, frames):
+    """Every tile schedule of the attention kernel (one instantiation per ceil(T / 32); T <= 32 has a two-tile position
+    prologue), the conv module's short runs and the GEMM tails at clip lengths the 3 s / 4 s configurations never reach:
+    masks of a 2-block model against the oracle in both arithmetic modes, multi-channel."""
+    import torch
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=2)
+    st = w.apply_golden_recipe(w.portable_state_dict(desc, 17))
+    params = O.ConformerParams(st)
+    sep = pkg("separator").HipSeparator(st, None, device=0)
+    try:
+        n = (frames - 1) * 256 + 512
+        clips = np.stack([mix_stage[0, s:s + n] for s in (0, 1000, 5000)])               # [3, n, 7]
+        for mode in ("split_f16", "exact_f32"):
+            sep.handle.set_linear_mode(mode)
+            out = sep.forward(torch.from_numpy(clips))
+            assert tuple(out["spk_masks"].shape) == (3, F, frames, 3)
+            for b in range(3):
+                om = O.conformer_forward(params, O.features(O.stft(clips[b])))            # [4, F, frames]
+                m = np.concatenate([out["spk_masks"].numpy()[b], out["noise_masks"].numpy()[b]], axis=-1)
+                assert np.abs(np.moveaxis(m, 2, 0) - om).max() < 1e-5, (frames, mode, b)
     finally:
         sep.close()
