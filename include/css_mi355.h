@@ -52,7 +52,8 @@ typedef enum css_status {
     CSS_ERR_SHAPE = -5,          /* css.py:202-203 mask / stft shape mismatch, channel count vs model      */
     CSS_ERR_STATE = -6,          /* stage called before the stage it depends on                            */
     CSS_ERR_NO_DEVICE = -7,      /* no usable gfx950 device                                                */
-    CSS_ERR_WEIGHT_WINDOW = -8   /* css.py:374  not enough frames to fit the weighting window              */
+    CSS_ERR_WEIGHT_WINDOW = -8,  /* css.py:374  not enough frames to fit the weighting window              */
+    CSS_ERR_RANGE = -9           /* an operand left the split-f16 range and the float32 fallback is off    */
 } css_status;
 
 /* Architecture of the mask estimator.  Mirrors the dataclasses of
@@ -215,6 +216,21 @@ int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_
 enum css_linear_mode { CSS_LINEAR_SPLIT_F16 = 0, CSS_LINEAR_EXACT_F32 = 1 };
 int css_set_linear_mode(css_handle_t h, int mode);
 int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css_status */
+/* Operand range of CSS_LINEAR_SPLIT_F16: |x| <= 65504 (float16).  Nothing is clamped: a larger activation becomes
+ * inf / NaN, reaches the stitched activity and the waveforms, and css_run* then repeats the whole pass on the exact
+ * float32 kernels (enable = 1, the default) or returns CSS_ERR_RANGE (enable = 0).  css_range_status: passes repeated
+ * so far, and whether the last pass was one.  css_check_range does the same test after a staged (css_stage_*) run.
+ * A model with a WEIGHT outside the range starts in, and stays in, CSS_LINEAR_EXACT_F32. */
+int css_set_range_fallback(css_handle_t h, int enable);
+int css_range_status(css_handle_t h, int64_t* fallbacks, int32_t* last_hit);
+int css_check_range(css_handle_t h);
+/* torch.nn.Linear (conformer.py:49-53,139-142,206,285) on caller data, y[M][N] = x[M][K] w[N][K]^T + bias[N] (bias may
+ * be NULL; K % 32 == 0), through one GEMM kernel of the path: kernel 0 = split-f16 operands, weights tile-major and read
+ * straight into the matrix cores (the encoder's Linear layers); 1 = split-f16 operands, both through LDS (mask head,
+ * inverse transform); 2 = exact float32.  layout: 0 = the launcher's choice, else a tile layout to force (kernel 0:
+ * 32 / 64 / 96 / 4 / 128; kernels 1, 2: 8 / 4 / 64).  For unit tests of the arithmetic; not on the hot path. */
+int css_linear_host(css_handle_t h, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
+                    int32_t kernel, int32_t layout, float* y);
 int css_get_plan(css_handle_t h, CssPlan* out);
 
 /* ---- stages (each replaces one reference function; state lives in the handle) -------------- */

@@ -29,7 +29,7 @@ class CssError(RuntimeError):
 
 # status codes (include/css_mi355.h: css_status)
 CSS_OK, CSS_ERR_INVALID_ARG, CSS_ERR_HIP, CSS_ERR_ZERO_WEIGHT, CSS_ERR_MASK_FLOOR = 0, -1, -2, -3, -4
-CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW = -5, -6, -7, -8
+CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW, CSS_ERR_RANGE = -5, -6, -7, -8, -9
 
 # buffer ids (css_buffer)
 (BUF_X, BUF_FEATURES, BUF_MASKS, BUF_SCM, BUF_BFW, BUF_SEP, BUF_PIT_COST, BUF_PERMS, BUF_MASK_ST, BUF_ACTIVITY,
@@ -93,6 +93,10 @@ SIGNATURES = {
     "css_get_kernel_stats": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "css_set_linear_mode": (C.c_int, [_P, C.c_int]),
     "css_get_linear_mode": (C.c_int, [_P]),
+    "css_set_range_fallback": (C.c_int, [_P, C.c_int]),
+    "css_range_status": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "css_check_range": (C.c_int, [_P]),
+    "css_linear_host": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
     "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
     "css_begin_range": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int64, C.c_int64]),
@@ -346,6 +350,31 @@ class Handle:
     def set_linear_mode(self, mode):
         """"split_f16" (default: float32-grade accuracy on the f16 matrix cores) or "exact_f32"."""
         check(self.h, self.lib.css_set_linear_mode(self.h, {"split_f16": 0, "exact_f32": 1}[mode]))
+
+    def set_range_fallback(self, enable: bool):
+        check(self.h, self.lib.css_set_range_fallback(self.h, int(enable)))
+
+    def range_status(self):
+        """(passes repeated on the exact float32 kernels so far, whether the last pass was one)"""
+        n, last = C.c_int64(), C.c_int32()
+        check(self.h, self.lib.css_range_status(self.h, C.byref(n), C.byref(last)))
+        return int(n.value), bool(last.value)
+
+    def check_range(self):
+        check(self.h, self.lib.css_check_range(self.h))
+
+    def linear(self, x: np.ndarray, w: np.ndarray, bias=None, kernel: int = 0, layout: int = 0) -> np.ndarray:
+        """y = x @ w.T + bias through one of the path's GEMM kernels (css_linear_host)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        m, k = x.shape
+        n = w.shape[0]
+        assert w.shape[1] == k
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        y = np.empty((m, n), dtype=np.float32)
+        check(self.h, self.lib.css_linear_host(self.h, _np_ptr(x), _np_ptr(w), _np_ptr(b) if b is not None else None,
+                                               m, n, k, int(kernel), int(layout), _np_ptr(y)))
+        return y
 
     def linear_mode(self):
         m = self.lib.css_get_linear_mode(self.h)

@@ -64,6 +64,7 @@ struct css_ctx {
     // Linear-layer arithmetic: split-f16 operands on the f16 matrix cores (float32-grade accuracy, gemm_split.hip) or,
     // after css_set_linear_mode(h, CSS_LINEAR_EXACT_F32), the exact float32 MFMA chain of gemm.hip.
     bool split = true;
+    bool split_ok = true;        // false: a weight lies outside the split-f16 operand range, CSS_LINEAR_SPLIT_F16 is refused
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
     DevBuf pe_frag[2];           // relative-position rows in attention-operand order for segment length pe_frag_T
@@ -97,6 +98,13 @@ struct css_ctx {
     // PCIe pieces of css_run* travel on their own stream, beside the kernels: the upload of the samples a lane's segments
     // read is followed by that lane's analysis transform and mask-estimator chain while the next piece is in flight, and
     // finished ranges of the output leave while the last ranges are still being synthesised.
+    // range check of the split-f16 operand format (split_f16.hpp): a device word set when the stitched activity or the
+    // waveforms hold a non-finite value, mirrored into page-locked host memory at the end of every pass
+    unsigned int* range_flag_dev = nullptr;
+    unsigned int* range_flag_host = nullptr;
+    bool range_fallback = true;      // repeat such a pass on the exact float32 kernels (else: CSS_ERR_RANGE)
+    int64_t range_fallbacks = 0;     // passes repeated so far
+    int range_last = 0;              // the last pass hit the range limit
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
     size_t ev_pool_used = 0;
@@ -428,6 +436,10 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
             return bail(CSS_ERR_HIP, "lane stream / event could not be created");
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(CSS_ERR_HIP, "copy stream could not be created");
+    if (hipMalloc((void**)&h->range_flag_dev, 64) != hipSuccess ||
+        hipHostMalloc((void**)&h->range_flag_host, 64, hipHostMallocDefault) != hipSuccess)
+        return bail(CSS_ERR_HIP, "range flag could not be allocated");
+    *h->range_flag_host = 0;
     if (hipMalloc((void**)&h->blob, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(weights) failed");
     if (hipMemcpy(h->blob, blob_host, need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "weight upload failed");
@@ -455,6 +467,11 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     if (hipMemcpy(h->dft_fwd, fwd.data(), fwd.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->dft_inv_t, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "dft upload failed");
+    // a weight beyond the split-f16 operand range (never seen in a trained checkpoint; weights are O(1)): this model
+    // runs on the exact float32 kernels
+    for (int64_t i = 0; i < need && h->split; ++i)
+        if (!(std::fabs(blob_host[i]) <= 65504.f)) h->split = false;
+    h->split_ok = h->split;
     if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
     *out = h;
     return CSS_OK;
@@ -479,6 +496,8 @@ int css_destroy(css_handle_t h) {
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    if (h->range_flag_dev) hipFree(h->range_flag_dev);
+    if (h->range_flag_host) hipHostFree(h->range_flag_host);
     for (auto& e : h->ev_pool) hipEventDestroy(e);
     if (h->wsplit) hipFree(h->wsplit);
     if (h->dft_split) hipFree(h->dft_split);
@@ -994,7 +1013,7 @@ static hipEvent_t pool_event(css_ctx* h) {
 // frames, and starts the estimator on its segments while the later pieces are still in flight.  Stitching needs every
 // segment (the permutation scan is sequential, css.py:266-285); after it the gate, the inverse transform and the
 // download run over frame ranges, a finished range leaving while the next one is synthesised.
-static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
+static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
     if (!h) return CSS_ERR_INVALID_ARG;
     if ((rc = begin_impl(h, n, n_ch, cfg)) != CSS_OK) return rc;
@@ -1126,6 +1145,11 @@ static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     }
     if (tail) HIPCHK(h, hipStreamWaitEvent(h->stream, tail, 0));
     hipEventRecord(h->ev[7], h->stream);
+    // range check (split_f16.hpp): an operand outside the split-f16 range turned into inf / NaN and reached these
+    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
+    launch_nonfinite_flag((const float*)h->activity.p, (int64_t)S * TL, h->range_flag_dev, h->stream);
+    launch_nonfinite_flag((const float*)h->wav.p, (int64_t)S * pl.n_out, h->range_flag_dev, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
@@ -1145,6 +1169,25 @@ static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         t.gemm_launches = h->prof_launches[CSS_PROF_LINEAR];
     }
     return CSS_OK;
+}
+
+// The pass, and -- when an operand left the split-f16 range (non-finite activity / samples) while the input itself was
+// finite -- the same pass again on the exact float32 kernels (css_set_range_fallback(h, 0): CSS_ERR_RANGE instead).
+static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
+    int rc = run_once(h, n, n_ch, cfg, io);
+    if (rc != CSS_OK) return rc;
+    h->range_last = 0;
+    if (!*h->range_flag_host || !h->split) return CSS_OK;   // (in exact mode non-finite output means non-finite input)
+    h->range_last = 1;
+    if (!h->range_fallback)
+        return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range (|x| > 65504): use CSS_LINEAR_EXACT_F32");
+    const CssTimings first = h->tim;
+    if ((rc = css_set_linear_mode(h, CSS_LINEAR_EXACT_F32)) != CSS_OK) return rc;
+    rc = run_once(h, n, n_ch, cfg, io);
+    const int rc2 = css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16);
+    h->range_fallbacks += 1;
+    h->tim.total += first.total;
+    return rc != CSS_OK ? rc : rc2;
 }
 
 int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, float* wav_host,
@@ -1182,6 +1225,69 @@ int css_set_lanes(css_handle_t h, int lanes) {
 
 int css_get_lanes(css_handle_t h) { return h ? h->lanes : (int)CSS_ERR_INVALID_ARG; }
 
+int css_set_range_fallback(css_handle_t h, int enable) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    h->range_fallback = enable != 0;
+    return CSS_OK;
+}
+
+int css_range_status(css_handle_t h, int64_t* fallbacks, int32_t* last_hit) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (fallbacks) *fallbacks = h->range_fallbacks;
+    if (last_hit) *last_hit = h->range_last;
+    return CSS_OK;
+}
+
+int css_check_range(css_handle_t h) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int S = h->d.num_spks;
+    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
+    launch_nonfinite_flag((const float*)h->activity.p, (int64_t)S * h->plan.mix_frames, h->range_flag_dev, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (*h->range_flag_host && h->split)
+        return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range (|x| > 65504): use CSS_LINEAR_EXACT_F32");
+    return CSS_OK;
+}
+
+// torch.nn.Linear on caller data through one of the path's three GEMM kernels (unit tests of the arithmetic).
+int css_linear_host(css_handle_t h, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
+                    int32_t kernel, int32_t layout, float* y) {
+    if (!h || !x || !w || !y || M < 1 || N < 1 || K < 32 || K % 32) return fail(h, CSS_ERR_INVALID_ARG, "bad argument (K must be a multiple of 32)");
+    if (kernel < 0 || kernel > 2) return fail(h, CSS_ERR_INVALID_ARG, "kernel must be 0 (split, weights direct), 1 (split, LDS staged) or 2 (exact float32)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int Np = (N + 31) / 32 * 32;
+    const size_t xf = (size_t)M * K, wf = (size_t)Np * K, yf = (size_t)M * N;
+    int rc;
+    if ((rc = ensure(h, h->stage, (2 * xf + 2 * wf + yf + (size_t)N + 256) * sizeof(float))) != CSS_OK) return rc;
+    float* xd = (float*)h->stage.p;
+    float* xs = xd + (xf + 15) / 16 * 16;
+    float* wd = xs + (xf + 15) / 16 * 16;
+    float* ws = wd + (wf + 15) / 16 * 16;
+    float* yd = ws + (wf + 15) / 16 * 16;
+    float* bd = yd + (yf + 15) / 16 * 16;
+    HIPCHK(h, hipMemcpyAsync(xd, x, xf * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(wd, w, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (bias) HIPCHK(h, hipMemcpyAsync(bd, bias, (size_t)N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GemmArgs g = linear(xd, K, wd, K, bias ? bd : nullptr, yd, N, M, N, K, ACT_NONE);
+    if (kernel != 2) {
+        launch_split_convert(xd, K, xs, M, K, K, h->stream);
+        if (kernel == 0) launch_split_convert_tiled(wd, K, ws, N, K, h->stream);
+        else launch_split_convert(wd, K, ws, N, K, K, h->stream);
+        g.A = xs; g.B = ws; g.split_in = 1; g.b_tiled = kernel == 0;
+        if (kernel == 0) g.tile_rows = layout; else g.layout = layout;
+    } else {
+        g.layout = layout;
+    }
+    launch_gemm(g, h->stream);
+    HIPCHK(h, hipMemcpyAsync(y, yd, yf * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
 int css_host_alloc(size_t bytes, void** out) {
     if (!out) return CSS_ERR_INVALID_ARG;
     *out = nullptr;
@@ -1194,6 +1300,7 @@ int css_set_linear_mode(css_handle_t h, int mode) {
     if (!h || (mode != CSS_LINEAR_SPLIT_F16 && mode != CSS_LINEAR_EXACT_F32)) return fail(h, CSS_ERR_INVALID_ARG, "unknown linear mode");
     const bool split = mode == CSS_LINEAR_SPLIT_F16;
     if (split == h->split) return CSS_OK;
+    if (split && !h->split_ok) return fail(h, CSS_ERR_RANGE, "a weight of this model lies outside the split-f16 operand range (|w| > 65504)");
     HIPCHK(h, hipSetDevice(h->device));
     if (split) {
         int rc = make_split_weights(h);

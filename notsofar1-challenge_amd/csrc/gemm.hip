@@ -173,11 +173,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 //                                    LDS bubbles when a launch has about one block per CU
 //   128 x 128, 4 waves (each 64x64)  fewest LDS reads per MFMA; ~3 % ahead once >= 4 blocks per CU are queued
 //    64 x 128, 4 waves (each 32x64)  twice the blocks: independent 4-wave blocks drift out of phase
-// CSS_GEMM_LAYOUT=8|4|64 forces one (experiments; tools/gemm_bench.hip).
+// GemmArgs::layout = 8 | 4 | 64 forces one (unit tests, tools/gemm_bench.hip); every layout gives the same bits.
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
     if (g.split_in) return g.b_tiled ? launch_gemm_split_wd(g, s) : launch_gemm_split(g, s);
-    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_LAYOUT"); return e ? std::atoi(e) : 0; }();
+    const int forced = g.layout;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;
     int layout = forced ? forced : (blocks128 < 1000 ? 8 : 4);

@@ -194,6 +194,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_split_kernel(GemmArgs g, int
     const int mrow = m0 + wm * (BM / WM) + 4 * h, ncol = n0 + wn * 64 + c;
     acc00 += cor00 * SPLIT_LO_INV;
     acc01 += cor01 * SPLIT_LO_INV;
+    if constexpr (TM == 2) {   // (before either epilogue: the 16-byte one used to emit these two tiles without their cross terms)
+        acc10 += cor10 * SPLIT_LO_INV;
+        acc11 += cor11 * SPLIT_LO_INV;
+    }
     // 16-byte stores through a wave-private LDS patch when the output rows allow it (gemm_common.hpp)
     const bool wide = (ldc % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     if (wide) {
@@ -211,8 +215,6 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_split_kernel(GemmArgs g, int
     emit_tile(acc00, mrow, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);
     emit_tile(acc01, mrow, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);
     if constexpr (TM == 2) {
-        acc10 += cor10 * SPLIT_LO_INV;
-        acc11 += cor11 * SPLIT_LO_INV;
         emit_tile(acc10, mrow + 32, ncol, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);
         emit_tile(acc11, mrow + 32, ncol + 32, M, N, C, ldc, bias, bias_m, act, res, ldr, alpha, so);
     }
@@ -237,10 +239,10 @@ void launch_split_convert(const float* src, int64_t ld_src, float* dst, int64_t 
     hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, rows, K, Kp);
 }
 
-// Layouts as in gemm.hip (128x128 with 8 or 4 waves, 64x128 with 4 waves); CSS_GEMM_SPLIT_LAYOUT=8|4|64 forces one.
+// Layouts as in gemm.hip (128x128 with 8 or 4 waves, 64x128 with 4 waves); GemmArgs::layout = 8 | 4 | 64 forces one.
 void launch_gemm_split(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
-    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_SPLIT_LAYOUT"); return e ? std::atoi(e) : 0; }();
+    const int forced = g.layout;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;
     int layout = forced ? forced : (blocks128 < 1000 ? 8 : 4);

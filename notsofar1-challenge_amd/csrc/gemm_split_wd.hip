@@ -305,12 +305,9 @@ void launch_split_convert_tiled(const float* src, int64_t ld_src, float* dst, in
 
 void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     if (g_in.M <= 0 || g_in.N <= 0) return;
-    static const int nt_env = [] { const char* e = std::getenv("CSS_EPI_NT"); return e ? std::atoi(e) : -1; }();
-    GemmArgs g = g_in;
-    if (nt_env >= 0) g.nt_store = nt_env;
+    const GemmArgs& g = g_in;
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
-    static const int forced = [] { const char* e = std::getenv("CSS_GEMM_WD_WAVES"); return e ? std::atoi(e) : 0; }();
-    const int pick = g.tile_rows ? g.tile_rows : forced;
+    const int pick = g.tile_rows;
     if (pick == 32) {
         const int tm32 = (g.M + 31) / 32;
         hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);

@@ -11,8 +11,12 @@
 // three products cost 3/16 of one float32 product.
 //
 // lo is scaled by 2^11 so that it is a normal f16 number whenever hi is (no dependence on denormal
-// support), and |x| < 2^-14 is carried entirely by lo (hi = 0).  x is clamped to the f16 range first
-// (+-65504: LayerNorm outputs, ReLU activations, attention contexts and weights are far inside it).
+// support), and |x| < 2^-14 is carried entirely by lo (hi = 0); below 2^-25 lo itself loses bits, an ABSOLUTE error
+// under 2^-36 per operand, invisible in any sum the path forms.  The format covers |x| <= 65504 (LayerNorm outputs,
+// ReLU activations, attention contexts, pi-bounded features and trained weights are orders of magnitude inside).  A
+// value outside is NOT clamped: hi becomes +-inf, lo NaN, and the non-finite result reaches the stitched activity and
+// the waveforms, where css_run* looks for it (api.hip: range check) and repeats the pass on the exact float32
+// kernels -- an out-of-range operand costs time, never a silently wrong answer.
 //
 // Memory layout of a split matrix [rows][K] (K % 32 == 0): the row is K/32 groups of 128 bytes, each
 // 32 hi halves followed by the 32 lo halves of the same k -- one row of a 32-wide K slab is one 128-byte
@@ -30,7 +34,6 @@ constexpr float SPLIT_LO_INV = 1.0f / 2048.0f;
 __device__ __forceinline__ int split_index(int k) { return ((k >> 5) << 6) | (k & 31); }
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     const _Float16 h = fabsf(x) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)x;
     hi = h;
     lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);

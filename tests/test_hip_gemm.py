@@ -1,0 +1,120 @@
+"""The three GEMM kernels of the path as stand-alone Linear layers (css_linear_host) against a float64 product:
+error envelope over operand magnitudes 1e-6 .. 1e3 and K in {512, 1024, 1824}, bit equality of every tile layout of a
+kernel (rows are independent of the launch shape: that is what makes the path batch-, lane- and shard-invariant), and
+the operand range of the split-f16 format (nothing is clamped; an out-of-range pass is repeated in float32).
+Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128)),
+           1: ("split-f16, LDS staged", (0, 8, 4, 64)),
+           2: ("exact float32", (0, 8, 4, 64))}
+
+
+@pytest.fixture(scope="module")
+def handle():
+    L = pkg("_lib")
+    if L.load().css_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=1)
+    sep = pkg("separator").HipSeparator(w.apply_golden_recipe(w.portable_state_dict(desc, 5)), None, device=0)
+    yield sep.handle
+    sep.close()
+
+
+def _case(rs, m, n, k, sx, sw):
+    x = (rs.standard_normal((m, k)) * sx).astype(np.float32)
+    w = (rs.standard_normal((n, k)) * sw).astype(np.float32)
+    b = (rs.standard_normal(n) * sx * sw).astype(np.float32)
+    y64 = x.astype(np.float64) @ w.astype(np.float64).T + b
+    scale = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)   # sum of |terms| per output
+    return x, w, b, y64, scale
+
+
+@pytest.mark.parametrize("k", [512, 1024, 1824])
+def test_error_envelope_vs_float64(handle, k):
+    """|y - y64| relative to the sum of the absolute terms: float32 accumulation leaves ~sqrt(K) 2^-24; the split
+    kernels must sit in the same envelope as the exact float32 kernel (their operands carry 22 bits, the dropped
+    lo x lo term is 2^-22 of a product)."""
+    rs = np.random.RandomState(k)
+    worst = {}
+    for sx, sw in [(1e-6, 1.0), (1e-3, 1e-3), (1.0, 1.0), (1.0, 30.0), (1e3, 1.0), (3e4, 1e-2)]:
+        x, w, b, y64, scale = _case(rs, 333, 640, k, sx, sw)
+        for kern in KERNELS:
+            y = handle.linear(x, w, b, kernel=kern)
+            assert np.isfinite(y).all(), (kern, sx, sw)
+            worst[kern] = max(worst.get(kern, 0.0), float((np.abs(y - y64) / scale).max()))
+    print(f"K={k}: max |err| / sum|terms|:", {KERNELS[kk][0]: f"{v:.2e}" for kk, v in worst.items()})
+    for kern, v in worst.items():
+        assert v < 1.5e-6, (KERNELS[kern][0], v)
+    assert worst[0] < 3 * worst[2] + 1e-7 and worst[1] < 3 * worst[2] + 1e-7
+
+
+@pytest.mark.parametrize("shape", [(100, 512, 512), (7440, 1536, 512), (23808, 512, 1024), (1028, 22506, 512),
+                                   (28125, 512, 544), (777, 1028, 1824)])
+def test_tile_layouts_give_the_same_bits(handle, shape):
+    """Every tile layout of a kernel, and the launcher's own choice at this shape, writes the same bits -- including
+    the large launches (long meetings, 128-segment batches) where the launcher switches layouts."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n)
+    x, w, b, y64, scale = _case(rs, m, n, k, 1.0, 0.5)
+    split = None
+    for kern, (name, layouts) in KERNELS.items():
+        ref = None
+        for lay in layouts:
+            y = handle.linear(x, w, b, kernel=kern, layout=lay)
+            if ref is None:
+                ref = y
+                assert float((np.abs(y - y64) / scale).max()) < 1.5e-6, (name, lay)
+            else:
+                assert np.array_equal(y, ref), (name, lay, float(np.abs(y - ref).max()))
+        if kern in (0, 1):   # the two split kernels accumulate in the same order
+            if split is None:
+                split = ref
+            else:
+                assert np.array_equal(ref, split)
+
+
+def test_split_operand_range_is_not_clamped(handle):
+    """An operand beyond the float16 range must not pass silently: the split kernels return non-finite values (which
+    css_run* detects at the end of a pass), the exact kernel the right answer."""
+    rs = np.random.RandomState(1)
+    x, w, b, y64, scale = _case(rs, 64, 128, 512, 1.0, 1.0)
+    x[3, 17] = 1.0e5
+    y64 = x.astype(np.float64) @ w.astype(np.float64).T + b
+    assert not np.isfinite(handle.linear(x, w, b, kernel=0)[3]).any()
+    assert not np.isfinite(handle.linear(x, w, b, kernel=1)[3]).any()
+    y = handle.linear(x, w, b, kernel=2)
+    assert np.isfinite(y).all() and np.abs(y - y64).max() < 0.5
+
+
+def test_out_of_range_pass_is_repeated_in_float32(mc_state, mix60):
+    """A recording at integer PCM scale (x 32768) drives the stitched spectra past 65504: the split-f16 rows of the
+    inverse transform overflow, the pass is detected and repeated on the exact float32 kernels -- the result is the
+    exact mode's, bit for bit; with the fallback off the same call fails with CSS_ERR_RANGE."""
+    L, CSS = pkg("_lib"), pkg("css")
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0)
+    try:
+        h = sep.handle
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+        mix = np.ascontiguousarray(mix60[0, :12 * 16000]) * np.float32(32768.0 * 8)
+        assert h.range_status() == (0, False)
+        got = h.run(mix, run_cfg)
+        assert h.range_status() == (1, True) and np.isfinite(got).all() and h.linear_mode() == "split_f16"
+        h.set_linear_mode("exact_f32")
+        ref = h.run(mix, run_cfg)
+        h.set_linear_mode("split_f16")
+        assert np.array_equal(got, ref)
+        quiet = h.run(np.ascontiguousarray(mix60[0, :12 * 16000]), run_cfg)
+        assert h.range_status() == (1, False) and np.isfinite(quiet).all()
+        h.set_range_fallback(False)
+        with pytest.raises(L.CssError) as e:
+            h.run(mix, run_cfg)
+        assert e.value.code == L.CSS_ERR_RANGE
+    finally:
+        sep.close()

@@ -66,7 +66,13 @@ def test_eight_virtual_ranks_equal_the_fused_pass(L, long_run):
     assert sum(p.seg_hi - p.seg_lo for p in plans) == 1209 + 7                            # one halo segment per seam
     assert all(151 <= p.own_seg_hi - p.own_seg_lo <= 152 for p in plans)
     out = virtual_rank_run(PAR, L, long_run["h"], long_run["pcm"], long_run["run_cfg"], 8)
-    assert np.array_equal(out, long_run["wav"])
+    ref = long_run["wav"]
+    if not np.array_equal(out, ref):
+        bad = np.flatnonzero((out != ref).any(axis=0))
+        fr = bad // 256
+        owners = sorted({next(p.rank for p in plans if p.t_lo <= min(f, 112_498) < p.t_hi) for f in (fr[0], fr[-1])})
+        pytest.fail(f"{bad.size} samples differ: first at {bad[0]} (frame {fr[0]}), last at {bad[-1]} (frame {fr[-1]}), "
+                    f"ranks {owners}; seams at frames {[p.t_lo for p in plans]}")
 
 
 def test_decisions_and_window_vs_oracle(L, long_run, mc_state):

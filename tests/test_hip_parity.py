@@ -435,10 +435,13 @@ def test_other_model_widths_vs_oracle(L, mix_stage, dims):
 
 
 @pytest.mark.parametrize("frames", [2, 8, 24, 32, 33, 48, 64, 65, 97, 256])
-def test_short_and_odd_segment_lengths_vs_oracle(L, mix_stage, frames):
+def test_short_and_odd_segment_lengths_vs_oracle(L, mix60, frames):
     """Every tile schedule of the attention kernel (one instantiation per ceil(T / 32); T <= 32 has a two-tile position
     prologue), the conv module's short runs and the GEMM tails at clip lengths the 3 s / 4 s configurations never reach:
-    masks of a 2-block model against the oracle in both arithmetic modes, multi-channel."""
+    masks of a 2-block model against the oracle in both arithmetic modes, multi-channel.  The two modes see the same
+    features, so they must agree to the arithmetic's own noise (1e-5); against the oracle the bar is the one of the
+    other mask tests (5e-5): the oracle's float64-evaluated IPD features differ from the float32 ones in rare,
+    ill-conditioned elements (numerical hazard 3), more so the fewer frames the statistics average over."""
     import torch
     w = pkg("weights")
     desc = w.ModelDesc(num_blocks=2)
@@ -447,14 +450,17 @@ def test_short_and_odd_segment_lengths_vs_oracle(L, mix_stage, frames):
     sep = pkg("separator").HipSeparator(st, None, device=0)
     try:
         n = (frames - 1) * 256 + 512
-        clips = np.stack([mix_stage[0, s:s + n] for s in (0, 1000, 5000)])               # [3, n, 7]
+        clips = np.stack([mix60[0, s:s + n] for s in (0, 1000, 5000)])                   # [3, n, 7]
+        got = {}
         for mode in ("split_f16", "exact_f32"):
             sep.handle.set_linear_mode(mode)
             out = sep.forward(torch.from_numpy(clips))
             assert tuple(out["spk_masks"].shape) == (3, F, frames, 3)
-            for b in range(3):
-                om = O.conformer_forward(params, O.features(O.stft(clips[b])))            # [4, F, frames]
-                m = np.concatenate([out["spk_masks"].numpy()[b], out["noise_masks"].numpy()[b]], axis=-1)
-                assert np.abs(np.moveaxis(m, 2, 0) - om).max() < 1e-5, (frames, mode, b)
+            got[mode] = np.concatenate([out["spk_masks"].numpy(), out["noise_masks"].numpy()], axis=-1)   # [3, F, T, 4]
+        assert np.abs(got["split_f16"] - got["exact_f32"]).max() < 1e-5, frames
+        for b in range(3):
+            om = O.conformer_forward(params, O.features(O.stft(clips[b])))                # [4, F, frames]
+            for mode, m in got.items():
+                assert np.abs(np.moveaxis(m[b], 2, 0) - om).max() < 5e-5, (frames, mode, b)
     finally:
         sep.close()
