@@ -130,7 +130,9 @@ typedef enum css_buffer {
     CSS_BUF_Y = 12,         /* float  [S][T_long][KI_pad]                                           */
     CSS_BUF_WAV = 13,       /* float  [S][n_out]                                                    */
     CSS_BUF_HIDDEN = 14,    /* float  [batch tokens][D]  encoder output of the last batch           */
-    CSS_BUF_WTA_OVERRIDE = 15 /* uint8 [segments][F][T_seg]  (write-only) injected WTA decisions     */
+    CSS_BUF_WTA_OVERRIDE = 15,/* uint8 [segments][F][T_seg]  (write-only) injected WTA decisions     */
+    CSS_BUF_LEVEL = 16      /* float  [1]  max |sample| of the PCM laid out so far in this session: sets the power-of-two
+                               gain of the split-f16 synthesis operand; ranks of a sharded meeting exchange its maximum */
 } css_buffer;
 
 /* ---- library ------------------------------------------------------------------------------ */

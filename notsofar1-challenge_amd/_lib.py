@@ -33,7 +33,7 @@ CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW, CSS_ERR_
 
 # buffer ids (css_buffer)
 (BUF_X, BUF_FEATURES, BUF_MASKS, BUF_SCM, BUF_BFW, BUF_SEP, BUF_PIT_COST, BUF_PERMS, BUF_MASK_ST, BUF_ACTIVITY,
- BUF_ACT_B, BUF_ACT_FINAL, BUF_Y, BUF_WAV, BUF_HIDDEN, BUF_WTA_OVERRIDE) = range(16)
+ BUF_ACT_B, BUF_ACT_FINAL, BUF_Y, BUF_WAV, BUF_HIDDEN, BUF_WTA_OVERRIDE, BUF_LEVEL) = range(17)
 _BUF_DTYPES = {BUF_SCM: np.float64, BUF_BFW: np.float64, BUF_PIT_COST: np.float64, BUF_PERMS: np.int32,
                BUF_ACT_B: np.uint8, BUF_ACT_FINAL: np.uint8, BUF_WTA_OVERRIDE: np.uint8}
 
@@ -488,7 +488,7 @@ class Handle:
         el = C.c_int32()
         check(self.h, self.lib.css_buffer_dims(self.h, which, dims, C.byref(el)))
         shape = [int(x) for x in dims]
-        rank = {BUF_X: 3, BUF_SCM: 4, BUF_BFW: 4, BUF_SEP: 4, BUF_MASK_ST: 3, BUF_Y: 3, BUF_WTA_OVERRIDE: 3}.get(which, 2)
+        rank = {BUF_X: 3, BUF_SCM: 4, BUF_BFW: 4, BUF_SEP: 4, BUF_MASK_ST: 3, BUF_Y: 3, BUF_WTA_OVERRIDE: 3, BUF_LEVEL: 1}.get(which, 2)
         return tuple(shape[:rank]), int(el.value)
 
     def read(self, which: int) -> np.ndarray:

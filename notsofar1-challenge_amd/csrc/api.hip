@@ -81,7 +81,7 @@ struct css_ctx {
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host, w_on_device;   // segment weights of the session / what segw holds (uploaded when they change)
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, qkf, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
-        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc;
+        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc, level;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
     // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two or three chains drift out of
@@ -100,6 +100,7 @@ struct css_ctx {
     // finished ranges of the output leave while the last ranges are still being synthesised.
     // range check of the split-f16 operand format (split_f16.hpp): a device word set when the stitched activity or the
     // waveforms hold a non-finite value, mirrored into page-locked host memory at the end of every pass
+    unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
     unsigned int* range_flag_dev = nullptr;
     unsigned int* range_flag_host = nullptr;
     bool range_fallback = true;      // repeat such a pass on the exact float32 kernels (else: CSS_ERR_RANGE)
@@ -297,6 +298,7 @@ StitchArgs stitch_args(css_ctx* h) {
     a.activity_th = h->cfg.activity_th; a.dilation = h->cfg.dilation_frames; a.erosion = h->cfg.erosion_frames;
     a.Y = (float*)h->Y.p; a.KIp = h->KIp;
     a.y_split = h->split ? 1 : 0;
+    a.level = h->split ? h->peak_dev : nullptr;
     return a;
 }
 
@@ -436,10 +438,13 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
             return bail(CSS_ERR_HIP, "lane stream / event could not be created");
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(CSS_ERR_HIP, "copy stream could not be created");
-    if (hipMalloc((void**)&h->range_flag_dev, 64) != hipSuccess ||
+    if (hipMalloc(&h->level.p, 64) != hipSuccess || hipMemset(h->level.p, 0, 64) != hipSuccess ||
+        hipMalloc((void**)&h->range_flag_dev, 64) != hipSuccess ||
         hipHostMalloc((void**)&h->range_flag_host, 64, hipHostMallocDefault) != hipSuccess)
         return bail(CSS_ERR_HIP, "range flag could not be allocated");
     *h->range_flag_host = 0;
+    h->level.cap = 64;
+    h->peak_dev = (unsigned int*)h->level.p;
     if (hipMalloc((void**)&h->blob, need * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(weights) failed");
     if (hipMemcpy(h->blob, blob_host, need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "weight upload failed");
@@ -484,7 +489,7 @@ int css_destroy(css_handle_t h) {
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->qkf, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
                       &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
-                      &h->in16, &h->pcm_f, &h->enc};
+                      &h->in16, &h->pcm_f, &h->enc, &h->level};
     for (int l = 1; l < css_ctx::MAX_LANES; ++l) {
         for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lqkf[l], &h->lctx[l]})
             if (b->p) hipFree(b->p);
@@ -564,6 +569,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
 #define ENS(buf, bytes, ...)                                              \
     if ((rc = ensure(h, h->buf, (size_t)(bytes), ##__VA_ARGS__)) != CSS_OK) return rc;
     hipEventRecord(h->ev[0], h->stream);
+    HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
     ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
     ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
     if ((rc = ensure_activations(h, std::min<int64_t>(h->max_batch, nseg), T)) != CSS_OK) return rc;
@@ -640,8 +646,8 @@ static void stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* p
     const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
     {
         CSS_PROF(CSS_PROF_DEINTERLEAVE, st);
-        if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, st);
-        else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
+        if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, h->peak_dev, st);
+        else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, h->peak_dev, st);
     }
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
@@ -956,7 +962,7 @@ static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int6
         g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
         { CSS_PROF(CSS_PROF_ISTFT_GEMM, h->stream); launch_gemm(g, h->stream); }
-        { CSS_PROF(CSS_PROF_WAVE_OLA, h->stream); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->stream); }
+        { CSS_PROF(CSS_PROF_WAVE_OLA, h->stream); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->split ? h->peak_dev : nullptr, h->stream); }
     }
     hipEventRecord(h->ev[6], h->stream);
     HIPCHK(h, hipGetLastError());
@@ -1374,7 +1380,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
-    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, h->stream);
+    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, nullptr, h->stream);
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
     g.B = cm; g.ldb = hop; g.strideB = n_pad;
@@ -1436,7 +1442,7 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
     for (int b = 0; b < batch; ++b) {
         // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
-        launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
+        launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, nullptr, h->stream);
         GemmArgs g{};
         g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
         g.B = cm + (size_t)b * C * n_pad; g.ldb = hop; g.strideB = n_pad;
@@ -1477,7 +1483,7 @@ int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t
     g.M = (int)t_frames; g.N = N; g.K = KI; g.batch = batch;
     g.alpha = 1.f;
     launch_gemm(g, h->stream);
-    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, 0, t_frames, n_out, 0, h->stream);
+    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, 0, t_frames, n_out, 0, nullptr, h->stream);
     HIPCHK(h, hipMemcpyAsync(wav, wv, w_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CSS_OK;
@@ -1506,6 +1512,7 @@ static int buffer_info(css_ctx* h, int which, DevBuf** buf, int64_t dims[4], int
         case CSS_BUF_WAV: *buf = &h->wav; dims[0] = S; dims[1] = h->plan.n_out; break;
         case CSS_BUF_HIDDEN: *buf = &h->hx; dims[0] = h->last_batch_tokens; dims[1] = h->d.attention_dim; break;
         case CSS_BUF_WTA_OVERRIDE: *buf = &h->wta; dims[0] = nseg; dims[1] = F; dims[2] = T; *elem = 1; break;
+        case CSS_BUF_LEVEL: *buf = &h->level; dims[0] = 1; break;
         default: return CSS_ERR_INVALID_ARG;
     }
     return CSS_OK;
@@ -1534,13 +1541,23 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
     if ((which == CSS_BUF_FEATURES || which == CSS_BUF_Y) && h->split) {
         // the device holds the rows as split-f16 GEMM operands (split_f16.hpp); hand out float32 = hi + lo * 2^-11
         const int64_t rows = which == CSS_BUF_Y ? dims[0] * dims[1] : dims[0], K = which == CSS_BUF_Y ? dims[2] : dims[1];
+        float unscale = 1.f;
+        if (which == CSS_BUF_Y) {   // the rows carry the session's level gain (split_f16.hpp level_gain)
+            float peak = 0.f;
+            HIPCHK(h, hipMemcpy(&peak, h->peak_dev, sizeof(float), hipMemcpyDeviceToHost));
+            if (peak > 0.f && peak < 3.0e38f) {
+                int e;
+                std::frexp(peak, &e);
+                unscale = std::ldexp(1.f, std::min(std::max(e, -100), 100));
+            }
+        }
         std::vector<float> row((size_t)K);
         for (int64_t r = 0; r < rows; ++r) {
             float* dst = (float*)host + r * K;
             const _Float16* src = (const _Float16*)dst;
             for (int64_t k = 0; k < K; ++k) {
                 const int64_t i = ((k >> 5) << 6) | (k & 31);
-                row[(size_t)k] = (float)src[i] + (float)src[i + 32] * (1.0f / 2048.0f);
+                row[(size_t)k] = ((float)src[i] + (float)src[i + 32] * (1.0f / 2048.0f)) * unscale;
             }
             std::memcpy(dst, row.data(), (size_t)K * sizeof(float));
         }

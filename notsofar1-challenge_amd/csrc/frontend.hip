@@ -32,23 +32,32 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // ------------------------------------------------------------------------------------------------
 // split_out: each channel row is written as a split-f16 GEMM operand (split_f16.hpp; n_pad % 32 == 0).  The
 // overlapping frames the analysis GEMM reads (row stride = hop, a multiple of 32) are valid split rows of it.
+__device__ __forceinline__ void peak_update(unsigned int* peak, float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (peak && (threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak, __float_as_uint(m));   // non-negative floats order like uints
+}
+
 __global__ void deinterleave_kernel(const float* __restrict__ pcm, float* __restrict__ out, int64_t n, int C,
-                                    int64_t n_pad, int64_t i_lo, int64_t i_hi, int split_out) {
+                                    int64_t n_pad, int64_t i_lo, int64_t i_hi, int split_out, unsigned int* peak) {
     const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= i_hi) return;
-    for (int c = 0; c < C; ++c) {
-        const float v = i < n ? pcm[i * C + c] : 0.f;
-        if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)c * n_pad + (i & ~(int64_t)31)), (int)(i & 31), v);
-        else out[(int64_t)c * n_pad + i] = v;
-    }
+    float m = 0.f;
+    if (i < i_hi)
+        for (int c = 0; c < C; ++c) {
+            const float v = i < n ? pcm[i * C + c] : 0.f;
+            m = fmaxf(m, fabsf(v));
+            if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)c * n_pad + (i & ~(int64_t)31)), (int)(i & 31), v);
+            else out[(int64_t)c * n_pad + i] = v;
+        }
+    peak_update(peak, m);
 }
 
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         int split_out, hipStream_t s) {
+                         int split_out, unsigned int* peak, hipStream_t s) {
     if (i_hi <= i_lo) return;
     const int64_t blocks = (i_hi - i_lo + 255) / 256;
     hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad, i_lo, i_hi,
-                       split_out);
+                       split_out, peak);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -72,18 +81,22 @@ void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, 
 // the same scaling straight into the channel-major frame buffer [C][n_pad] (zeros past n), samples [i_lo, i_hi): planes
 // are already channel-major, so the wav edge needs no sample-major detour
 __global__ void pcm16_to_cm_kernel(const int16_t* __restrict__ planes, float* __restrict__ out, int64_t n, int64_t n_pad,
-                                   int64_t i_lo, int64_t i_hi) {
+                                   int64_t i_lo, int64_t i_hi, unsigned int* peak) {
     const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= i_hi) return;
-    const int c = blockIdx.y;
-    out[(int64_t)c * n_pad + i] = i < n ? (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f) : 0.f;
+    float v = 0.f;
+    if (i < i_hi) {
+        const int c = blockIdx.y;
+        v = i < n ? (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f) : 0.f;
+        out[(int64_t)c * n_pad + i] = v;
+    }
+    peak_update(peak, fabsf(v));
 }
 
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
-                                   int64_t i_hi, hipStream_t s) {
+                                   int64_t i_hi, unsigned int* peak, hipStream_t s) {
     if (i_hi <= i_lo) return;
     hipLaunchKernelGGL(pcm16_to_cm_kernel, dim3((unsigned)((i_hi - i_lo + 255) / 256), C), dim3(256), 0, s, planes, pcm_cm, n,
-                       n_pad, i_lo, i_hi);
+                       n_pad, i_lo, i_hi, peak);
 }
 
 __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ a, int64_t n, unsigned int* __restrict__ flag) {
@@ -273,7 +286,8 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
 // Gather form: one thread per output sample, no atomics, bit-reproducible.
 // ------------------------------------------------------------------------------------------------
 __global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ out, int64_t T_frames, int hop,
-                                int64_t q_lo, int64_t q_hi, int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0) {
+                                int64_t q_lo, int64_t q_hi, int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0,
+                                const unsigned int* __restrict__ level) {
     const int b = blockIdx.y;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t q = q_lo + idx / hop;
@@ -285,15 +299,16 @@ __global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__
     float v = 0.f;
     if (q - 1 >= f_lo && q - 1 < f_hi) v = g[(q - 1) * 2 * hop + hop + r];
     if (q >= f_lo && q < f_hi) v += g[q * 2 * hop + r];
+    if (level) v *= 1.0f / level_gain(level);   // a power of two: exact
     out[(int64_t)b * out_ld + n] = v;
 }
 
 void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
-                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, hipStream_t s) {
+                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, const unsigned int* level, hipStream_t s) {
     const int64_t total = (q_hi - q_lo) * hop;
     if (total <= 0) return;
     const dim3 grid((unsigned)((total + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0);
+    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, level);
 }
 
 // ------------------------------------------------------------------------------------------------

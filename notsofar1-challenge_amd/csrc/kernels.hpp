@@ -97,13 +97,14 @@ void launch_relpos_attention(const float* qkv, const float* qk_frag, const float
 // ------------------------------------------------------------------------------------------------
 // samples [i_lo, i_hi) of every channel: pcm [n][C] -> pcm_cm [C][n_pad] (zeros past n)
 // (split_out: channel rows as split-f16 GEMM operands, n_pad % 32 == 0)
+// peak (may be null): max |sample| of what was laid out, as float bits (atomicMax; split_f16.hpp level_gain)
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         int split_out, hipStream_t s);
+                         int split_out, unsigned int* peak, hipStream_t s);
 // wav edges on the device: C mono PCM16 planes [C][n] -> sample-major float32 [n][C]; and peak-normalised PCM16
 // encoding of the S output streams (peak_bits: S words of scratch, holds max|x| as float bits afterwards)
 void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s);
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
-                                   int64_t i_hi, hipStream_t s);
+                                   int64_t i_hi, unsigned int* peak, hipStream_t s);
 // *flag |= 1 if any of a[0..n) is not finite (the split-f16 operand range check, DESIGN.md "Numerical hazards" 6)
 void launch_nonfinite_flag(const float* a, int64_t n, unsigned int* flag, hipStream_t s);
 void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
@@ -115,8 +116,9 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
                      int split_out, hipStream_t s);
 // out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
 // only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
+// level (may be null): the samples are multiplied by 1 / level_gain(level) (undoes the scaling of the split spectra rows)
 void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
-                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, hipStream_t s);
+                     int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, const unsigned int* level, hipStream_t s);
 // [B][2F][T] planes -> [B][T][KIp] rows for the inverse GEMM
 void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s);
 
@@ -157,6 +159,7 @@ struct StitchArgs {
     float activity_th; int dilation; int erosion;
     float* Y; int KIp;         // [S][T_long][KIp]
     int y_split;               // Y rows as split-f16 GEMM operands (split_f16.hpp) instead of float32
+    const unsigned int* level; // with y_split: the rows are scaled by level_gain(level) (split_f16.hpp); null = 1
 };
 // scratch: pit_cost_scratch_bytes(total boundaries) bytes, indexed by absolute boundary
 size_t pit_cost_scratch_bytes(int64_t n_boundaries);

@@ -39,6 +39,21 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);
 }
 
+// Level normalisation of the one split operand whose magnitude follows the recording's level, the stitched spectra fed
+// to the synthesis transform: they are multiplied by a power of two that brings the recording's peak sample into
+// [0.5, 1) (peak_bits: max |sample| as float bits, gathered while the PCM is laid out channel-major) and the
+// synthesised samples are multiplied back -- exact in float32, so integer-scaled PCM (+-32768) cannot overflow the
+// format and a recording at -100 dBFS does not fall into its 11-bit range.  nullptr / silence: gain 1.
+__device__ __forceinline__ float level_gain(const unsigned int* peak_bits) {
+    if (!peak_bits) return 1.f;
+    const float p = __uint_as_float(*peak_bits);
+    if (!(p > 0.f) || !(p < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(p, &e);                                   // p = m * 2^e, m in [0.5, 1)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.f, -e);
+}
+
 // store element k of a split row (row = base pointer of the row, as halves)
 __device__ __forceinline__ void split_store(_Float16* row, int k, float x) {
     _Float16 hi, lo;

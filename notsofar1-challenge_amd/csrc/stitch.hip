@@ -386,12 +386,13 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
         tile[tx * TS + a.F + f] = im;
     }
     __syncthreads();
+    const float lvl = a.y_split ? level_gain(a.level) : 1.f;
     for (int r = 0; r < OT; ++r) {
         if (t0 + r >= t_hi) break;
         float* out = a.Y + ((int64_t)s * a.T_long + t0 + r) * a.KIp;
         for (int j = threadIdx.x; j < a.KIp; j += 256) {
             const float v = j < 2 * a.F ? tile[r * TS + j] : 0.f;  // zero K padding
-            if (a.y_split) split_store(reinterpret_cast<_Float16*>(out), j, v);   // operand rows of the synthesis GEMM
+            if (a.y_split) split_store(reinterpret_cast<_Float16*>(out), j, v * lvl);   // operand rows of the synthesis GEMM
             else out[j] = v;
         }
     }

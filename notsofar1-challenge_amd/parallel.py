@@ -157,6 +157,11 @@ class HipShardBackend:
         from . import _lib
         return self._view(_lib.BUF_ACT_B, "|u1")
 
+    def level_view(self):
+        """max |sample| of the PCM this rank has laid out [1] float32, in place on the device"""
+        from . import _lib
+        return self._view(_lib.BUF_LEVEL, "<f4")
+
     def istft_partial(self, lo, hi, out):
         self.h.stage_istft_partial(lo, hi, out.data_ptr(), out.stride(0))
 
@@ -216,9 +221,12 @@ class ShardedSession:
             be.pit_costs(me.b_lo, me.b_hi)
             if self.world == 1:
                 return None
-            send = be.scratch("send_costs", (self.max_b, self.S * self.S), torch.float64)
+            # one more row rides along: the peak sample of this rank's slice (every rank must scale the split-f16 operand
+            # of the synthesis transform by the same power of two, or the last bits would depend on the sharding)
+            send = be.scratch("send_costs", (self.max_b + 1, self.S * self.S), torch.float64)
             if me.b_hi > me.b_lo:
                 send[:me.b_hi - me.b_lo].copy_(be.costs_view()[me.b_lo:me.b_hi])
+            send[self.max_b, 0] = be.level_view()[0]
             return send
 
     # phase 2: identical permutation scan on every rank, overlap-add of the masks, activity bits
@@ -226,10 +234,11 @@ class ShardedSession:
         me, be, torch = self.me, self.be, self.torch
         with self._ctx():
             if self.world > 1:
-                assert tuple(all_costs.shape) == (self.world, self.max_b, self.S * self.S), all_costs.shape
+                assert tuple(all_costs.shape) == (self.world, self.max_b + 1, self.S * self.S), all_costs.shape
                 if self.nseg > 1:
-                    idx = self._gather_index("idx_costs", [(p.b_lo, p.b_hi) for p in self.plans], self.max_b, self.nseg - 1)
+                    idx = self._gather_index("idx_costs", [(p.b_lo, p.b_hi) for p in self.plans], self.max_b + 1, self.nseg - 1)
                     be.costs_view()[:self.nseg - 1].copy_(all_costs.reshape(-1, self.S * self.S).index_select(0, idx))
+                be.level_view().copy_(all_costs[:, self.max_b, 0].max().to(torch.float32).reshape(1))
             be.pit_scan()
             be.stitch_masks(me.t_lo, me.t_hi)
             if self.world == 1:

@@ -30,6 +30,7 @@ class OracleStageBackend:
         self.sep = [None] * self.nseg
         self.costs = np.full((max(self.nseg - 1, 1), self.S * self.S), np.nan)
         self.perms = None
+        self.level = np.zeros(1, np.float32)
         self.mask_st = np.full((self.S, self.F, self.TL), np.nan, np.float32)
         self.act_b = np.zeros((self.S, self.TL), np.uint8)
         self.Y = np.full((self.S, self.F, self.TL), np.nan + 0j, dtype=np.complex64)
@@ -94,6 +95,9 @@ class OracleStageBackend:
 
     def act_view(self):
         return torch.from_numpy(self.act_b)
+
+    def level_view(self):
+        return torch.from_numpy(self.level)
 
     def scratch(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)

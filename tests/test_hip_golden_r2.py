@@ -1,0 +1,206 @@
+"""The HIP path (through the C ABI) against the second set of reference fixtures (tests/golden/gen_golden_r2.py): every
+non-default CssCfg branch, three other segmentations, BASELINE.json configs[1] / configs[2] at full size (60 s), and
+css_inference against the captured session triple.  Needs an MI355X."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import css_oracle as O
+from conftest import GOLDEN, pkg, rel_rms, take_windows
+from test_oracle_golden_r2 import VARIANTS, sha, unpack2, unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+F, S = 257, 3
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = pkg("_lib")
+    if lib.load().css_device_count() < 1:
+        pytest.fail("no HIP device visible: the parity tests must run on the GPU box")
+    return lib
+
+
+@pytest.fixture(scope="module")
+def sep_mc(L, mc_state):
+    s = pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=64)
+    yield s
+    s.close()
+
+
+def staged_run(h, L, pcm, run_cfg, wta=None):
+    """the pass stage by stage, with the reference's winner-take-all decisions injected when given"""
+    h.begin(pcm, pcm.shape[0], pcm.shape[1], run_cfg)
+    p = h.get_plan()
+    nseg, TL = int(p.num_segments), int(p.mix_frames)
+    if wta is not None:
+        h.write(L.BUF_WTA_OVERRIDE, wta)
+    h.stage_stft(); h.stage_masknet(0, nseg); h.stage_mvdr(0, nseg)
+    h.stage_pit_costs(0, nseg - 1); h.stage_pit_scan(); h.stage_stitch(0, TL); h.stage_istft(0, TL)
+    return h.read(L.BUF_WAV), h.read(L.BUF_PERMS), h.read(L.BUF_ACT_B).astype(bool).T, h.read(L.BUF_ACT_FINAL).astype(bool).T
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_csscfg_branches_vs_reference(L, sep_mc, mix60, golden, name):
+    """css.py:211-247 and :263-271 against the REFERENCE (not the oracle): decisions exact, waveforms <= 1e-4."""
+    CSS = pkg("css")
+    g = golden("variants_mc.npz")
+    mix = np.ascontiguousarray(mix60[0, int(g["opt_offset"]):int(g["opt_offset"]) + int(g["opt_samples"])])
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False, **VARIANTS[name]), 16000, 7)
+    wav, perms, act_b, act_f = staged_run(sep_mc.handle, L, mix, run_cfg, g["opt_wta_index"])
+    p = f"opt_{name}"
+    assert wav.shape[1] == int(g[p + "_wav_len"])
+    assert [tuple(x) for x in perms[1:]] == [tuple(x) for x in g[p + "_pit_perm"]]
+    shape = tuple(g[p + "_activity_shape"])
+    assert np.array_equal(act_b, unpack_bits(g[p + "_activity_b"], shape))
+    assert np.array_equal(act_f, unpack_bits(g[p + "_activity_final"], shape))
+    ww = take_windows(wav, 4)
+    for k in range(S):   # the fourth window lies in the ragged, ill-conditioned last segment (test_oracle_golden_r2.py)
+        assert rel_rms(ww[k][:3], g[p + "_wav_windows"][k][:3]) < 1e-4, (name, k)
+
+
+@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0)])
+def test_other_segmentations_vs_reference(L, sep_mc, mix60, golden, seg_hop):
+    CSS = pkg("css")
+    g = golden("variants_mc.npz")
+    name = f"seg{int(seg_hop[0])}{int(seg_hop[1])}"
+    mix = np.ascontiguousarray(mix60[0, int(g["seg_offset"]):int(g["seg_offset"]) + int(g["seg_samples"])])
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False, segment_size_sec=seg_hop[0], hop_size_sec=seg_hop[1])
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    wta = unpack2(g[name + "_wta_index"], g[name + "_wta_shape"])
+    h = sep_mc.handle
+    wav, perms, act_b, act_f = staged_run(h, L, mix, run_cfg, wta)
+    Ts = int(g[name + "_segment_frames"])
+    assert int(run_cfg.c.segment_frames) == Ts and h.get_plan().num_segments == wta.shape[0]
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, wta.shape[0], Ts)
+    assert np.abs(np.moveaxis(m[:S, :, 0], 0, 2)[::8, ::4] - g[name + "_masks_spk_seg0"]).max() < 1.5e-5
+    flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != wta).sum())
+    assert flips <= 1e-5 * wta.size + 3
+    assert [tuple(x) for x in perms[1:]] == [tuple(x) for x in g[name + "_pit_perm"]]
+    assert np.array_equal(act_f, unpack_bits(g[name + "_activity_final"], tuple(g[name + "_activity_shape"])))
+    ww = take_windows(wav, 4)
+    for k in range(S):
+        assert rel_rms(ww[k][:3], g[name + "_wav_windows"][k][:3]) < 1e-4, (name, k)
+
+
+def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden):
+    """BASELINE.json configs[1] at full size against the reference's own 60 s run: decisions, winner-take-all maps,
+    stitched masks, and the waveforms -- free-running where no decision differs, and on the reference's decisions."""
+    CSS = pkg("css")
+    g = golden("e2e60_mc.npz")
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    h = sep_mc.handle
+    pcm = np.ascontiguousarray(mix60[0])
+    free = h.run(pcm, run_cfg)
+    wta = unpack2(g["wta_packed"], g["wta_shape"])
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, 40, 186)
+    perms = h.read(L.BUF_PERMS)
+    act_f = h.read(L.BUF_ACT_FINAL).astype(bool).T
+    mask_st = h.read(L.BUF_MASK_ST)                                    # [S, F, T_long]
+    assert free.shape == (3, int(g["wav_len"])) and h.get_plan().num_segments == int(g["num_segments"])
+    assert sha(np.ascontiguousarray(perms[1:]).astype(np.int32)) == str(g["sha_pit_perm"])
+    # segments with an IPD feature ON the atan2 branch cut (see test_oracle_golden_r2.py): the reference is discontinuous
+    # there; everything else must agree to rounding
+    X = O.stft(pcm)
+    def on_cut(i):
+        f = O.features(X[:, i * 93:i * 93 + 186])[257:].reshape(6, 257, -1)[:, 1:256]
+        return bool(np.abs(np.abs(f) - np.pi).min() < 5e-7)
+    cut = [i for i in range(39) if on_cut(i)]
+    per_seg = [int((np.argmax(m[:, :, i], axis=0) != wta[i]).sum()) for i in range(40)]
+    assert sum(n for i, n in enumerate(per_seg) if i not in cut) <= 1e-5 * wta.size + 3, per_seg
+    assert all(per_seg[i] <= 0.005 * 257 * 186 for i in cut) and len(cut) <= 8, (cut, per_seg)
+    stable_t = np.ones(3749, bool)
+    for i in cut + [39]:
+        stable_t[i * 93:i * 93 + 186 + 2] = False
+    ref_act = unpack_bits(g["activity_final"], tuple(g["activity_shape"]))
+    assert np.array_equal(act_f[stable_t], ref_act[stable_t])
+    if all(per_seg[i] == 0 for i in cut):
+        assert sha(np.packbits(act_f)) == str(g["sha_activity_final"])
+    ms = np.abs(mask_st.transpose(1, 2, 0)[::32, ::16] - g["mask_stitched"])
+    assert ms[:, stable_t[::16]].max() < 1.5e-5
+    # waveforms, one sample per frame, outside the unstable regions: on the reference's decisions, and free-running
+    # wherever no decision of the covering segments differs
+    forced, _, _, _ = staged_run(h, L, pcm, run_cfg, wta)
+    t = np.flatnonzero(stable_t)
+    for k in range(S):
+        assert rel_rms(forced[k, ::256][t], g["wav_dec"][k][t]) < 1e-4, k
+    clean_t = stable_t.copy()
+    for i, n in enumerate(per_seg):
+        if n:
+            clean_t[max(i * 93 - 2, 0):i * 93 + 186 + 2] = False
+    assert clean_t.mean() > 0.6
+    t = np.flatnonzero(clean_t)
+    for k in range(S):
+        assert rel_rms(free[k, ::256][t], g["wav_dec"][k][t]) < 1e-4, k
+
+
+def test_config3_60s_sc_vs_reference(L, sc_state, mix60, golden):
+    """BASELINE.json configs[2] at full size: single-channel model, no beamformer, mask multiplication."""
+    CSS = pkg("css")
+    g = golden("e2e60_sc.npz")
+    sep = pkg("separator").HipSeparator(sc_state[0], None, device=0, max_batch_segments=64)
+    try:
+        h = sep.handle
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 1)
+        wav = h.run(np.ascontiguousarray(mix60[0, :, :1]), run_cfg)
+        assert h.get_plan().num_segments == 40 and wav.shape[1] == int(g["wav_len"])
+        assert sha(np.ascontiguousarray(h.read(L.BUF_PERMS)[1:]).astype(np.int32)) == str(g["sha_pit_perm"])
+        assert sha(np.packbits(h.read(L.BUF_ACT_FINAL).astype(bool).T)) == str(g["sha_activity_final"])
+        for k in range(S):
+            assert rel_rms(wav[k, ::256], g["wav_dec"][k]) < 2e-5, k
+            assert rel_rms(take_windows(wav, 4)[k], g["wav_windows"][k]) < 2e-5, k
+    finally:
+        sep.close()
+
+
+def test_css_inference_against_the_captured_triple(tmp_path, mc_state, mix60):
+    """css_inference (css.py:51-107) on the session the reference was run on: same Series columns, same files, same
+    lengths, the input mixture bit for bit, the separated streams to within a PCM16 step; cache and pass-through rules."""
+    import pandas as pd
+    import torch
+    import yaml
+    with open(os.path.join(GOLDEN, "session_triple.json")) as f:
+        t = json.load(f)
+    dec = np.load(os.path.join(GOLDEN, "session_triple_dec.npz"))
+    CSS, W = pkg("css"), pkg("wavio")
+    n, off, gain = t["input"]["n_samples"], t["input"]["mix_offset"], t["input"]["pcm16_gain"]
+    pcm16 = np.clip(np.rint(mix60[0, off:off + n] * gain * 32768.0), -32768, 32767).astype(np.int16)
+    names = []
+    for c in range(7):
+        p = tmp_path / "in" / f"ch{c}.wav"
+        W.write_pcm16_samples(p, pcm16[:, c], 16000)
+        names.append(str(p))
+    # a checkpoint directory as the trainer writes it (css/helpers.py:14-37): one yaml, one .pt with "module." keys
+    mdir = tmp_path / "models" / "notsofar" / "conformer1.0" / "mc"
+    mdir.mkdir(parents=True)
+    torch.save({"model": {"module." + k: torch.from_numpy(np.asarray(v)) for k, v in mc_state[0].items()}}, mdir / "ckpt.pt")
+    with open(mdir / "train.yaml", "w") as f:
+        yaml.safe_dump({"conformer_css_cfg": {"nnet_conf": {"conformer_conf": {
+            "attention_dim": 512, "attention_heads": 8, "num_blocks": 18, "dropout_rate": 0.0}}}}, f)
+    session = pd.Series({"session_id": t["input"]["session_id"], "is_mc": True, "wav_file_names": names, "device_name": "synth"})
+    out_dir = tmp_path / "out"
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
+    res = CSS.css_inference(str(out_dir), str(tmp_path / "models"), session, cfg, fetch_from_cache=False)
+    rel = lambda p: os.path.relpath(str(p), str(out_dir))
+    assert sorted(res.index.tolist()) == t["output_columns"]
+    assert [rel(p) for p in res["sep_wav_file_names"]] == t["sep_wav_file_names"]
+    files = sorted(rel(os.path.join(dp, f)) for dp, _, fs in os.walk(out_dir) for f in fs)
+    assert files == t["files"]
+    for name in files:
+        pcm, sr = W.read_wav_pcm16(out_dir / name)
+        assert sr == 16000 and len(pcm) == t["lengths"][name]
+        if name.endswith("input_mixture.wav"):
+            assert sha(pcm.astype(np.int16)) == t["pcm16_sha256"][name]
+        else:
+            ref = dec[name.replace("/", "__")].astype(np.float64)              # every 64th sample, before PCM16
+            got = pcm[::64].astype(np.float64) / 32767.0
+            assert np.abs(got - ref).max() <= 1.01 / 32767.0                    # within one PCM16 step
+            assert rel_rms(got, ref) < 5e-4                                     # (quantisation: 1 / 32767 / sqrt(12) / rms 0.18)
+    res2 = CSS.css_inference(str(out_dir), str(tmp_path / "models"), session, cfg, fetch_from_cache=True)
+    assert [rel(p) for p in res2["sep_wav_file_names"]] == t["cached_sep_wav_file_names"]
+    res3 = CSS.css_inference(str(out_dir), "unused", session, CSS.CssCfg(pass_through_ch0=True), fetch_from_cache=False)
+    assert [os.path.basename(p) for p in res3["sep_wav_file_names"]] == t["pass_through"]

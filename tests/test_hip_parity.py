@@ -2,7 +2,12 @@
 real reference.  Everything here needs an MI355X: run with `-m gpu`.
 
 Tolerances (float32 path; written where they are asserted):
-  * masks vs oracle                      max-abs <= 5e-5 (observed ~5e-6)
+  * masks vs oracle / vs reference       max-abs <= 1.5e-5 on the golden inputs (observed 3e-6 .. 9e-6: 2x margin).
+                                         SURVEY.md 8(d) asks for 5e-6; that is the oracle's own distance class (1.6e-6 to
+                                         the reference) but not reachable in the max norm by a float32 feature path: the
+                                         IPD of a short mean-removed phasor amplifies the float32 rounding of the STFT
+                                         (feature error p99 1e-5, max 7e-4, DESIGN.md hazard 3) and the masks inherit it.
+                                         Arbitrary clips / model widths (tests at the end) keep 5e-5 for the same reason.
   * separated waveforms vs reference     rel-RMS <= 1e-4 on identical winner-take-all decisions
                                          (BASELINE.json north_star: "within 1e-4 RMS on the separated waveforms")
   * decisions (segment indices, permutations, activity bits): exact
@@ -131,10 +136,10 @@ def test_stage_by_stage_vs_oracle(L, CSS, sep_mc, mc_state, mix_stage, golden):
     hid = h.read(L.BUF_HIDDEN)
     assert np.abs(hid[:T] - taps["block17"]).max() < 1e-4
     per_seg, m = hip_masks_per_segment(h, L, nseg)
-    assert np.abs(m[:, :, 0, :] - om).max() < 5e-5
+    assert np.abs(m[:, :, 0, :] - om).max() < 1.5e-5
     fd, td = int(g["fdec"]), int(g["tdec"])
-    assert np.abs(per_seg[0][0][::fd, ::td] - g["masks_spk"][0]).max() < 5e-5      # vs the reference's masks
-    assert np.abs(per_seg[1][0][::fd, ::td] - g["masks_spk"][1]).max() < 5e-5
+    assert np.abs(per_seg[0][0][::fd, ::td] - g["masks_spk"][0]).max() < 1.5e-5    # vs the reference's masks
+    assert np.abs(per_seg[1][0][::fd, ::td] - g["masks_spk"][1]).max() < 1.5e-5
 
     # everything downstream of the masks, against the oracle driven by the HIP masks with a float64 MVDR
     taps = {}
@@ -148,7 +153,8 @@ def test_stage_by_stage_vs_oracle(L, CSS, sep_mc, mc_state, mix_stage, golden):
     bfw = h.read(L.BUF_BFW)  # [seg, S, F, 14]
     w = bfw[0, :, :, 0::2] + 1j * bfw[0, :, :, 1::2]
     assert rel_rms(w, taps["mvdr0"]["w"]) < 1e-4
-    assert rel_rms(w, g["w_seg0"]) < 2e-3          # the reference's complex64 solve, on its own masks
+    print(f"W vs the reference's complex64 solve: {rel_rms(w, g['w_seg0']):.2e}")
+    assert rel_rms(w, g["w_seg0"]) < 1e-3          # the reference's complex64 solve, on its own masks
     sep_ = h.read(L.BUF_SEP).reshape(nseg, S, F, T, 2)
     costs = h.read(L.BUF_PIT_COST)
     assert np.abs(costs[0].reshape(S, S) - oside["pit_costs"][0]).max() < 1e-9
@@ -208,7 +214,7 @@ def test_e2e_decisions_match_reference(e2e, L, sep_mc):
     assert np.array_equal(side["activity_b"].numpy(), _unpack(g["activity_b"], shape))
     assert np.array_equal(side["activity_final"].numpy()[0], _unpack(g["activity_final"], shape))
     assert tuple(side["mask_stitched"].shape) == (1, F, shape[0], 3) and side["segment_frames"] == T
-    assert np.abs(side["mask_stitched"].numpy()[0, ::16, ::8] - g["mask_stitched"]).max() < 5e-5
+    assert np.abs(side["mask_stitched"].numpy()[0, ::16, ::8] - g["mask_stitched"]).max() < 1.5e-5
     flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != g["wta_index"]).sum())
     assert flips <= 1e-5 * g["wta_index"].size + 3      # float32-rounding-level ties only
 
@@ -229,9 +235,12 @@ def test_e2e_waveform_vs_reference(e2e, L, CSS, sep_mc):
     for k in range(S):
         assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-4
         assert rel_rms(w2[k, ::64], g["wav_dec"][k]) < 1e-4
-    ww = take_windows(np.stack(wavs))                        # free-running decisions: a handful of flips at most
+    # free-running decisions: 1e-4 as well when no winner-take-all decision differs from the reference's (one flipped
+    # time-frequency point moves a stream by ~1e-4, a handful stay below 1e-3)
+    flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != g["wta_index"]).sum())
+    ww = take_windows(np.stack(wavs))
     for k in range(S):
-        assert rel_rms(ww[k], g["wav_windows"][k]) < 1e-3
+        assert rel_rms(ww[k], g["wav_windows"][k]) < (1e-4 if flips == 0 else 1e-3), flips
 
 
 def test_e2e_forced_permutations(e2e, L, CSS, sep_mc):
