@@ -219,7 +219,7 @@ enum css_linear_mode { CSS_LINEAR_SPLIT_F16 = 0, CSS_LINEAR_EXACT_F32 = 1 };
 int css_set_linear_mode(css_handle_t h, int mode);
 int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css_status */
 /* Operand range of CSS_LINEAR_SPLIT_F16: |x| <= 65504 (float16).  Nothing is clamped: a larger activation becomes
- * inf / NaN, reaches the stitched activity and the waveforms, and css_run* then repeats the whole pass on the exact
+ * inf / NaN, the GEMM that consumes it raises a device flag, and css_run* then repeats the whole pass on the exact
  * float32 kernels (enable = 1, the default) or returns CSS_ERR_RANGE (enable = 0).  css_range_status: passes repeated
  * so far, and whether the last pass was one.  css_check_range does the same test after a staged (css_stage_*) run.
  * A model with a WEIGHT outside the range starts in, and stays in, CSS_LINEAR_EXACT_F32. */

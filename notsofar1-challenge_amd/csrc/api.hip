@@ -570,6 +570,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if ((rc = ensure(h, h->buf, (size_t)(bytes), ##__VA_ARGS__)) != CSS_OK) return rc;
     hipEventRecord(h->ev[0], h->stream);
     HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
     ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
     ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
     if ((rc = ensure_activations(h, std::min<int64_t>(h->max_batch, nseg), T)) != CSS_OK) return rc;
@@ -708,6 +709,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
                    int act, int split_out) {
         GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
         g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
+        g.range_flag = sp ? h->range_flag_dev : nullptr;
         return g;
     };
     if (ph_lo < 0) {
@@ -785,6 +787,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     g.M = nout; g.N = M; g.K = D; g.batch = 1;
     g.bias = W.head_b; g.bias_along_m = 1; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
     g.split_in = sp;
+    g.range_flag = sp ? h->range_flag_dev : nullptr;
     gemm(h, g, st);
     if (!lane) h->last_batch_tokens = M;
     return CSS_OK;
@@ -956,6 +959,7 @@ static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int6
     if (f_hi > f_lo) {
         GemmArgs g{};
         g.split_in = h->split ? 1 : 0;   // Y rows were written as split operands by the stitch stage
+        g.range_flag = h->split ? h->range_flag_dev : nullptr;
         g.A = (const float*)h->Y.p + f_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
         g.B = h->split ? h->dft_split : h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
         g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
@@ -1151,10 +1155,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     }
     if (tail) HIPCHK(h, hipStreamWaitEvent(h->stream, tail, 0));
     hipEventRecord(h->ev[7], h->stream);
-    // range check (split_f16.hpp): an operand outside the split-f16 range turned into inf / NaN and reached these
-    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
-    launch_nonfinite_flag((const float*)h->activity.p, (int64_t)S * TL, h->range_flag_dev, h->stream);
-    launch_nonfinite_flag((const float*)h->wav.p, (int64_t)S * pl.n_out, h->range_flag_dev, h->stream);
+    // range check (split_f16.hpp): a split GEMM whose operand left the format's range raised this word
     HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -1177,13 +1178,13 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     return CSS_OK;
 }
 
-// The pass, and -- when an operand left the split-f16 range (non-finite activity / samples) while the input itself was
-// finite -- the same pass again on the exact float32 kernels (css_set_range_fallback(h, 0): CSS_ERR_RANGE instead).
+// The pass, and -- when an operand left the split-f16 range (a split GEMM saw a non-finite accumulator) -- the same pass
+// again on the exact float32 kernels (css_set_range_fallback(h, 0): CSS_ERR_RANGE instead).
 static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc = run_once(h, n, n_ch, cfg, io);
     if (rc != CSS_OK) return rc;
     h->range_last = 0;
-    if (!*h->range_flag_host || !h->split) return CSS_OK;   // (in exact mode non-finite output means non-finite input)
+    if (!*h->range_flag_host || !h->split) return CSS_OK;
     h->range_last = 1;
     if (!h->range_fallback)
         return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range (|x| > 65504): use CSS_LINEAR_EXACT_F32");
@@ -1248,9 +1249,6 @@ int css_check_range(css_handle_t h) {
     int rc = check_session(h);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
-    const int S = h->d.num_spks;
-    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
-    launch_nonfinite_flag((const float*)h->activity.p, (int64_t)S * h->plan.mix_frames, h->range_flag_dev, h->stream);
     HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (*h->range_flag_host && h->split)

@@ -99,19 +99,6 @@ void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t
                        n_pad, i_lo, i_hi, peak);
 }
 
-__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ a, int64_t n, unsigned int* __restrict__ flag) {
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        bad |= !(fabsf(a[i]) <= 3.402823466e+38f);   // false for NaN and for +-inf
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-}
-
-void launch_nonfinite_flag(const float* a, int64_t n, unsigned int* flag, hipStream_t s) {
-    if (n <= 0) return;
-    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, n, flag);
-}
-
 // peak[s] = max |wav[s][:]| (as float bits: non-negative floats order like unsigned integers; peak zeroed by the caller)
 __global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ wav, int64_t n, unsigned int* __restrict__ peak) {
     const int s = blockIdx.y;

@@ -19,6 +19,14 @@ __device__ __forceinline__ int xcd_tile(int L, int n_tiles) {
     return xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
 }
 
+// split-f16 operand range (split_f16.hpp): an out-of-range operand is +-inf / NaN and so is every accumulator it feeds
+__device__ __forceinline__ void range_check(const f32x16& acc, unsigned int* __restrict__ flag) {
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bad |= !(fabsf(acc[r]) <= 3.402823466e+38f);   // false for NaN and +-inf
+    if (bad) atomicOr(flag, 1u);
+}
+
 // One 32x32 accumulator tile -> memory.  All 16 residual / row-bias operands are requested (at
 // clamped, always valid addresses) before the first one is consumed, so the epilogue pays one memory
 // round trip per tile instead of one per element; out-of-range elements are computed and not stored.

@@ -198,6 +198,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_split_kernel(GemmArgs g, int
         acc10 += cor10 * SPLIT_LO_INV;
         acc11 += cor11 * SPLIT_LO_INV;
     }
+    if (g.range_flag) {
+        range_check(acc00, g.range_flag);
+        range_check(acc01, g.range_flag);
+        if constexpr (TM == 2) { range_check(acc10, g.range_flag); range_check(acc11, g.range_flag); }
+    }
     // 16-byte stores through a wave-private LDS patch when the output rows allow it (gemm_common.hpp)
     const bool wide = (ldc % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     if (wide) {

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
 #define CSS_E1(t, ...)                                                                                      \
     if constexpr (t < TM) {                                                                                 \
         acc##t += cor##t * SPLIT_LO_INV;                                                                    \
+        if (g.range_flag) range_check(acc##t, g.range_flag);                                                \
         if (fragq) emit_tile_frag(acc##t, pre##t.bn, mtile + 32 * t, h, c, M, g.frag_out, g.frag_T, g.frag_invT, g.frag_heads, \
                                   (ntile % g.frag_D) >> 6, ntile / g.frag_D, (ntile >> 5) & 1, patch);          \
         else if (wide) emit_tile_pre_wide(acc##t, pre##t, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, res != nullptr, alpha, so, \

@@ -44,6 +44,9 @@ struct GemmArgs {
     float frag_invT;
     int tile_rows;         // weights-direct kernel: 0 = choose, else 64 / 96 / 128 (8 waves) / 4 (128 rows, 4 waves)
     int narrow_epilogue;   // tools: keep the 4-byte-per-lane epilogue of the weights-direct kernel (A/B timing)
+    // split kernels: *range_flag |= 1 when a finished accumulator is not finite -- an operand left the split-f16 range
+    // (split_f16.hpp: nothing is clamped); checked here, in the consumer, because a ReLU downstream would launder a NaN
+    unsigned int* range_flag;
     int layout;            // LDS-staged kernels (gemm.hip, gemm_split.hip): 0 = choose, else 8 / 4 (128-row tiles, 8 / 4 waves) / 64
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
@@ -105,8 +108,6 @@ void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int6
 void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s);
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
                                    int64_t i_hi, unsigned int* peak, hipStream_t s);
-// *flag |= 1 if any of a[0..n) is not finite (the split-f16 operand range check, DESIGN.md "Numerical hazards" 6)
-void launch_nonfinite_flag(const float* a, int64_t n, unsigned int* flag, hipStream_t s);
 void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
                          hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows

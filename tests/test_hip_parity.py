@@ -154,7 +154,7 @@ def test_stage_by_stage_vs_oracle(L, CSS, sep_mc, mc_state, mix_stage, golden):
     w = bfw[0, :, :, 0::2] + 1j * bfw[0, :, :, 1::2]
     assert rel_rms(w, taps["mvdr0"]["w"]) < 1e-4
     print(f"W vs the reference's complex64 solve: {rel_rms(w, g['w_seg0']):.2e}")
-    assert rel_rms(w, g["w_seg0"]) < 1e-3          # the reference's complex64 solve, on its own masks
+    assert rel_rms(w, g["w_seg0"]) < 1.2e-4        # the reference's complex64 solve, on its own masks (measured 5.9e-5)
     sep_ = h.read(L.BUF_SEP).reshape(nseg, S, F, T, 2)
     costs = h.read(L.BUF_PIT_COST)
     assert np.abs(costs[0].reshape(S, S) - oside["pit_costs"][0]).max() < 1e-9
