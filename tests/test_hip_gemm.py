@@ -132,12 +132,13 @@ def test_recording_level_does_not_reach_the_operand_range(mc_state, mix60):
 
 
 def test_out_of_range_pass_is_repeated_in_float32(mc_state, mix60):
-    """A model whose input scale drives the features past 65504: the split-f16 operands of the first Linear layer
-    overflow (to inf, not to a clamp), the pass is detected and repeated on the exact float32 kernels -- the result is
-    the exact mode's, bit for bit; with the fallback off the same call fails with CSS_ERR_RANGE."""
+    """A model whose first feed-forward layer drives its ReLU outputs past 65504 (weights themselves in range): the
+    split-f16 operand of the next Linear layer overflows -- to inf, not to a clamp --, that GEMM raises the range flag,
+    and the pass is repeated on the exact float32 kernels: the result is the exact mode's, bit for bit; with the
+    fallback off the same call fails with CSS_ERR_RANGE."""
     L, CSS = pkg("_lib"), pkg("css")
     st = dict(mc_state[0])
-    key = pkg("weights").PREFIX + "input_scale"
+    key = pkg("weights").PREFIX + "conformer.encoders.0.feed_forward_in.net.0.weight"
     st[key] = np.asarray(st[key], np.float32) * np.float32(3e5)
     sep = pkg("separator").HipSeparator(st, None, device=0)
     try:

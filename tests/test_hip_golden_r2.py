@@ -198,10 +198,13 @@ def test_css_inference_against_the_captured_triple(tmp_path, mc_state, mix60):
         else:
             # every 64th sample, before PCM16 -- of the part the first two segments cover alone; the ragged third segment
             # (the last 2 s) has an ill-conditioned noise covariance, the reference's own complex64 solve is noise there
+            # -- and up to one common gain: write_wav divides by the stream's peak, which may sit in that tail
             ref = dec[name.replace("/", "__")].astype(np.float64)[:650]
             got = (pcm[::64].astype(np.float64) / 32767.0)[:650]
-            assert np.abs(got - ref).max() <= 1.6 / 32767.0                     # within a PCM16 step (+ the peak's own move)
-            assert rel_rms(got, ref) < 5e-4                                     # (quantisation: 1 / 32767 / sqrt(12) / rms 0.18)
+            gain = float(got @ ref / (ref @ ref))
+            assert abs(gain - 1) < 0.02, gain
+            assert np.abs(got - gain * ref).max() <= 1.1 / 32767.0              # within a PCM16 step
+            assert rel_rms(got, gain * ref) < 2e-4                              # (quantisation: 1 / 32767 / sqrt(12) / rms 0.18 = 5e-5)
     res2 = CSS.css_inference(str(out_dir), str(tmp_path / "models"), session, cfg, fetch_from_cache=True)
     assert [rel(p) for p in res2["sep_wav_file_names"]] == t["cached_sep_wav_file_names"]
     res3 = CSS.css_inference(str(out_dir), "unused", session, CSS.CssCfg(pass_through_ch0=True), fetch_from_cache=False)
