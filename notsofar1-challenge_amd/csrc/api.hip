@@ -107,6 +107,10 @@ struct css_ctx {
     int64_t range_fallbacks = 0;     // passes repeated so far
     int range_last = 0;              // the last pass hit the range limit
     hipStream_t copy_stream = nullptr;
+    // css_run*: what follows the mask estimator (covariances and beamformer per segment on the lanes, then -- in segment
+    // order, on this stream -- stitching costs, the permutation scan, overlap-add, gate, synthesis) trails the lanes unit
+    // by unit instead of waiting for the last segment of the recording
+    hipStream_t tail_stream = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
     size_t ev_pool_used = 0;
 
@@ -436,8 +440,9 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         if (hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
             return bail(CSS_ERR_HIP, "lane stream / event could not be created");
-    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(CSS_ERR_HIP, "copy stream could not be created");
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(CSS_ERR_HIP, "copy / tail stream could not be created");
     if (hipMalloc(&h->level.p, 64) != hipSuccess || hipMemset(h->level.p, 0, 64) != hipSuccess ||
         hipMalloc((void**)&h->range_flag_dev, 64) != hipSuccess ||
         hipHostMalloc((void**)&h->range_flag_host, 64, hipHostMallocDefault) != hipSuccess)
@@ -501,6 +506,7 @@ int css_destroy(css_handle_t h) {
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); hipStreamDestroy(h->tail_stream); }
     if (h->range_flag_dev) hipFree(h->range_flag_dev);
     if (h->range_flag_host) hipHostFree(h->range_flag_host);
     for (auto& e : h->ev_pool) hipEventDestroy(e);
@@ -539,6 +545,8 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
     if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256] (at most 4 s segments)");
+    if (cfg->stitching_loss < 0 || cfg->stitching_loss > 1 || cfg->stitching_input < 0 || cfg->stitching_input > 1)
+        return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     if (hop <= 0 || 4 * hop < T || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/4 <= hop < T (at most four segments overlap; at least one frame of overlap for the stitching cost)");
     HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};
@@ -616,6 +624,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     const int rc = begin_impl(h, n_samples, n_ch, cfg);
     if (rc != CSS_OK) return rc;
     h->pcm_src = pcm;
+    launch_pcm_peak_f32(pcm, n_samples * n_ch, h->peak_dev, h->stream);
     hipEventRecord(h->ev[1], h->stream);
     return CSS_OK;
 }
@@ -629,6 +638,7 @@ int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     if ((rc = ensure(h, h->pcm_in, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
     if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->stream)) != CSS_OK) return rc;
     h->pcm_src = (const float*)h->pcm_in.p;
+    launch_pcm_peak_f32(h->pcm_src + s_lo * n_ch, (s_hi - s_lo) * n_ch, h->peak_dev, h->stream);
     hipEventRecord(h->ev[1], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -647,8 +657,8 @@ static void stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* p
     const int64_t i_lo = t_lo * hop, i_hi = std::min<int64_t>((f_hi - 1) * hop + N, h->n_pad);
     {
         CSS_PROF(CSS_PROF_DEINTERLEAVE, st);
-        if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, h->peak_dev, st);
-        else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, h->peak_dev, st);
+        if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, st);
+        else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
     }
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
@@ -809,7 +819,8 @@ static int64_t batch_len(int64_t n, int64_t cap) {
 // (see css_ctx::lanes).  prep(first segment, count, stream), when given, is enqueued at the head of each lane's chain:
 // the fused path puts the analysis transform of the frames that lane is the first to read there (run_impl).
 using LanePrep = std::function<int(int64_t, int, hipStream_t)>;
-static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const LanePrep& prep) {
+using LanePost = LanePrep;   // post(first segment, count, stream): enqueued at the END of each lane's chain
+static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const LanePrep& prep, const LanePost& post) {
     const int L = h->d.num_blocks;
     const int sp = h->split ? 1 : 0;
     int rc;
@@ -822,7 +833,8 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
     const LaneSplit ls = lane_split(h, nb);
     if (ls.nl == 1) {
         if ((rc = prep(s0, nb, h->stream)) != CSS_OK) return rc;
-        return masknet_lane(h, io, s0, nb, 0, -1, L + 1);
+        if ((rc = masknet_lane(h, io, s0, nb, 0, -1, L + 1)) != CSS_OK) return rc;
+        return post(s0, nb, h->stream);
     }
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));    // everything the estimator reads is ordered before this
     for (int l = 1; l < ls.nl; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_fork, 0));
@@ -836,6 +848,10 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
             const int lo = l * ls.per, n = std::min(ls.per, nb - lo);
             if (n > 0 && (rc = masknet_lane(h, io, s0 + lo, n, l, ph, ph + 1, true)) != CSS_OK) return rc;
         }
+    for (int l = 0; l < ls.nl; ++l) {
+        const int lo = l * ls.per, n = std::min(ls.per, nb - lo);
+        if (n > 0 && (rc = post(s0 + lo, n, l ? h->lane_stream[l] : h->stream)) != CSS_OK) return rc;
+    }
     for (int l = 1; l < ls.nl; ++l) {
         HIPCHK(h, hipEventRecord(h->ev_join[l], h->lane_stream[l]));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[l], 0));
@@ -843,7 +859,8 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
     return CSS_OK;
 }
 static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb) {
-    return masknet_batch(h, io, s0, nb, LanePrep([](int64_t, int, hipStream_t) { return (int)CSS_OK; }));
+    const LanePrep none = [](int64_t, int, hipStream_t) { return (int)CSS_OK; };
+    return masknet_batch(h, io, s0, nb, none, none);
 }
 
 int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
@@ -865,46 +882,58 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     return CSS_OK;
 }
 
+// make_mvdr + mask floor / multiply (+ power normalisation) for segments [lo, hi) on `st`
+static void mvdr_on(css_ctx* h, int64_t seg_lo, int64_t seg_hi, hipStream_t st) {
+    if (seg_hi <= seg_lo) return;
+    MvdrArgs a = mvdr_args(h, seg_lo, (int)(seg_hi - seg_lo));
+    if (a.use_mvdr) {
+        { CSS_PROF(CSS_PROF_SCM, st); launch_scm(a, st); }
+        { CSS_PROF(CSS_PROF_MVDR_SOLVE, st); launch_mvdr_solve(a, st); }
+    }
+    CSS_PROF(CSS_PROF_BEAMFORM, st);
+    launch_beamform(a, st);
+    if (h->cfg.normalize_segment_power) launch_segment_power_norm(a, (double*)h->pnorm.p, st);
+}
+
 int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     int rc = check_session(h);
     if (rc) return rc;
     if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
-    if (seg_hi > seg_lo) {
-        MvdrArgs a = mvdr_args(h, seg_lo, (int)(seg_hi - seg_lo));
-        if (a.use_mvdr) {
-            { CSS_PROF(CSS_PROF_SCM, h->stream); launch_scm(a, h->stream); }
-            { CSS_PROF(CSS_PROF_MVDR_SOLVE, h->stream); launch_mvdr_solve(a, h->stream); }
-        }
-        CSS_PROF(CSS_PROF_BEAMFORM, h->stream);
-        launch_beamform(a, h->stream);
-        if (h->cfg.normalize_segment_power) launch_segment_power_norm(a, (double*)h->pnorm.p, h->stream);
-    }
+    mvdr_on(h, seg_lo, seg_hi, h->stream);
     hipEventRecord(h->ev[4], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
+}
+
+static void pit_costs_on(css_ctx* h, int64_t b_lo, int64_t b_hi, hipStream_t st) {
+    if (b_hi <= b_lo) return;
+    CSS_PROF(CSS_PROF_PIT, st);
+    launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->pit_part.p,
+                     (double*)h->costs.p, st);
 }
 
 int css_stage_pit_costs(css_handle_t h, int64_t b_lo, int64_t b_hi) {
     int rc = check_session(h);
     if (rc) return rc;
     if (b_lo < 0 || b_hi > h->plan.num_segments - 1 || b_lo > b_hi) return fail(h, CSS_ERR_INVALID_ARG, "boundary range out of bounds");
-    if (h->cfg.stitching_loss < 0 || h->cfg.stitching_loss > 1 || h->cfg.stitching_input < 0 || h->cfg.stitching_input > 1)
-        return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     HIPCHK(h, hipSetDevice(h->device));
-    CSS_PROF(CSS_PROF_PIT, h->stream);
-    launch_pit_costs(stitch_args(h), h->cfg.stitching_loss, h->cfg.stitching_input, b_lo, b_hi, (double*)h->pit_part.p,
-                     (double*)h->costs.p, h->stream);
+    pit_costs_on(h, b_lo, b_hi, h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
+}
+
+// permutations of segments b_lo + 1 .. b_hi (b_lo == 0: also the identity of segment 0)
+static void pit_scan_on(css_ctx* h, int64_t b_lo, int64_t b_hi, hipStream_t st) {
+    CSS_PROF(CSS_PROF_PIT, st);
+    launch_pit_scan((const double*)h->costs.p, b_lo, b_hi, h->d.num_spks, (int32_t*)h->perms.p, st);
 }
 
 int css_stage_pit_scan(css_handle_t h) {
     int rc = check_session(h);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
-    CSS_PROF(CSS_PROF_PIT, h->stream);
-    launch_pit_scan((const double*)h->costs.p, h->plan.num_segments - 1, h->d.num_spks, (int32_t*)h->perms.p, h->stream);
+    pit_scan_on(h, 0, h->plan.num_segments - 1, h->stream);
     HIPCHK(h, hipGetLastError());
     h->perms_done = true;
     return CSS_OK;
@@ -953,7 +982,7 @@ int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
 
 // synthesis GEMM over frames [f_lo, f_hi), then overlap-add of output blocks [q_lo, q_hi) using only those frames
 static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
-                      int64_t out_q0) {
+                      int64_t out_q0, hipStream_t st) {
     const int S = h->d.num_spks, N = h->d.frame_len;
     const int64_t TL = h->plan.mix_frames;
     if (f_hi > f_lo) {
@@ -965,10 +994,10 @@ static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int6
         g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
         g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
         g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
-        { CSS_PROF(CSS_PROF_ISTFT_GEMM, h->stream); launch_gemm(g, h->stream); }
-        { CSS_PROF(CSS_PROF_WAVE_OLA, h->stream); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->split ? h->peak_dev : nullptr, h->stream); }
+        { CSS_PROF(CSS_PROF_ISTFT_GEMM, st); launch_gemm(g, st); }
+        { CSS_PROF(CSS_PROF_WAVE_OLA, st); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->split ? h->peak_dev : nullptr, st); }
     }
-    hipEventRecord(h->ev[6], h->stream);
+    hipEventRecord(h->ev[6], st);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
@@ -978,14 +1007,14 @@ int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     if (rc) return rc;
     const int64_t TL = h->plan.mix_frames;
     const int64_t q_hi = (t_hi == TL) ? TL + 1 : t_hi;  // the last range also writes the tail half-frame
-    return istft_impl(h, std::max<int64_t>(t_lo - 1, 0), t_hi, t_lo, q_hi, (float*)h->wav.p, h->plan.n_out, 0);
+    return istft_impl(h, std::max<int64_t>(t_lo - 1, 0), t_hi, t_lo, q_hi, (float*)h->wav.p, h->plan.n_out, 0, h->stream);
 }
 
 int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld) {
     int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
     if (!shard_dev || shard_ld < (t_hi - t_lo + 1) * h->d.frame_hop) return fail(h, CSS_ERR_INVALID_ARG, "shard buffer too small");
-    return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo);
+    return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo, h->stream);
 }
 
 int css_sync(css_handle_t h) {
@@ -1018,11 +1047,14 @@ static hipEvent_t pool_event(css_ctx* h) {
 }
 
 // One pass of css/css.py:110 separate_and_stitch as a pipeline.  The recording's segments go through the mask estimator
-// in batches, each cut into lanes (css_ctx::lanes); a (batch, lane) UNIT owns the frames no earlier unit reads.  Its
-// samples cross PCIe on the copy stream as one piece; the lane's chain waits for that piece only, transforms the unit's
-// frames, and starts the estimator on its segments while the later pieces are still in flight.  Stitching needs every
-// segment (the permutation scan is sequential, css.py:266-285); after it the gate, the inverse transform and the
-// download run over frame ranges, a finished range leaving while the next one is synthesised.
+// in batches, each cut into lanes (css_ctx::lanes); a (batch, lane) UNIT owns the frames no earlier unit reads.
+//   in    its samples cross PCIe on the copy stream as one piece; the lane's chain waits for that piece only, transforms
+//         the unit's frames, and starts the estimator on its segments while the later pieces are still in flight;
+//   lane  features -> Conformer -> masks, then covariances, MVDR solve and beamformer of the same segments;
+//   tail  in unit order on the tail stream: stitching costs of the unit's boundaries, the permutation scan CONTINUED over
+//         them (css.py:266-285 is sequential, but only forwards), overlap-add of the frames no later segment covers,
+//         gate and synthesis of those frames less the dilate / erode halo, and their samples back over PCIe --
+//         while the lanes work on the next units.  Only the last unit's tail is not hidden.
 static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
     if (!h) return CSS_ERR_INVALID_ARG;
@@ -1044,12 +1076,13 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     } else {
         h->pcm_src = io.pcm_dev;
     }
+    if (io.wav16_host && (rc = ensure(h, h->enc, (size_t)S * pl.n_out * sizeof(int16_t) + 64)) != CSS_OK) return rc;
     const int16_t* planes_dev = io.planes_host ? (const int16_t*)h->in16.p : nullptr;
     hipEventRecord(h->ev[1], h->stream);
     hipEventRecord(h->ev[2], h->stream);   // the analysis transform is part of the lanes' chains (CssTimings.stft = 0)
 
     // ---- units, their frames and samples
-    struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x; int lane; };
+    struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x, m; };
     std::vector<Unit> units;
     const int64_t cap = batch_len(nseg, std::min<int64_t>(h->max_batch, nseg));
     int64_t f_prev = 0, s_prev = 0;
@@ -1060,7 +1093,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             const int lo = l * ls.per, cnt = std::min(ls.per, nb - lo);
             if (cnt <= 0) continue;
             Unit u{};
-            u.seg_lo = s0 + lo; u.n = cnt; u.lane = l;
+            u.seg_lo = s0 + lo; u.n = cnt;
             const bool last = u.seg_lo + cnt == nseg;
             u.f_lo = f_prev;
             u.f_hi = last ? TL : std::min<int64_t>((u.seg_lo + cnt - 1) * hop + T, TL);
@@ -1070,14 +1103,17 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             f_prev = u.f_hi; s_prev = u.s_hi;
             u.up = from_host ? pool_event(h) : nullptr;
             u.x = pool_event(h);
+            u.m = pool_event(h);
             units.push_back(u);
         }
     }
-    // ---- PCIe pieces, in unit order, on the copy stream (after whatever the previous pass still reads there)
+    // ---- everything starts after whatever the previous pass left on the three streams
+    hipEvent_t start = pool_event(h);
+    HIPCHK(h, hipEventRecord(start, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, start, 0));
+    HIPCHK(h, hipStreamWaitEvent(h->tail_stream, start, 0));
+    // ---- PCIe pieces, in unit order, on the copy stream
     if (from_host) {
-        hipEvent_t start = pool_event(h);
-        HIPCHK(h, hipEventRecord(start, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, start, 0));
         for (const Unit& u : units) {
             if (io.pcm_host) {
                 if ((rc = upload_pcm(h, io.pcm_host, u.s_lo, u.s_hi, h->copy_stream)) != CSS_OK) return rc;
@@ -1088,10 +1124,56 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             }
             HIPCHK(h, hipEventRecord(u.up, h->copy_stream));
         }
+        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, units.back().up, 0));
     }
+    // the recording's level (power-of-two gain of the split synthesis operand), once every sample is on the device
+    if (planes_dev) launch_pcm_peak_i16(planes_dev, n * n_ch, h->peak_dev, h->tail_stream);
+    else launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->tail_stream);
     if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
-    // ---- the estimator, unit by unit
+
+    // ---- the tail of unit `k` (all earlier tails are already enqueued on the tail stream)
+    const int64_t halo = h->cfg.dilation_frames + h->cfg.erosion_frames;
+    const StitchArgs sa = stitch_args(h);
+    int64_t t_done = 0, g_done = 0;     // frames overlap-added / gated and synthesised so far
+    hipEvent_t out_done = nullptr;
+    auto tail_of = [&](size_t k) -> int {
+        const Unit& u = units[k];
+        hipStream_t ts = h->tail_stream;
+        const bool last = k + 1 == units.size();
+        HIPCHK(h, hipStreamWaitEvent(ts, u.m, 0));
+        const int64_t b_lo = std::max<int64_t>(u.seg_lo - 1, 0), b_hi = u.seg_lo + u.n - 1;
+        pit_costs_on(h, b_lo, b_hi, ts);
+        pit_scan_on(h, b_lo, b_hi, ts);
+        const int64_t t_hi = last ? TL : std::min<int64_t>((u.seg_lo + u.n) * hop, TL);   // no later segment covers these
+        if (t_hi > t_done) { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, t_done, t_hi, ts); }
+        t_done = std::max(t_done, t_hi);
+        const int64_t g_hi = last ? TL : std::max<int64_t>(t_done - halo, g_done);
+        if (g_hi > g_done || last) {
+            { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, g_done, g_hi, ts); }
+            { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, g_done, g_hi, ts); }
+            if (last) hipEventRecord(h->ev[5], ts);
+            const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
+            if ((rc = istft_impl(h, std::max<int64_t>(g_done - 1, 0), g_hi, g_done, q_hi, (float*)h->wav.p, pl.n_out, 0, ts)) != CSS_OK) return rc;
+            if (io.wav_host) {
+                const int64_t a = g_done * fhop, b = (g_hi == TL) ? pl.n_out : g_hi * fhop;
+                hipEvent_t done = pool_event(h);
+                HIPCHK(h, hipEventRecord(done, ts));
+                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
+                for (int sp = 0; sp < S; ++sp)
+                    HIPCHK(h, hipMemcpyAsync(io.wav_host + (size_t)sp * io.cap + a, (const float*)h->wav.p + (size_t)sp * pl.n_out + a,
+                                             (size_t)(b - a) * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+                if (last) {
+                    out_done = pool_event(h);
+                    HIPCHK(h, hipEventRecord(out_done, h->copy_stream));
+                }
+            }
+            g_done = g_hi;
+        }
+        return CSS_OK;
+    };
+
+    // ---- the estimator, unit by unit; each lane appends the beamformer of its own segments
     MaskIo mio{(const float*)h->X.p, h->T_ld, pl.stft_frames, hop, T, (float*)h->masks.p, nseg * T};
     size_t ui = 0;
     const LanePrep prep = [&](int64_t seg_lo, int cnt, hipStream_t st) -> int {
@@ -1107,42 +1189,31 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         ++ui;
         return CSS_OK;
     };
-    for (int64_t s0 = 0; s0 < nseg; s0 += cap)
-        if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep)) != CSS_OK) return rc;
-    h->stft_done = true;
-    hipEventRecord(h->ev[3], h->stream);
-    // ---- everything that needs all segments
-    if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
-    if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
-    if ((rc = css_stage_pit_scan(h)) != CSS_OK) return rc;
-    if ((rc = css_stage_stitch_masks(h, 0, TL)) != CSS_OK) return rc;
-    const StitchArgs sa = stitch_args(h);
-    { CSS_PROF(CSS_PROF_GATE, h->stream); launch_morphology(sa, 0, TL, h->stream); }
-    // ---- gate, inverse transform and download by frame range
-    const int nchunk = (io.wav_host && TL >= 256) ? 4 : 1;
-    hipEvent_t tail = nullptr;
-    for (int c = 0; c < nchunk; ++c) {
-        const int64_t t_lo = TL * c / nchunk, t_hi = TL * (c + 1) / nchunk;
-        { CSS_PROF(CSS_PROF_OLA_STFT, h->stream); launch_ola_stft(sa, t_lo, t_hi, h->stream); }
-        if (c == nchunk - 1) hipEventRecord(h->ev[5], h->stream);
-        if ((rc = css_stage_istft(h, t_lo, t_hi)) != CSS_OK) return rc;   // reads frame t_lo - 1 of the previous range
-        if (io.wav_host) {
-            const int64_t a = t_lo * fhop, b = (t_hi == TL) ? pl.n_out : t_hi * fhop;
-            hipEvent_t done = pool_event(h);
-            HIPCHK(h, hipEventRecord(done, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
-            HIPCHK(h, hipMemcpy2DAsync(io.wav_host + a, (size_t)io.cap * sizeof(float), (const float*)h->wav.p + a,
-                                       (size_t)pl.n_out * sizeof(float), (size_t)(b - a) * sizeof(float), S,
-                                       hipMemcpyDeviceToHost, h->copy_stream));
-            if (c == nchunk - 1) {
-                tail = pool_event(h);
-                HIPCHK(h, hipEventRecord(tail, h->copy_stream));
-            }
-        }
+    size_t first = 0;
+    const LanePost post = [&](int64_t seg_lo, int cnt, hipStream_t st) -> int {
+        Unit* u = nullptr;
+        for (size_t k = first; k < ui; ++k)
+            if (units[k].seg_lo == seg_lo && units[k].n == cnt) u = &units[k];
+        if (!u) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
+        mvdr_on(h, seg_lo, seg_lo + cnt, st);
+        HIPCHK(h, hipEventRecord(u->m, st));
+        return CSS_OK;
+    };
+    for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
+        first = ui;
+        if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post)) != CSS_OK) return rc;
+        for (size_t k = first; k < ui; ++k)
+            if ((rc = tail_of(k)) != CSS_OK) return rc;
     }
+    h->stft_done = h->perms_done = true;
+    hipEventRecord(h->ev[3], h->stream);
+    hipEventRecord(h->ev[4], h->stream);
+    // ---- join: the main stream continues after the tail (and the last download)
+    hipEvent_t tail_done = pool_event(h);
+    HIPCHK(h, hipEventRecord(tail_done, h->tail_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, tail_done, 0));
     if (io.wav16_host) {
         const int64_t n_out = pl.n_out;
-        if ((rc = ensure(h, h->enc, (size_t)S * n_out * sizeof(int16_t) + 64)) != CSS_OK) return rc;
         unsigned int* pk = (unsigned int*)h->enc.p;
         int16_t* o16 = (int16_t*)((char*)h->enc.p + 64);
         { CSS_PROF(CSS_PROF_ENCODE, h->stream); launch_encode_pcm16((const float*)h->wav.p, S, n_out, pk, o16, n_out, h->stream); }
@@ -1153,15 +1224,16 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         HIPCHK(h, hipMemcpy2DAsync(io.wav_dev, (size_t)io.cap * sizeof(float), h->wav.p, (size_t)pl.n_out * sizeof(float),
                                    (size_t)pl.n_out * sizeof(float), S, hipMemcpyDeviceToDevice, h->stream));
     }
-    if (tail) HIPCHK(h, hipStreamWaitEvent(h->stream, tail, 0));
-    hipEventRecord(h->ev[7], h->stream);
     // range check (split_f16.hpp): a split GEMM whose operand left the format's range raised this word
     HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    if (out_done) HIPCHK(h, hipStreamWaitEvent(h->stream, out_done, 0));
+    hipEventRecord(h->ev[7], h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
     CssTimings& t = h->tim;
-    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = ms(3, 4); t.stitch = ms(4, 5);
+    // (the stages overlap: masknet = begin of the first chain .. end of the last, stitch / istft = the LAST unit's tail)
+    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = 0.f; t.stitch = ms(4, 5);
     t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
     t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
     for (int c = 0; c < CSS_PROF_COUNT; ++c) { h->prof_ms[c] = 0.f; h->prof_launches[c] = 0; }
@@ -1378,7 +1450,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
-    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, nullptr, h->stream);
+    launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, h->stream);
     GemmArgs g{};
     g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
     g.B = cm; g.ldb = hop; g.strideB = n_pad;
@@ -1440,7 +1512,7 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
     for (int b = 0; b < batch; ++b) {
         // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
-        launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, nullptr, h->stream);
+        launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
         GemmArgs g{};
         g.A = h->dft_fwd; g.lda = N; g.strideA = 0;
         g.B = cm + (size_t)b * C * n_pad; g.ldb = hop; g.strideB = n_pad;

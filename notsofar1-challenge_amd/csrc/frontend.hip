@@ -32,32 +32,23 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // ------------------------------------------------------------------------------------------------
 // split_out: each channel row is written as a split-f16 GEMM operand (split_f16.hpp; n_pad % 32 == 0).  The
 // overlapping frames the analysis GEMM reads (row stride = hop, a multiple of 32) are valid split rows of it.
-__device__ __forceinline__ void peak_update(unsigned int* peak, float m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (peak && (threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak, __float_as_uint(m));   // non-negative floats order like uints
-}
-
 __global__ void deinterleave_kernel(const float* __restrict__ pcm, float* __restrict__ out, int64_t n, int C,
-                                    int64_t n_pad, int64_t i_lo, int64_t i_hi, int split_out, unsigned int* peak) {
+                                    int64_t n_pad, int64_t i_lo, int64_t i_hi, int split_out) {
     const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float m = 0.f;
-    if (i < i_hi)
-        for (int c = 0; c < C; ++c) {
-            const float v = i < n ? pcm[i * C + c] : 0.f;
-            m = fmaxf(m, fabsf(v));
-            if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)c * n_pad + (i & ~(int64_t)31)), (int)(i & 31), v);
-            else out[(int64_t)c * n_pad + i] = v;
-        }
-    peak_update(peak, m);
+    if (i >= i_hi) return;
+    for (int c = 0; c < C; ++c) {
+        const float v = i < n ? pcm[i * C + c] : 0.f;
+        if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)c * n_pad + (i & ~(int64_t)31)), (int)(i & 31), v);
+        else out[(int64_t)c * n_pad + i] = v;
+    }
 }
 
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         int split_out, unsigned int* peak, hipStream_t s) {
+                         int split_out, hipStream_t s) {
     if (i_hi <= i_lo) return;
     const int64_t blocks = (i_hi - i_lo + 255) / 256;
     hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, pcm_cm, n, C, n_pad, i_lo, i_hi,
-                       split_out, peak);
+                       split_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -81,22 +72,38 @@ void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, 
 // the same scaling straight into the channel-major frame buffer [C][n_pad] (zeros past n), samples [i_lo, i_hi): planes
 // are already channel-major, so the wav edge needs no sample-major detour
 __global__ void pcm16_to_cm_kernel(const int16_t* __restrict__ planes, float* __restrict__ out, int64_t n, int64_t n_pad,
-                                   int64_t i_lo, int64_t i_hi, unsigned int* peak) {
+                                   int64_t i_lo, int64_t i_hi) {
     const int64_t i = i_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float v = 0.f;
-    if (i < i_hi) {
-        const int c = blockIdx.y;
-        v = i < n ? (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f) : 0.f;
-        out[(int64_t)c * n_pad + i] = v;
-    }
-    peak_update(peak, fabsf(v));
+    if (i >= i_hi) return;
+    const int c = blockIdx.y;
+    out[(int64_t)c * n_pad + i] = i < n ? (float)planes[(int64_t)c * n + i] * (1.0f / 32768.0f) : 0.f;
+}
+
+// max |sample| over count values as float bits (non-negative floats order like unsigned integers), OR-ed into *peak by
+// atomicMax: the recording's level for the power-of-two gain of the split synthesis operand (split_f16.hpp level_gain)
+template <class T>
+__global__ __launch_bounds__(256) void pcm_peak_kernel(const T* __restrict__ x, int64_t count, float scale, unsigned int* __restrict__ peak) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf((float)x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak, __float_as_uint(m * scale));
+}
+
+void launch_pcm_peak_f32(const float* x, int64_t count, unsigned int* peak, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(pcm_peak_kernel<float>, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, s, x, count, 1.0f, peak);
+}
+void launch_pcm_peak_i16(const int16_t* x, int64_t count, unsigned int* peak, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, s, x, count, 1.0f / 32768.0f, peak);
 }
 
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
-                                   int64_t i_hi, unsigned int* peak, hipStream_t s) {
+                                   int64_t i_hi, hipStream_t s) {
     if (i_hi <= i_lo) return;
     hipLaunchKernelGGL(pcm16_to_cm_kernel, dim3((unsigned)((i_hi - i_lo + 255) / 256), C), dim3(256), 0, s, planes, pcm_cm, n,
-                       n_pad, i_lo, i_hi, peak);
+                       n_pad, i_lo, i_hi);
 }
 
 // peak[s] = max |wav[s][:]| (as float bits: non-negative floats order like unsigned integers; peak zeroed by the caller)

@@ -100,14 +100,16 @@ void launch_relpos_attention(const float* qkv, const float* qk_frag, const float
 // ------------------------------------------------------------------------------------------------
 // samples [i_lo, i_hi) of every channel: pcm [n][C] -> pcm_cm [C][n_pad] (zeros past n)
 // (split_out: channel rows as split-f16 GEMM operands, n_pad % 32 == 0)
-// peak (may be null): max |sample| of what was laid out, as float bits (atomicMax; split_f16.hpp level_gain)
 void launch_deinterleave(const float* pcm, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo, int64_t i_hi,
-                         int split_out, unsigned int* peak, hipStream_t s);
+                         int split_out, hipStream_t s);
+// *peak = max(*peak, max |x|) as float bits (int16 samples scaled by 2^-15): the recording's level (split_f16.hpp level_gain)
+void launch_pcm_peak_f32(const float* x, int64_t count, unsigned int* peak, hipStream_t s);
+void launch_pcm_peak_i16(const int16_t* x, int64_t count, unsigned int* peak, hipStream_t s);
 // wav edges on the device: C mono PCM16 planes [C][n] -> sample-major float32 [n][C]; and peak-normalised PCM16
 // encoding of the S output streams (peak_bits: S words of scratch, holds max|x| as float bits afterwards)
 void launch_pcm16_to_float(const int16_t* planes, float* pcm, int64_t n, int C, hipStream_t s);
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
-                                   int64_t i_hi, unsigned int* peak, hipStream_t s);
+                                   int64_t i_hi, hipStream_t s);
 void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_bits, int16_t* out, int64_t out_ld,
                          hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
@@ -166,7 +168,9 @@ struct StitchArgs {
 size_t pit_cost_scratch_bytes(int64_t n_boundaries);
 void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* scratch, double* costs,
                       hipStream_t s);
-void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s);
+// permutations of segments b_lo + 1 .. b_hi from the raw costs of boundaries [b_lo, b_hi), continuing from the
+// permutation of segment b_lo already in perms (b_lo == 0: the identity, written here)
+void launch_pit_scan(const double* costs, int64_t b_lo, int64_t b_hi, int S, int32_t* perms, hipStream_t s);
 void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms);
 void launch_ola_masks(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s);
 void launch_morphology(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s);

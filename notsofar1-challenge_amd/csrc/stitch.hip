@@ -164,17 +164,29 @@ __device__ __forceinline__ void perm_from_index(int idx, int S, int* p) {
     }
 }
 
-__global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict__ costs, int64_t n_boundaries, int S,
+__global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict__ costs, int64_t b_lo, int64_t n_boundaries, int S,
                                                        int32_t* __restrict__ perms) {
     __shared__ uint8_t next[SCAN_CHUNK * NPMAX];
     __shared__ uint8_t state_of[SCAN_CHUNK];
     __shared__ int carry;
     int np = 1;
     for (int i = 2; i <= S; ++i) np *= i;
-    if (threadIdx.x == 0) carry = 0;  // identity = lexicographic index 0
-    if (threadIdx.x < S) perms[threadIdx.x] = threadIdx.x;
+    if (threadIdx.x == 0) {
+        carry = 0;  // identity = lexicographic index 0
+        if (b_lo > 0) {   // resume: the lexicographic index of the permutation segment b_lo already has
+            int want[SMAX], p[SMAX];
+            for (int a = 0; a < S; ++a) want[a] = perms[b_lo * S + a];
+            for (int k = 0; k < np; ++k) {
+                perm_from_index(k, S, p);
+                bool same = true;
+                for (int a = 0; a < S; ++a) same &= p[a] == want[a];
+                if (same) carry = k;
+            }
+        }
+    }
+    if (b_lo == 0 && threadIdx.x < S) perms[threadIdx.x] = threadIdx.x;
     __syncthreads();
-    for (int64_t b0 = 0; b0 < n_boundaries; b0 += SCAN_CHUNK) {
+    for (int64_t b0 = b_lo; b0 < n_boundaries; b0 += SCAN_CHUNK) {
         const int nb = (int)(n_boundaries - b0 < SCAN_CHUNK ? n_boundaries - b0 : SCAN_CHUNK);
         for (int e = threadIdx.x; e < nb * np; e += blockDim.x) {
             const int b = e / np, pin = e - b * np;
@@ -210,8 +222,8 @@ __global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict_
     }
 }
 
-void launch_pit_scan(const double* costs, int64_t n_boundaries, int S, int32_t* perms, hipStream_t s) {
-    hipLaunchKernelGGL(pit_scan_kernel, dim3(1), dim3(256), 0, s, costs, n_boundaries, S, perms);
+void launch_pit_scan(const double* costs, int64_t b_lo, int64_t b_hi, int S, int32_t* perms, hipStream_t s) {
+    hipLaunchKernelGGL(pit_scan_kernel, dim3(1), dim3(256), 0, s, costs, b_lo, b_hi, S, perms);
 }
 
 void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
