@@ -1051,10 +1051,10 @@ static hipEvent_t pool_event(css_ctx* h) {
 //   in    its samples cross PCIe on the copy stream as one piece; the lane's chain waits for that piece only, transforms
 //         the unit's frames, and starts the estimator on its segments while the later pieces are still in flight;
 //   lane  features -> Conformer -> masks, then covariances, MVDR solve and beamformer of the same segments;
-//   tail  in unit order on the tail stream: stitching costs of the unit's boundaries, the permutation scan CONTINUED over
+//   tail  batch by batch on the tail stream: stitching costs of the batch's boundaries, the permutation scan CONTINUED over
 //         them (css.py:266-285 is sequential, but only forwards), overlap-add of the frames no later segment covers,
 //         gate and synthesis of those frames less the dilate / erode halo, and their samples back over PCIe --
-//         while the lanes work on the next units.  Only the last unit's tail is not hidden.
+//         while the lanes work on the next batch.  Only the last batch's tail is not hidden.
 static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
     if (!h) return CSS_ERR_INVALID_ARG;
@@ -1137,11 +1137,13 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     const StitchArgs sa = stitch_args(h);
     int64_t t_done = 0, g_done = 0;     // frames overlap-added / gated and synthesised so far
     hipEvent_t out_done = nullptr;
-    auto tail_of = [&](size_t k) -> int {
-        const Unit& u = units[k];
+    // (one tail per BATCH, not per unit: these kernels are latency-bound chains of small launches -- a third of the
+    // frames takes the same ~120 us -- and the lanes of a batch finish together, so per-unit tails only queue up)
+    auto tail_of = [&](size_t k0, size_t k1) -> int {   // units [k0, k1)
         hipStream_t ts = h->tail_stream;
-        const bool last = k + 1 == units.size();
-        HIPCHK(h, hipStreamWaitEvent(ts, u.m, 0));
+        const bool last = k1 == units.size();
+        for (size_t k = k0; k < k1; ++k) HIPCHK(h, hipStreamWaitEvent(ts, units[k].m, 0));
+        struct { int64_t seg_lo; int64_t n; } u{units[k0].seg_lo, units[k1 - 1].seg_lo + units[k1 - 1].n - units[k0].seg_lo};
         const int64_t b_lo = std::max<int64_t>(u.seg_lo - 1, 0), b_hi = u.seg_lo + u.n - 1;
         pit_costs_on(h, b_lo, b_hi, ts);
         pit_scan_on(h, b_lo, b_hi, ts);
@@ -1202,8 +1204,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         first = ui;
         if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post)) != CSS_OK) return rc;
-        for (size_t k = first; k < ui; ++k)
-            if ((rc = tail_of(k)) != CSS_OK) return rc;
+        if ((rc = tail_of(first, ui)) != CSS_OK) return rc;
     }
     h->stft_done = h->perms_done = true;
     hipEventRecord(h->ev[3], h->stream);
