@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long", action="store_true", help="N = 1: skip the 30-min meeting")
+    ap.add_argument("--lanes", type=int, default=0, help="kernel chains per mask-estimator batch (0 = the library's default)")
     args = ap.parse_args()
 
     import torch
@@ -253,6 +254,8 @@ def main():
     plan = L.plan(desc, run_cfg, n)
     sep = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=args.max_batch)
     h = sep.handle
+    if args.lanes:
+        h.set_lanes(args.lanes)
     pcm_pin = L.pinned_copy(np.ascontiguousarray(mix[0]))
     out_pin = L.pinned_empty((S, int(plan.n_out)), np.float32)
     torch.cuda.synchronize()

@@ -1082,7 +1082,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     hipEventRecord(h->ev[2], h->stream);   // the analysis transform is part of the lanes' chains (CssTimings.stft = 0)
 
     // ---- units, their frames and samples
-    struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x, m; };
+    struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x, v, m; };   // pieces landed, planes, beamformer, costs
     std::vector<Unit> units;
     const int64_t cap = batch_len(nseg, std::min<int64_t>(h->max_batch, nseg));
     int64_t f_prev = 0, s_prev = 0;
@@ -1103,6 +1103,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             f_prev = u.f_hi; s_prev = u.s_hi;
             u.up = from_host ? pool_event(h) : nullptr;
             u.x = pool_event(h);
+            u.v = pool_event(h);
             u.m = pool_event(h);
             units.push_back(u);
         }
@@ -1145,32 +1146,38 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         for (size_t k = k0; k < k1; ++k) HIPCHK(h, hipStreamWaitEvent(ts, units[k].m, 0));
         struct { int64_t seg_lo; int64_t n; } u{units[k0].seg_lo, units[k1 - 1].seg_lo + units[k1 - 1].n - units[k0].seg_lo};
         const int64_t b_lo = std::max<int64_t>(u.seg_lo - 1, 0), b_hi = u.seg_lo + u.n - 1;
-        pit_costs_on(h, b_lo, b_hi, ts);
+        // (the boundaries' costs were computed on the lanes, behind each unit's beamformer)
         pit_scan_on(h, b_lo, b_hi, ts);
         const int64_t t_hi = last ? TL : std::min<int64_t>((u.seg_lo + u.n) * hop, TL);   // no later segment covers these
         if (t_hi > t_done) { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, t_done, t_hi, ts); }
         t_done = std::max(t_done, t_hi);
-        const int64_t g_hi = last ? TL : std::max<int64_t>(t_done - halo, g_done);
-        if (g_hi > g_done || last) {
-            { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, g_done, g_hi, ts); }
-            { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, g_done, g_hi, ts); }
-            if (last) hipEventRecord(h->ev[5], ts);
-            const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
-            if ((rc = istft_impl(h, std::max<int64_t>(g_done - 1, 0), g_hi, g_done, q_hi, (float*)h->wav.p, pl.n_out, 0, ts)) != CSS_OK) return rc;
-            if (io.wav_host) {
-                const int64_t a = g_done * fhop, b = (g_hi == TL) ? pl.n_out : g_hi * fhop;
-                hipEvent_t done = pool_event(h);
-                HIPCHK(h, hipEventRecord(done, ts));
-                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
-                for (int sp = 0; sp < S; ++sp)
-                    HIPCHK(h, hipMemcpyAsync(io.wav_host + (size_t)sp * io.cap + a, (const float*)h->wav.p + (size_t)sp * pl.n_out + a,
-                                             (size_t)(b - a) * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
-                if (last) {
-                    out_done = pool_event(h);
-                    HIPCHK(h, hipEventRecord(out_done, h->copy_stream));
+        const int64_t g_end = last ? TL : std::max<int64_t>(t_done - halo, g_done);
+        if (g_end > g_done || last) {
+            { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, g_done, g_end, ts); }
+            // the last range leaves in two pieces, so that the first piece's download runs beside the second's synthesis
+            // (more pieces do not pay: these launches are latency-bound, a fifth of the frames costs what all of them cost)
+            const int pieces = (last && io.wav_host && g_end - g_done >= 512) ? 2 : 1;
+            for (int pc = 0; pc < pieces; ++pc) {
+                const int64_t g_hi = pc + 1 == pieces ? g_end : g_done + (g_end - g_done) * 3 / 5;
+                { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, g_done, g_hi, ts); }
+                if (last && pc + 1 == pieces) hipEventRecord(h->ev[5], ts);
+                const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
+                if ((rc = istft_impl(h, std::max<int64_t>(g_done - 1, 0), g_hi, g_done, q_hi, (float*)h->wav.p, pl.n_out, 0, ts)) != CSS_OK) return rc;
+                if (io.wav_host) {
+                    const int64_t a = g_done * fhop, b = (g_hi == TL) ? pl.n_out : g_hi * fhop;
+                    hipEvent_t done = pool_event(h);
+                    HIPCHK(h, hipEventRecord(done, ts));
+                    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
+                    for (int sp = 0; sp < S; ++sp)
+                        HIPCHK(h, hipMemcpyAsync(io.wav_host + (size_t)sp * io.cap + a, (const float*)h->wav.p + (size_t)sp * pl.n_out + a,
+                                                 (size_t)(b - a) * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+                    if (last && pc + 1 == pieces) {
+                        out_done = pool_event(h);
+                        HIPCHK(h, hipEventRecord(out_done, h->copy_stream));
+                    }
                 }
+                g_done = g_hi;
             }
-            g_done = g_hi;
         }
         return CSS_OK;
     };
@@ -1198,6 +1205,11 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             if (units[k].seg_lo == seg_lo && units[k].n == cnt) u = &units[k];
         if (!u) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
         mvdr_on(h, seg_lo, seg_lo + cnt, st);
+        HIPCHK(h, hipEventRecord(u->v, st));
+        // raw stitching costs of this unit's boundaries (losses.py:50-71); the first one joins the previous unit's last
+        // segment, whose masks / separated spectra are final once that unit's beamformer is
+        if (u != &units[0]) HIPCHK(h, hipStreamWaitEvent(st, (u - 1)->v, 0));
+        pit_costs_on(h, std::max<int64_t>(seg_lo - 1, 0), seg_lo + cnt - 1, st);
         HIPCHK(h, hipEventRecord(u->m, st));
         return CSS_OK;
     };
