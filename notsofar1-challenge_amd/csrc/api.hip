@@ -980,23 +980,34 @@ int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     return css_stage_stitch_gate(h, y_lo, t_hi);
 }
 
-// synthesis GEMM over frames [f_lo, f_hi), then overlap-add of output blocks [q_lo, q_hi) using only those frames
-static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
-                      int64_t out_q0, hipStream_t st) {
+// synthesis GEMM over frames [f_lo, f_hi) into G
+static void istft_gemm_on(css_ctx* h, int64_t f_lo, int64_t f_hi, hipStream_t st) {
+    if (f_hi <= f_lo) return;
     const int S = h->d.num_spks, N = h->d.frame_len;
     const int64_t TL = h->plan.mix_frames;
-    if (f_hi > f_lo) {
-        GemmArgs g{};
-        g.split_in = h->split ? 1 : 0;   // Y rows were written as split operands by the stitch stage
-        g.range_flag = h->split ? h->range_flag_dev : nullptr;
-        g.A = (const float*)h->Y.p + f_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
-        g.B = h->split ? h->dft_split : h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
-        g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
-        g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
-        g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
-        { CSS_PROF(CSS_PROF_ISTFT_GEMM, st); launch_gemm(g, st); }
-        { CSS_PROF(CSS_PROF_WAVE_OLA, st); launch_wave_ola((const float*)h->G.p, out, S, TL, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, h->split ? h->peak_dev : nullptr, st); }
-    }
+    GemmArgs g{};
+    g.split_in = h->split ? 1 : 0;   // Y rows were written as split operands by the stitch stage
+    g.range_flag = h->split ? h->range_flag_dev : nullptr;
+    g.A = (const float*)h->Y.p + f_lo * h->KIp; g.lda = h->KIp; g.strideA = TL * h->KIp;
+    g.B = h->split ? h->dft_split : h->dft_inv_t; g.ldb = h->KIp; g.strideB = 0;
+    g.C = (float*)h->G.p + f_lo * N; g.ldc = N; g.strideC = TL * N;
+    g.M = (int)(f_hi - f_lo); g.N = N; g.K = h->KIp; g.batch = S;
+    g.bias = nullptr; g.act = ACT_NONE; g.residual = nullptr; g.alpha = 1.f;
+    CSS_PROF(CSS_PROF_ISTFT_GEMM, st);
+    launch_gemm(g, st);
+}
+// overlap-add of output blocks [q_lo, q_hi) from the frames [f_lo, f_hi) of G; `out` may be mapped host memory
+static void wave_ola_on(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
+                        int64_t out_q0, hipStream_t st) {
+    if (f_hi <= f_lo) return;
+    CSS_PROF(CSS_PROF_WAVE_OLA, st);
+    launch_wave_ola((const float*)h->G.p, out, h->d.num_spks, h->plan.mix_frames, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld,
+                    out_q0, h->split ? h->peak_dev : nullptr, st);
+}
+static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
+                      int64_t out_q0, hipStream_t st) {
+    istft_gemm_on(h, f_lo, f_hi, st);
+    wave_ola_on(h, f_lo, f_hi, q_lo, q_hi, out, out_ld, out_q0, st);
     hipEventRecord(h->ev[6], st);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -1036,6 +1047,13 @@ struct RunIo {
     float* peaks_host = nullptr;
     int64_t cap = 0;
 };
+
+// device address of page-locked (hipHostMalloc / css_host_alloc / registered) host memory, nullptr for pageable memory
+static void* mapped_host(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
 
 static hipEvent_t pool_event(css_ctx* h) {
     if (h->ev_pool_used == h->ev_pool.size()) {
@@ -1124,12 +1142,18 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
                                              (size_t)(u.s_hi - u.s_lo) * sizeof(int16_t), hipMemcpyHostToDevice, h->copy_stream));
             }
             HIPCHK(h, hipEventRecord(u.up, h->copy_stream));
+            // the recording's level (power-of-two gain of the split synthesis operand) piece by piece, beside the next upload
+            if (io.pcm_host) launch_pcm_peak_f32(h->pcm_src + u.s_lo * n_ch, (u.s_hi - u.s_lo) * n_ch, h->peak_dev, h->copy_stream);
+            else
+                for (int c = 0; c < n_ch; ++c)
+                    launch_pcm_peak_i16(planes_dev + (size_t)c * n + u.s_lo, u.s_hi - u.s_lo, h->peak_dev, h->copy_stream);
         }
-        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, units.back().up, 0));
+        hipEvent_t level = pool_event(h);
+        HIPCHK(h, hipEventRecord(level, h->copy_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, level, 0));
+    } else {
+        launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->tail_stream);
     }
-    // the recording's level (power-of-two gain of the split synthesis operand), once every sample is on the device
-    if (planes_dev) launch_pcm_peak_i16(planes_dev, n * n_ch, h->peak_dev, h->tail_stream);
-    else launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->tail_stream);
     if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
 
@@ -1138,6 +1162,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     const StitchArgs sa = stitch_args(h);
     int64_t t_done = 0, g_done = 0;     // frames overlap-added / gated and synthesised so far
     hipEvent_t out_done = nullptr;
+    // page-locked output: the overlap-add of the synthesis writes the samples straight into the caller's buffer over
+    // PCIe (no device-side copy of the waveforms, no copy call: the runtime's device-to-host copies made the host wait
+    // for the events they depend on); pageable output: into the device buffer, then a copy
+    float* wav_mapped = io.wav_host ? (float*)mapped_host(io.wav_host) : nullptr;
     // (one tail per BATCH, not per unit: these kernels are latency-bound chains of small launches -- a third of the
     // frames takes the same ~120 us -- and the lanes of a batch finish together, so per-unit tails only queue up)
     auto tail_of = [&](size_t k0, size_t k1) -> int {   // units [k0, k1)
@@ -1162,8 +1190,26 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
                 { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, g_done, g_hi, ts); }
                 if (last && pc + 1 == pieces) hipEventRecord(h->ev[5], ts);
                 const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
-                if ((rc = istft_impl(h, std::max<int64_t>(g_done - 1, 0), g_hi, g_done, q_hi, (float*)h->wav.p, pl.n_out, 0, ts)) != CSS_OK) return rc;
-                if (io.wav_host) {
+                const int64_t f_lo = std::max<int64_t>(g_done - 1, 0);
+                istft_gemm_on(h, f_lo, g_hi, ts);
+                if (wav_mapped) {   // the PCIe-bound overlap-add goes to the copy stream: the next piece's kernels run beside it
+                    hipEvent_t done = pool_event(h);
+                    HIPCHK(h, hipEventRecord(done, ts));
+                    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
+                    wave_ola_on(h, f_lo, g_hi, g_done, q_hi, wav_mapped, io.cap, 0, h->copy_stream);
+                    hipEventRecord(h->ev[6], h->copy_stream);
+                    if (last && pc + 1 == pieces) {
+                        out_done = pool_event(h);
+                        HIPCHK(h, hipEventRecord(out_done, h->copy_stream));
+                    }
+                } else if (io.wav_dev) {   // device-resident output: straight into the caller's buffer
+                    wave_ola_on(h, f_lo, g_hi, g_done, q_hi, io.wav_dev, io.cap, 0, ts);
+                    hipEventRecord(h->ev[6], ts);
+                } else {
+                    wave_ola_on(h, f_lo, g_hi, g_done, q_hi, (float*)h->wav.p, pl.n_out, 0, ts);
+                    hipEventRecord(h->ev[6], ts);
+                }
+                if (io.wav_host && !wav_mapped) {
                     const int64_t a = g_done * fhop, b = (g_hi == TL) ? pl.n_out : g_hi * fhop;
                     hipEvent_t done = pool_event(h);
                     HIPCHK(h, hipEventRecord(done, ts));
@@ -1233,9 +1279,6 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         HIPCHK(h, hipMemcpy2DAsync(io.wav16_host, (size_t)io.cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
                                    (size_t)n_out * sizeof(int16_t), S, hipMemcpyDeviceToHost, h->stream));
         if (io.peaks_host) HIPCHK(h, hipMemcpyAsync(io.peaks_host, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    } else if (io.wav_dev) {
-        HIPCHK(h, hipMemcpy2DAsync(io.wav_dev, (size_t)io.cap * sizeof(float), h->wav.p, (size_t)pl.n_out * sizeof(float),
-                                   (size_t)pl.n_out * sizeof(float), S, hipMemcpyDeviceToDevice, h->stream));
     }
     // range check (split_f16.hpp): a split GEMM whose operand left the format's range raised this word
     HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));

@@ -84,7 +84,21 @@ __global__ void pcm16_to_cm_kernel(const int16_t* __restrict__ planes, float* __
 template <class T>
 __global__ __launch_bounds__(256) void pcm_peak_kernel(const T* __restrict__ x, int64_t count, float scale, unsigned int* __restrict__ peak) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf((float)x[i]));
+    constexpr int V = 16 / (int)sizeof(T);                        // values per 16-byte load
+    const int64_t head = std::min<int64_t>(count, (V - (int64_t)((reinterpret_cast<uintptr_t>(x) / sizeof(T)) % V)) % V);
+    const int64_t nv = (count - head) / V;
+    struct alignas(16) Vec { T v[V]; };
+    const Vec* xv = reinterpret_cast<const Vec*>(x + head);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const Vec q = xv[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m = fmaxf(m, fabsf((float)q.v[e]));
+    }
+    if (blockIdx.x == 0)   // the unaligned head and the tail
+        for (int64_t i = threadIdx.x; i < head + (count - head - nv * V); i += 256) {
+            const int64_t j = i < head ? i : head + nv * V + (i - head);
+            m = fmaxf(m, fabsf((float)x[j]));
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak, __float_as_uint(m * scale));
@@ -92,11 +106,11 @@ __global__ __launch_bounds__(256) void pcm_peak_kernel(const T* __restrict__ x, 
 
 void launch_pcm_peak_f32(const float* x, int64_t count, unsigned int* peak, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(pcm_peak_kernel<float>, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, s, x, count, 1.0f, peak);
+    hipLaunchKernelGGL(pcm_peak_kernel<float>, dim3((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, s, x, count, 1.0f, peak);
 }
 void launch_pcm_peak_i16(const int16_t* x, int64_t count, unsigned int* peak, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, s, x, count, 1.0f / 32768.0f, peak);
+    hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256 + 1, 2048)), dim3(256), 0, s, x, count, 1.0f / 32768.0f, peak);
 }
 
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,

@@ -7,10 +7,14 @@ d = sys.argv[1]
 kt = pd.read_csv(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0])
 mc = pd.read_csv(glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True)[0])
 kt["name"] = kt["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("css::", "").str.slice(0, 40)
-# a pass starts with the first deinterleave kernel after a gap; take the last pass
-starts = kt[kt["name"].str.contains("deinterleave")]["Start_Timestamp"].values
-gaps = [starts[0]] + [b for a, b in zip(starts, starts[1:]) if b - a > 2_000_000]
-t0 = gaps[-1] - 700_000
+# a pass starts with its first host-to-device copy; take the last pass (H2D copies closer than 2 ms belong together)
+h2d = mc[mc["Direction"].str.contains("HOST_TO_DEVICE")]["Start_Timestamp"].sort_values().values if len(mc) else []
+if len(h2d):
+    groups = [h2d[0]] + [b for a, b in zip(h2d, h2d[1:]) if b - a > 2_000_000]
+    t0 = groups[-1] - 20_000
+else:
+    starts = kt[kt["name"].str.contains("deinterleave")]["Start_Timestamp"].values
+    t0 = ([starts[0]] + [b for a, b in zip(starts, starts[1:]) if b - a > 2_000_000])[-1] - 20_000
 k = kt[kt["Start_Timestamp"] >= t0].copy(); m = mc[mc["Start_Timestamp"] >= t0].copy()
 base = min(k["Start_Timestamp"].min(), m["Start_Timestamp"].min() if len(m) else 1 << 62)
 rel = lambda x: (x - base) / 1e3
@@ -24,6 +28,6 @@ for q, g in k.groupby("Queue_Id"):
     g = g.sort_values("Start_Timestamp")
     busy = ((g["End_Timestamp"] - g["Start_Timestamp"]).sum()) / 1e3
     print(f"queue {q}: {len(g)} kernels, first {g.iloc[0]['name']} at {rel(g.iloc[0]['Start_Timestamp']):.1f}, last {g.iloc[-1]['name']} ends {rel(g.iloc[-1]['End_Timestamp']):.1f}, sum of durations {busy:.1f} us")
-    head = g.head(4); tail = g.tail(14)
+    head = g.head(5); tail = g.tail(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     for _, r in pd.concat([head, tail]).iterrows():
         print(f"    {rel(r['Start_Timestamp']):9.1f} -> {rel(r['End_Timestamp']):9.1f}  {r['name']}")
