@@ -171,6 +171,15 @@ int css_get_stream(css_handle_t h, void** stream_out);
  * not depend on it, bit for bit. */
 int css_set_lanes(css_handle_t h, int lanes);
 int css_get_lanes(css_handle_t h);
+/* Schedule choices of the css_run* pipeline.  They change WHEN work is enqueued, never a result bit; the defaults are what
+ * measured best on the 60 s / 30 min meetings (tools/ab_tuning.py runs the alternatives on one box). */
+enum css_tuning {
+    CSS_TUNE_TAIL_PIECES = 0,   /* pieces the last frame range is synthesised and downloaded in (1..4, default 1)          */
+    CSS_TUNE_OUT_MAPPED = 1,    /* 1 (default): the overlap-add kernel writes page-locked output over PCIe itself; 0: DMA  */
+    CSS_TUNE_TAIL_PER_UNIT = 2, /* 1: stitch / synthesise after every lane's unit; 0 (default): once per batch             */
+    CSS_TUNE_COUNT = 3
+};
+int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,
  * asynchronously, in pieces that overlap the first and last kernels of the pass; pageable memory works too, at the
  * driver's staged-copy rate.  (hipHostMalloc / hipHostFree; no handle needed.) */

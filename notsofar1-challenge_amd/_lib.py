@@ -81,6 +81,7 @@ SIGNATURES = {
     "css_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "css_set_lanes": (C.c_int, [_P, C.c_int]),
     "css_get_lanes": (C.c_int, [_P]),
+    "css_set_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "css_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "css_host_free": (C.c_int, [_P]),
     "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
@@ -293,6 +294,11 @@ class Handle:
 
     def set_lanes(self, lanes: int):
         check(self.h, self.lib.css_set_lanes(self.h, int(lanes)))
+
+    def set_tuning(self, which, value: int):
+        """which: "tail_pieces" | "out_mapped" | "tail_per_unit" (include/css_mi355.h css_tuning)"""
+        idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2}[which] if isinstance(which, str) else int(which)
+        check(self.h, self.lib.css_set_tuning(self.h, idx, int(value)))
 
     def lanes(self) -> int:
         return int(self.lib.css_get_lanes(self.h))

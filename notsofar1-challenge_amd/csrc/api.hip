@@ -111,6 +111,10 @@ struct css_ctx {
     // order, on this stream -- stitching costs, the permutation scan, overlap-add, gate, synthesis) trails the lanes unit
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
+    // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
+    int tune[CSS_TUNE_COUNT] = {1, 1, 0};
+    const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
+    void* mapped_val = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
     size_t ev_pool_used = 0;
 
@@ -1165,7 +1169,11 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // page-locked output: the overlap-add of the synthesis writes the samples straight into the caller's buffer over
     // PCIe (no device-side copy of the waveforms, no copy call: the runtime's device-to-host copies made the host wait
     // for the events they depend on); pageable output: into the device buffer, then a copy
-    float* wav_mapped = io.wav_host ? (float*)mapped_host(io.wav_host) : nullptr;
+    float* wav_mapped = nullptr;
+    if (io.wav_host && h->tune[CSS_TUNE_OUT_MAPPED]) {
+        if (h->mapped_key != io.wav_host) { h->mapped_key = io.wav_host; h->mapped_val = mapped_host(io.wav_host); }
+        wav_mapped = (float*)h->mapped_val;
+    }
     // (one tail per BATCH, not per unit: these kernels are latency-bound chains of small launches -- a third of the
     // frames takes the same ~120 us -- and the lanes of a batch finish together, so per-unit tails only queue up)
     auto tail_of = [&](size_t k0, size_t k1) -> int {   // units [k0, k1)
@@ -1184,9 +1192,12 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, g_done, g_end, ts); }
             // the last range leaves in two pieces, so that the first piece's download runs beside the second's synthesis
             // (more pieces do not pay: these launches are latency-bound, a fifth of the frames costs what all of them cost)
-            const int pieces = (last && io.wav_host && g_end - g_done >= 512) ? 2 : 1;
+            const int pieces = (last && io.wav_host && g_end - g_done >= 512) ? std::max(h->tune[CSS_TUNE_TAIL_PIECES], 1) : 1;
+            const int64_t g_first = g_done;
             for (int pc = 0; pc < pieces; ++pc) {
-                const int64_t g_hi = pc + 1 == pieces ? g_end : g_done + (g_end - g_done) * 3 / 5;
+                // (two pieces: 3/5 + 2/5, the second download is the exposed one; more: equal parts)
+                const int64_t g_hi = pc + 1 == pieces ? g_end
+                                     : (pieces == 2 ? g_first + (g_end - g_first) * 3 / 5 : g_first + (g_end - g_first) * (pc + 1) / pieces);
                 { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, g_done, g_hi, ts); }
                 if (last && pc + 1 == pieces) hipEventRecord(h->ev[5], ts);
                 const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
@@ -1262,7 +1273,12 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         first = ui;
         if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post)) != CSS_OK) return rc;
-        if ((rc = tail_of(first, ui)) != CSS_OK) return rc;
+        if (h->tune[CSS_TUNE_TAIL_PER_UNIT]) {
+            for (size_t k = first; k < ui; ++k)
+                if ((rc = tail_of(k, k + 1)) != CSS_OK) return rc;
+        } else if ((rc = tail_of(first, ui)) != CSS_OK) {
+            return rc;
+        }
     }
     h->stft_done = h->perms_done = true;
     hipEventRecord(h->ev[3], h->stream);
@@ -1359,6 +1375,12 @@ int css_set_lanes(css_handle_t h, int lanes) {
 }
 
 int css_get_lanes(css_handle_t h) { return h ? h->lanes : (int)CSS_ERR_INVALID_ARG; }
+
+int css_set_tuning(css_handle_t h, int which, int value) {
+    if (!h || which < 0 || which >= CSS_TUNE_COUNT || value < 0 || value > 16) return fail(h, CSS_ERR_INVALID_ARG, "unknown tuning option / value");
+    h->tune[which] = value;
+    return CSS_OK;
+}
 
 int css_set_range_fallback(css_handle_t h, int enable) {
     if (!h) return CSS_ERR_INVALID_ARG;
