@@ -27,11 +27,16 @@ __device__ __forceinline__ int valid_frames(int64_t stft_frames, int64_t seg, in
 //   w_k[f,t] = mask_k[f,t] if it is the maximum over the S speaker masks and the summed noise mask,
 //              else 1e-10                                            (mvdr_util.py:50-55)
 //   Phi_k[f] = sum_t w_k[f,t] x[f,t] x[f,t]^H  (+ 1e-15 I)            (mvdr_util.py:61-65)
-// A group of 16 lanes owns one (bin f, mask k) of a segment: its lanes stride over time (64-byte contiguous reads
-// of the seven Re/Im plane rows), 49 float64 accumulators per lane, and the 16 partial sums are combined with four
-// DPP steps (quad swaps, then the 8- and 16-lane mirrors) -- no LDS, no wave-wide butterfly: the 49 x 6
-// ds_bpermute reductions of the earlier one-wave-per-mask version left its waves parked 65 % of the time (303 us for
-// 40 segments).  Block = 4 bins x 4 masks.
+//
+// One wave per (segment, bin).  The 14 Re / Im plane rows and the mask rows of the bin are read ONCE, as whole
+// contiguous rows, into a wave-private LDS tile (the four masks used to re-read the planes 64 bytes at a time).  A frame
+// has one winner, so
+//   Phi_k = sum_{t: k wins} (m_k - 1e-10) P_t  +  1e-10 sum_t P_t,        P_t = x_t x_t^H  (7 real + 21 complex entries)
+// and the outer product of a frame is formed once, for its winner, instead of once per mask: the frames are sorted by
+// winner into four lists (wave ballots), the 16 lanes of group k walk list k -- every lane busy on every step, a third
+// of the float64 work of the mask-major loop -- and keep two accumulator sets, the weighted sum and the plain sum; the
+// plain sums of the four groups add up to sum_t P_t (a frame with tied winners is in each of their lists, but counts
+// towards the plain sum only in the first one).  The 16 partial sums are combined with four DPP steps (row16_sum).
 // ------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
@@ -49,80 +54,118 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void scm_kernel(MvdrArgs a) {
-    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    const int f = blockIdx.x * 4 + (grp >> 2), k = grp & 3, segl = blockIdx.y;
+constexpr int SCM_WAVES = 2;   // bins per block
+
+__global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float scm_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = lane >> 4, l16 = lane & 15;
+    const int f = blockIdx.x * SCM_WAVES + wave, segl = blockIdx.y;
     const int64_t seg = a.seg_lo + segl;
     const int nm = a.S + 1;
     const int F = a.F, T = a.T;
-    if (k >= nm || f >= F) return;   // whole 16-lane rows leave together
+    if (f >= F) return;   // (whole waves; no block-wide barrier below)
     const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
     const int64_t st = seg * (int64_t)a.hop;
-    double acc[NPACK];
-#pragma unroll
-    for (int i = 0; i < NPACK; ++i) acc[i] = 0.0;
-    const float* mrow = a.masks + (int64_t)f * a.mask_ld + seg * (int64_t)T;
-    const int64_t mstride = (int64_t)F * a.mask_ld;
+    // wave-private tile: x[14][T] (rows c: Re, 7 + c: Im), m[4][T], then the four frame lists (uint16) and 4 x 49 doubles
+    float* xs = scm_lds + (size_t)wave * ((14 + 4) * T + 2 * T + 4 * NPACK * 2);
+    float* ms = xs + 14 * T;
+    unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * T);    // [4][T]
+    double* plain = reinterpret_cast<double*>(ms + 4 * T + 2 * T);            // [4][NPACK] (8-byte aligned: T is even or padded below)
+    // ---- the bin's rows, contiguous along time
+    for (int r = 0; r < 2 * NC; ++r) {
+        const float* src = a.X + ((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st;
+        for (int t = lane; t < tv; t += 64) xs[r * T + t] = src[t];
+    }
+    for (int j = 0; j < nm; ++j) {
+        const float* src = a.masks + ((int64_t)j * F + f) * a.mask_ld + seg * (int64_t)T;
+        for (int t = lane; t < tv; t += 64) ms[j * T + t] = src[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- frames by winner: list j holds the frames mask j wins (bit 15: the frame's first winner)
     const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
-    // the operands of frame t + 16 are requested before frame t is accumulated (49 x 3 float64 operations per frame are
-    // long enough to cover the round trip; the loads of a frame used to start only when the previous one was done)
-    float n_m[4], n_xr[NC], n_xi[NC];
-    int n_ov = 0;
-    auto fetch = [&](int t_) {
-        const bool ok = t_ < tv;
-        const int tc = ok ? t_ : 0;
+    int cnt[4] = {0, 0, 0, 0};
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int t0 = 0; t0 < tv; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < tv;
+        float mv[4], mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) n_m[j] = (ok && j < nm) ? mrow[j * mstride + tc] : 0.f;
-        n_ov = (ok && ov) ? ov[tc] : 0;
+        for (int j = 0; j < 4; ++j) {
+            mv[j] = (ok && j < nm) ? ms[j * T + t] : -INFINITY;
+            mx = fmaxf(mx, mv[j]);
+        }
+        const int ovv = (ok && ov) ? ov[t] : -1;
+        bool seen = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // ties keep every tied mask, like mask == mask_max in the reference
+            const bool win = ok && j < nm && (ov ? (ovv == j) : (mv[j] == mx));
+            const unsigned long long b = __ballot(win);
+            if (win) lists[j * T + cnt[j] + __popcll(b & lt)] = (unsigned short)(t | (seen ? 0 : 0x8000));
+            cnt[j] += __popcll(b);
+            seen |= win;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- group k walks its list
+    double acc[NPACK], pl[NPACK];
+#pragma unroll
+    for (int i = 0; i < NPACK; ++i) { acc[i] = 0.0; pl[i] = 0.0; }
+    const int nk = k == 0 ? cnt[0] : (k == 1 ? cnt[1] : (k == 2 ? cnt[2] : cnt[3]));
+    for (int i = l16; i < nk; i += 16) {
+        const unsigned e = lists[k * T + i];
+        const int t = e & 0x7fff;
+        const double first = (e & 0x8000) ? 1.0 : 0.0;
+        const double w = (double)ms[k * T + t] - 1e-10;
+        double xr[NC], xi[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { xr[c] = (double)xs[c * T + t]; xi[c] = (double)xs[(NC + c) * T + t]; }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            n_xr[c] = ok ? a.X[((int64_t)c * 2 * F + f) * a.T_ld + st + tc] : 0.f;
-            n_xi[c] = ok ? a.X[((int64_t)c * 2 * F + F + f) * a.T_ld + st + tc] : 0.f;
+            const double p = xr[c] * xr[c] + xi[c] * xi[c];
+            acc[c] += w * p;
+            pl[c] += first * p;
         }
-    };
-    fetch(l16);
-    for (int t = l16; t < tv; t += 16) {
-        float mv[4], xr[NC], xi[NC];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mv[j] = n_m[j];
-        const int ovv = n_ov;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { xr[c] = n_xr[c]; xi[c] = n_xi[c]; }
-        fetch(t + 16);
-        // masks of this TF point: S speakers, then the noise mask (sum over noise outputs; one here)
-        float mk = 0.f, mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < nm) {
-                mx = fmaxf(mx, mv[j]);
-                if (j == k) mk = mv[j];
-            }
-        const bool win = ov ? (ovv == k) : (mk == mx);  // ties keep every tied mask, like mask == mask_max
-        const double w = win ? (double)mk : 1e-10;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] += w * ((double)xr[c] * xr[c] + (double)xi[c] * xi[c]);
         int p = NC;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int d = c + 1; d < NC; ++d) {
-                acc[p] += w * ((double)xr[c] * xr[d] + (double)xi[c] * xi[d]);      // Re x_c conj(x_d)
-                acc[p + 1] += w * ((double)xi[c] * xr[d] - (double)xr[c] * xi[d]);  // Im
+                const double pr = xr[c] * xr[d] + xi[c] * xi[d];      // Re x_c conj(x_d)
+                const double pi = xi[c] * xr[d] - xr[c] * xi[d];      // Im
+                acc[p] += w * pr; pl[p] += first * pr;
+                acc[p + 1] += w * pi; pl[p + 1] += first * pi;
                 p += 2;
             }
         }
     }
+    // ---- reduce over the group's 16 lanes; the plain sums of the four groups meet in LDS
+#pragma unroll
+    for (int i = 0; i < NPACK; ++i) {
+        acc[i] = row16_sum(acc[i]);
+        const double v = row16_sum(pl[i]);
+        if (l16 == (i & 15)) plain[k * NPACK + i] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (k >= nm) return;
     double* out = a.scm + ((seg * nm + k) * (int64_t)F + f) * NPACK;
 #pragma unroll
     for (int i = 0; i < NPACK; ++i) {
-        double v = row16_sum(acc[i]);
+        if (l16 != (i & 15)) continue;   // the 49 results leave through all 16 lanes
+        double v = acc[i] + 1e-10 * ((plain[i] + plain[NPACK + i]) + (plain[2 * NPACK + i] + plain[3 * NPACK + i]));
         if (i < NC) v += 1e-15;  // Ri += 1e-15 * I   (mvdr_util.py:63-65)
-        if (l16 == (i & 15)) out[i] = v;   // the 49 results leave through all 16 lanes
+        out[i] = v;
     }
 }
 
 void launch_scm(const MvdrArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(scm_kernel, dim3((a.F + 3) / 4, a.nseg), dim3(256), 0, s, a);
+    // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 49 doubles
+    const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * NPACK * 2) * sizeof(float);
+    hipLaunchKernelGGL(scm_kernel, dim3((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), dim3(64 * SCM_WAVES), per_wave * SCM_WAVES, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,140 @@
+// Analysis transform (feature.py:88-128: Hann-windowed 512-point DFT, hop 256) as an LDS-staged FFT.
+//
+// The reference evaluates the transform as a convolution with a DFT kernel (a direct O(N^2) sum); round 1 mirrored
+// that as a GEMM on the float32 matrix cores (13.8 GFLOP per minute of 7-channel audio, 180 us).  The transform is
+// memory-sized work -- 27 MB of samples in, 54 MB of planes out per minute -- so it is done here the cheap way:
+// a block owns 32 consecutive frames of one channel, reads their samples as contiguous runs (window applied on the
+// way in), packs each real frame into 256 complex points, runs four radix-4 Stockham stages over all 32 frames in LDS,
+// separates the real spectrum (bins 0 .. 256) and writes it transposed -- time fastest, 128-byte runs -- into the
+// planes X[c][Re f | Im f][t] every later stage reads.  The rounding is that of an FFT (~log2 N ulps against ~sqrt N for
+// the direct sum; both ~1e-7 relative to the frame's largest bin, tests/test_hip_parity.py holds the planes to 1e-6
+// against the oracle and 2e-6 against the reference).  The imaginary parts of the DC and Nyquist bins are exact zeros
+// by construction (the IPD feature's branch cut depends on it, frontend.hip CSS_PHASE_NEG_REAL).
+#include <cmath>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace css {
+
+constexpr int FFT_N = 512;            // frame length
+constexpr int FFT_H = 256;            // packed complex length = hop
+constexpr int FFT_TB = 32;            // frames per block
+constexpr int FFT_FS = FFT_H + 1;     // frame stride in LDS (complex elements): odd, so 32 frames hit 32 distinct bank pairs
+constexpr int FFT_THREADS = 512;
+
+// tables: window[512] | tw256[256] (cos, -sin of 2 pi m / 256) | tw512[257] (cos, -sin of 2 pi k / 512)
+size_t stft_table_floats() { return FFT_N + 2 * FFT_H + 2 * (FFT_H + 1); }
+
+void stft_build_tables(float* t) {
+    for (int n = 0; n < FFT_N; ++n) t[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));   // torch.hann_window (periodic), float32
+    float* t256 = t + FFT_N;
+    for (int m = 0; m < FFT_H; ++m) {
+        t256[2 * m] = (float)std::cos(2.0 * M_PI * m / FFT_H);
+        t256[2 * m + 1] = (float)(-std::sin(2.0 * M_PI * m / FFT_H));
+    }
+    float* t512 = t256 + 2 * FFT_H;
+    for (int k = 0; k <= FFT_H; ++k) {
+        t512[2 * k] = (float)std::cos(2.0 * M_PI * k / FFT_N);
+        t512[2 * k + 1] = (float)(-std::sin(2.0 * M_PI * k / FFT_N));
+    }
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// x: channel c's samples start at x + c * x_stride; frame t (0 .. nf-1) begins at sample t * 256.
+// out: plane row r of channel c, frame t at out + (c * 2F + r) * row_ld + t   (r = f: Re, F + f: Im; F = 257)
+__global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int nf,
+                                                               const float* __restrict__ tab, float* __restrict__ out,
+                                                               int64_t row_ld) {
+    extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
+    float2* bufA = fft_lds;
+    float2* bufB = fft_lds + FFT_TB * FFT_FS;
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y;
+    const int t0 = blockIdx.x * FFT_TB;
+    const float* xc = x + (int64_t)c * x_stride;
+    const float* win = tab;
+    const float2* tw256 = reinterpret_cast<const float2*>(tab + FFT_N);
+    const float2* tw512 = reinterpret_cast<const float2*>(tab + FFT_N + 2 * FFT_H);
+    // ---- windowed, packed load: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1]
+#pragma unroll 4
+    for (int e = tid; e < FFT_TB * FFT_H; e += FFT_THREADS) {
+        const int fr = e >> 8, n = e & 255;
+        const int t = min(t0 + fr, nf - 1);   // frames past the launch's range repeat the last one (never stored)
+        const float2 s = *reinterpret_cast<const float2*>(xc + (int64_t)t * FFT_H + 2 * n);
+        const float2 w = *reinterpret_cast<const float2*>(win + 2 * n);
+        bufA[fr * FFT_FS + n] = make_float2(s.x * w.x, s.y * w.y);
+    }
+    __syncthreads();
+    // ---- four radix-4 Stockham stages (decimation in time), ping-pong A -> B -> A -> B -> A
+    float2* src = bufA;
+    float2* dst = bufB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int Ns = 1 << (2 * p);              // 1, 4, 16, 64
+#pragma unroll
+        for (int i = 0; i < FFT_TB * 64 / FFT_THREADS; ++i) {
+            const int b = i * FFT_THREADS + tid;
+            const int fr = b >> 6, j = b & 63;
+            const int k = j & (Ns - 1);
+            const float2* in = src + fr * FFT_FS;
+            float2 u0 = in[j], u1 = in[j + 64], u2 = in[j + 128], u3 = in[j + 192];
+            if (p > 0) {
+                const int m = k * (64 / Ns);        // exp(-2 pi i k / (4 Ns)) = tw256[k * 64 / Ns]
+                u1 = cmulf(u1, tw256[m]);
+                u2 = cmulf(u2, tw256[2 * m]);
+                u3 = cmulf(u3, tw256[3 * m]);
+            }
+            // radix-4 butterfly (forward: multiply by -i is (x, y) -> (y, -x))
+            const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const float2 a2 = make_float2(u1.x + u3.x, u1.y + u3.y), a3 = make_float2(u1.y - u3.y, u3.x - u1.x);   // -i (u1 - u3)
+            const int j0 = ((j - k) << 2) + k;
+            float2* o = dst + fr * FFT_FS + j0;
+            o[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            o[Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+            o[2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            o[3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+        }
+        __syncthreads();
+        float2* tmp = src; src = dst; dst = tmp;
+    }
+    // ---- real spectrum from the packed transform Z (in src), written time-fastest
+    //   E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / (2i),  X[k] = E + e^{-2 pi i k / 512} O
+    const int F = FFT_H + 1;
+    const int tl = tid & (FFT_TB - 1);
+    const bool store = t0 + tl < nf;
+    float* oc = out + (int64_t)c * 2 * F * row_ld + t0 + tl;
+    for (int f = tid >> 5; f < F; f += FFT_THREADS / FFT_TB) {
+        const float2 z0 = src[tl * FFT_FS + (f & 255)];
+        const float2 z1 = src[tl * FFT_FS + ((256 - f) & 255)];
+        float re, im;
+        if (f == 0) { re = z0.x + z0.y; im = 0.f; }
+        else if (f == FFT_H) { re = z0.x - z0.y; im = 0.f; }
+        else {
+            const float2 e = make_float2(0.5f * (z0.x + z1.x), 0.5f * (z0.y - z1.y));
+            const float2 o = make_float2(0.5f * (z0.y + z1.y), 0.5f * (z1.x - z0.x));
+            const float2 wo = cmulf(tw512[f], o);
+            re = e.x + wo.x;
+            im = e.y + wo.y;
+        }
+        if (store) {
+            oc[(int64_t)f * row_ld] = re;
+            oc[(int64_t)(F + f) * row_ld] = im;
+        }
+    }
+}
+
+bool launch_stft_fft(const float* x, int64_t x_stride, int C, int nf, const float* tables, float* out, int64_t row_ld,
+                     hipStream_t s) {
+    if (nf <= 0 || C <= 0) return true;
+    const size_t lds = (size_t)2 * FFT_TB * FFT_FS * sizeof(float2);   // 131.6 KB
+    // (the attribute is per device: set it on every launch -- a host-side table lookup -- rather than behind a
+    // process-wide flag that a second device, or a second thread's first launch, would miss)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(stft_fft_kernel, dim3((nf + FFT_TB - 1) / FFT_TB, C), dim3(FFT_THREADS), lds, s, x, x_stride, nf, tables, out, row_ld);
+    return true;
+}
+
+}  // namespace css
