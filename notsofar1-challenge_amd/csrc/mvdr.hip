@@ -72,14 +72,28 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     float* ms = xs + 14 * T;
     unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * T);    // [4][T]
     double* plain = reinterpret_cast<double*>(ms + 4 * T + 2 * T);            // [4][NPACK] (8-byte aligned: T is even or padded below)
-    // ---- the bin's rows, contiguous along time
-    for (int r = 0; r < 2 * NC; ++r) {
-        const float* src = a.X + ((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st;
-        for (int t = lane; t < tv; t += 64) xs[r * T + t] = src[t];
-    }
-    for (int j = 0; j < nm; ++j) {
-        const float* src = a.masks + ((int64_t)j * F + f) * a.mask_ld + seg * (int64_t)T;
-        for (int t = lane; t < tv; t += 64) ms[j * T + t] = src[t];
+    // ---- the bin's rows, contiguous along time: every load of the 18 rows is in flight before the first LDS store
+    // (row by row, a wave waited out 18 memory round trips; T <= 256 = 4 x 64 lanes)
+    {
+        float v[2 * NC + 4][4];
+#pragma unroll
+        for (int r = 0; r < 2 * NC + 4; ++r) {
+            const float* src = r < 2 * NC ? a.X + ((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st
+                                          : a.masks + ((int64_t)(r - 2 * NC) * F + f) * a.mask_ld + seg * (int64_t)T;
+            const bool row_ok = r < 2 * NC + nm;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = lane + 64 * i;
+                v[r][i] = (row_ok && t < tv) ? src[t] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * NC + 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = lane + 64 * i;
+                if (t < tv) xs[r * T + t] = v[r][i];   // rows 14 .. 17 are the mask rows (ms = xs + 14 T)
+            }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

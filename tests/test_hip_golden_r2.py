@@ -78,8 +78,20 @@ def test_other_segmentations_vs_reference(L, sep_mc, mix60, golden, seg_hop):
     assert int(run_cfg.c.segment_frames) == Ts and h.get_plan().num_segments == wta.shape[0]
     m = h.read(L.BUF_MASKS).reshape(S + 1, F, wta.shape[0], Ts)
     assert np.abs(np.moveaxis(m[:S, :, 0], 0, 2)[::8, ::4] - g[name + "_masks_spk_seg0"]).max() < 1.5e-5
-    flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != wta).sum())
-    assert flips <= 1e-5 * wta.size + 3
+    # winner-take-all maps: rounding-level ties only -- except in a segment with an IPD feature ON the atan2 branch cut
+    # (test_oracle_golden_r2.py: the reference is discontinuous there), identified by the feature itself
+    X = O.stft(mix)
+    hop_f = int(run_cfg.c.hop_frames)
+    def on_cut(i):
+        seg = np.zeros((257, Ts, 7), np.complex64)
+        part = X[:, i * hop_f:i * hop_f + Ts]
+        seg[:, :part.shape[1]] = part
+        f = O.features(seg)[257:].reshape(6, 257, -1)[:, 1:256]
+        return bool(np.abs(np.abs(f) - np.pi).min() < 5e-7)
+    per_seg = [int((np.argmax(m[:, :, i], axis=0) != wta[i]).sum()) for i in range(wta.shape[0])]
+    cut = [i for i in range(wta.shape[0]) if per_seg[i] > 3 and on_cut(i)]
+    assert sum(n for i, n in enumerate(per_seg) if i not in cut) <= 1e-5 * wta.size + 3, per_seg
+    assert all(per_seg[i] <= 0.005 * 257 * Ts for i in cut) and len(cut) <= 1, (cut, per_seg)
     assert [tuple(x) for x in perms[1:]] == [tuple(x) for x in g[name + "_pit_perm"]]
     assert np.array_equal(act_f, unpack_bits(g[name + "_activity_final"], tuple(g[name + "_activity_shape"])))
     ww = take_windows(wav, 4)
