@@ -119,7 +119,8 @@ def _maybe_torch(arr: np.ndarray):
         return arr
 
 
-def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg: CssCfg) -> (List[np.ndarray], Dict):
+def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg: CssCfg,
+                        return_side_info: bool = True) -> (List[np.ndarray], Dict):
     """Applies speech separation in block-online fashion (css/css.py:110-338).
 
     Args:
@@ -128,6 +129,8 @@ def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg:
         fs: sample rate.
         device: GPU to run on (torch.device / 'cuda:N' / int).
         cfg: CSS configuration.
+        return_side_info: False skips the three device-to-host reads behind ``side_info`` (the stitched masks alone
+            are 347 MB for a 30-min meeting) and returns an empty dict; the reference always builds it.
     Returns:
         separated_wavs: list of ``cfg.num_spks`` float32 arrays [Nsamples_out].
         side_info: dict with 'mask_stitched' [1, F, T_long, S], 'activity_b' [T_long, S],
@@ -147,6 +150,8 @@ def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg:
     h = separator.handle
     wav = h.run(speech_mix[0], run_cfg)  # [S, n_out]
     separated_wavs = [wav[k] for k in range(desc.num_spks)]
+    if not return_side_info:
+        return separated_wavs, {}
 
     mask_st = h.read(_lib.BUF_MASK_ST)                       # [S, F, T_long]
     act_b = h.read(_lib.BUF_ACT_B).astype(bool)              # [S, T_long]
@@ -160,71 +165,88 @@ def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg:
     return separated_wavs, side_info
 
 
-def css_inference(out_dir: str, models_dir: str, session, cfg: CssCfg, fetch_from_cache: bool):
-    """Applies CSS to one session row (css/css.py:51-107).
+@dataclass
+class _SessionOutput:
+    """Where one session's CSS result lives and which shortcut, if any, answers the call without separating
+    (the rules of css/css.py:70-82: pass-through of channel 0, cache hit on an existing output directory)."""
+    directory: Path
+    shortcut: Optional[list]
 
-    Writes ``out_dir/css_inference/<session_id>/{input_mixture,sep_stream0..}.wav`` and returns a copy of
-    the session with ``sep_wav_file_names`` added.
-    """
-    _LOG.info("Running CSS (Continuous Speech Separation)")
-    session_css = session.copy()
+    @classmethod
+    def plan(cls, out_dir, session, cfg: CssCfg, fetch_from_cache: bool) -> "_SessionOutput":
+        assert isinstance(session.wav_file_names, list)
+        directory = Path(out_dir) / "css_inference" / session.session_id
+        if cfg.pass_through_ch0:
+            return cls(directory, session.wav_file_names[0:1])
+        if fetch_from_cache and directory.exists():
+            return cls(directory, sorted(directory.glob('sep*.wav')))
+        return cls(directory, None)
 
-    assert isinstance(session.wav_file_names, list)
-    if cfg.pass_through_ch0:
-        session_css['sep_wav_file_names'] = session.wav_file_names[0:1]
-        return session_css
+    def stream_path(self, i: int) -> Path:
+        return self.directory / f"sep_stream{i}.wav"
 
-    css_out_dir = Path(out_dir) / "css_inference" / session.session_id
-    if fetch_from_cache and css_out_dir.exists():
-        sep_wav_file_names = sorted(css_out_dir.glob('sep*.wav'))
-        session_css['sep_wav_file_names'] = sep_wav_file_names
-        return session_css
 
-    separator, _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if session.is_mc else cfg.checkpoint_sc))
-    device = f"cuda:{cfg.device_id}"
-    separator.eval()
+def _separate_pcm16_session(separator, raw, cfg: CssCfg, device):
+    """The device-side wav edges: raw int16 planes up, peak-normalised PCM16 streams down."""
+    sr = raw[0][1]
+    separator.to(device)
+    desc = separator.desc
+    run_cfg = make_run_cfg(cfg, sr, len(raw), desc.frame_len, desc.frame_hop)
+    pcm16, _ = separator.handle.run_pcm16([r[0] for r in raw], run_cfg)
+    mixture = raw[0][0].astype(np.float32) / np.float32(32768.0)
+    return sr, mixture, [pcm16[i] for i in range(pcm16.shape[0])], True
 
-    # Device-side wav edges (SURVEY.md 8f N1): when every input file is mono 16-bit PCM -- the NOTSOFAR recordings
-    # are -- the raw int16 samples go to the GPU (half the bytes of float32), are scaled there, and the separated
-    # streams come back already peak-normalised and PCM16-encoded exactly as write_wav encodes them.
-    raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
-    if raw and all(r is not None for r in raw) and len({r[0].shape[0] for r in raw}) == 1 and len({r[1] for r in raw}) == 1:
-        if session.is_mc:
-            assert len(raw) == NUM_MICS_MC, f'expecting {NUM_MICS_MC} microphones'
-        else:
-            assert len(raw) == 1
-        sr = raw[0][1]
-        separator.to(device)
-        desc = separator.desc
-        run_cfg = make_run_cfg(cfg, sr, len(raw), desc.frame_len, desc.frame_hop)
-        pcm16, _ = separator.handle.run_pcm16([r[0] for r in raw], run_cfg)
-        separator.close()
-        write_wav(css_out_dir / 'input_mixture.wav', samps=raw[0][0].astype(np.float32) / np.float32(32768.0), sr=sr)
-        sep_wav_file_names = []
-        for i in range(pcm16.shape[0]):
-            filename = css_out_dir / f"sep_stream{i}.wav"
-            _LOG.info(f"CSS: saving separated wav to {filename}")
-            write_pcm16_samples(filename, pcm16[i], sr)
-            sep_wav_file_names.append(str(filename))
-        session_css['sep_wav_file_names'] = sep_wav_file_names
-        return session_css
 
+def _separate_float_session(separator, session, cfg: CssCfg, device):
     mixwav, sr = load_audio(session.wav_file_names, is_mc=session.is_mc)
-
     if cfg.slice_audio_for_debug:
         mixwav = mixwav[:, sr * 20:sr * 30, :]
+    wavs, _ = separate_and_stitch(mixwav, separator, sr, device, cfg, return_side_info=False)
+    return sr, mixwav[0, :, 0], wavs, False
 
-    separated_wavs, _ = separate_and_stitch(mixwav, separator, sr, device, cfg)
-    separator.close()
 
-    write_wav(css_out_dir / 'input_mixture.wav', samps=mixwav[0, :, 0], sr=sr)
+def css_inference(out_dir: str, models_dir: str, session, cfg: CssCfg, fetch_from_cache: bool, separator=None):
+    """Applies CSS to one session row: the counterpart of css/css.py:51-107, same arguments, same files
+    (``out_dir/css_inference/<session_id>/{input_mixture,sep_stream0..}.wav``), same returned Series (a copy of the
+    session with ``sep_wav_file_names``).
 
-    sep_wav_file_names = []
-    for i, w in enumerate(separated_wavs):
-        filename = css_out_dir / f"sep_stream{i}.wav"
-        _LOG.info(f"CSS: saving separated wav to {filename}")
-        write_wav(filename, samps=w, sr=sr)
-        sep_wav_file_names.append(str(filename))
+    ``separator``: a model already resident on the GPU (the session loop of pipeline.py keeps one per model kind); by
+    default the checkpoint under ``models_dir`` is loaded for this call and released afterwards, as the reference does.
+    Mono 16-bit PCM inputs -- what the NOTSOFAR recordings are -- take the device-side wav edges: int16 over PCIe,
+    scaling, peak normalisation and PCM16 encoding on the GPU."""
+    _LOG.info("Running CSS (Continuous Speech Separation)")
+    result = session.copy()
+    where = _SessionOutput.plan(out_dir, session, cfg, fetch_from_cache)
+    if where.shortcut is not None:
+        result['sep_wav_file_names'] = where.shortcut
+        return result
 
-    session_css['sep_wav_file_names'] = sep_wav_file_names
-    return session_css
+    owned = separator is None
+    if owned:
+        separator, _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if session.is_mc else cfg.checkpoint_sc))
+    separator.eval()
+    device = f"cuda:{cfg.device_id}"
+    try:
+        raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
+        same_shape = raw and all(r is not None for r in raw) and len({(r[0].shape[0], r[1]) for r in raw}) == 1
+        if same_shape:
+            assert len(raw) == (NUM_MICS_MC if session.is_mc else 1), f'expecting {NUM_MICS_MC} microphones'
+            sr, mixture, streams, encoded = _separate_pcm16_session(separator, raw, cfg, device)
+        else:
+            sr, mixture, streams, encoded = _separate_float_session(separator, session, cfg, device)
+    finally:
+        if owned:
+            separator.close()
+
+    write_wav(where.directory / 'input_mixture.wav', samps=mixture, sr=sr)
+    names = []
+    for i, samples in enumerate(streams):
+        path = where.stream_path(i)
+        _LOG.info(f"CSS: saving separated wav to {path}")
+        if encoded:
+            write_pcm16_samples(path, samples, sr)
+        else:
+            write_wav(path, samps=samples, sr=sr)
+        names.append(str(path))
+    result['sep_wav_file_names'] = names
+    return result

@@ -22,9 +22,8 @@ import os
 from pathlib import Path
 from typing import Dict, Optional
 
-from .css import CssCfg, separate_and_stitch
+from .css import CssCfg, css_inference
 from .separator import load_css_model
-from .wavio import load_audio, write_wav
 
 _LOG = logging.getLogger('css')
 
@@ -41,44 +40,27 @@ def _rank_world(rank: Optional[int], world: Optional[int]):
 def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_from_cache: bool = False,
                  rank: Optional[int] = None, world: Optional[int] = None, device=None):
     """Run CSS on the sessions this rank owns; returns a DataFrame with those rows plus
-    ``sep_wav_file_names`` (same per-row contract as ``css_inference``, css/css.py:51-107)."""
+    ``sep_wav_file_names`` -- every row is exactly what ``css_inference`` returns for it (css/css.py:51-107)."""
+    import dataclasses
     import pandas as pd
     rank, world = _rank_world(rank, world)
     if device is None:
         device = f"cuda:{int(os.environ.get('LOCAL_RANK', cfg.device_id))}"
-    separators: Dict[bool, object] = {}
+    dev_index = int(str(device).split(":")[1]) if ":" in str(device) else int(cfg.device_id)
+    cfg = dataclasses.replace(cfg, device_id=dev_index)
+    resident: Dict[bool, object] = {}
     rows = []
-    for pos in range(rank, len(sessions_df), world):
-        session = sessions_df.iloc[pos]
-        session_css = session.copy()
-        assert isinstance(session.wav_file_names, list)
-        if cfg.pass_through_ch0:                                                   # css.py:73-75
-            session_css['sep_wav_file_names'] = session.wav_file_names[0:1]
-            rows.append(session_css)
-            continue
-        css_out_dir = Path(out_dir) / "css_inference" / session.session_id
-        if fetch_from_cache and css_out_dir.exists():                              # css.py:78-82
-            session_css['sep_wav_file_names'] = sorted(css_out_dir.glob('sep*.wav'))
-            rows.append(session_css)
-            continue
-        is_mc = bool(session.is_mc)
-        if is_mc not in separators:
-            sep, _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if is_mc else cfg.checkpoint_sc),
-                                    device=device)
-            separators[is_mc] = sep.eval()
-        mixwav, sr = load_audio(session.wav_file_names, is_mc=is_mc)
-        if cfg.slice_audio_for_debug:
-            mixwav = mixwav[:, sr * 20:sr * 30, :]
-        _LOG.info(f"CSS [{rank}/{world}] session {session.session_id}: {mixwav.shape[1] / sr:.1f} s")
-        separated_wavs, _ = separate_and_stitch(mixwav, separators[is_mc], sr, device, cfg)
-        write_wav(css_out_dir / 'input_mixture.wav', samps=mixwav[0, :, 0], sr=sr)
-        names = []
-        for i, w in enumerate(separated_wavs):
-            filename = css_out_dir / f"sep_stream{i}.wav"
-            write_wav(filename, samps=w, sr=sr)
-            names.append(str(filename))
-        session_css['sep_wav_file_names'] = names
-        rows.append(session_css)
-    for sep in separators.values():
-        sep.close()
+    try:
+        for pos in range(rank, len(sessions_df), world):
+            session = sessions_df.iloc[pos]
+            is_mc = bool(session.is_mc)
+            shortcut = cfg.pass_through_ch0 or (fetch_from_cache and (Path(out_dir) / "css_inference" / session.session_id).exists())
+            if not shortcut and is_mc not in resident:   # one resident model per kind, loaded on first use
+                resident[is_mc], _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if is_mc else cfg.checkpoint_sc),
+                                                    device=device)
+            _LOG.info(f"CSS [{rank}/{world}] session {session.session_id}")
+            rows.append(css_inference(out_dir, models_dir, session, cfg, fetch_from_cache, separator=resident.get(is_mc)))
+    finally:
+        for sep in resident.values():
+            sep.close()
     return pd.DataFrame(rows)

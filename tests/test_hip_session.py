@@ -88,22 +88,82 @@ def test_css_inference_from_files(tmp_path, tiny_models):
         css.css_inference(str(tmp_path / "out2"), str(tmp_path / "nope"), session, cfg, False)
 
 
-def test_session_loop_shards_by_session(tmp_path, tiny_models):
-    import pandas as pd
-    css, wavio, pipe = pkg("css"), pkg("wavio"), pkg("pipeline")
-    models_dir, models = tiny_models
-    mix = (pkg("synth").synth_meeting(5.0, 7, seed=10) * 0.05).astype(np.float32)
-    rows = [_write_session(tmp_path, wavio, mix[:, : 70000 + 1000 * i], f"S{i}_mc", True) for i in range(2)]
+def _session_rows(tmp_path, wavio):
+    mix = (pkg("synth").synth_meeting(8.0, 7, seed=10) * 0.25).astype(np.float32)
+    rows = [_write_session(tmp_path, wavio, mix[:, : 100000 + 1000 * i], f"S{i}_mc", True) for i in range(2)]
     rows.append(_write_session(tmp_path, wavio, mix[:, :72000, :1], "S2_sc", False))
-    df = pd.DataFrame(rows)
+    return rows
+
+
+def _check_session_outputs(part, models, wavio, css, sep_mod):
+    """Every row's files hold exactly what the handle returns for that session's PCM16 planes (bit for bit), and the
+    oracle -- driven by its own masks, free-running -- agrees with them to the conditioning of these short clips."""
+    cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
+    for _, row in part.iterrows():
+        kind = "mc" if row.is_mc else "sc"
+        st, desc = models[kind]
+        raw = [wavio.read_wav_pcm16(p) for p in row.wav_file_names]
+        sep = sep_mod.HipSeparator(st, None, device=0)
+        try:
+            run_cfg = css.make_run_cfg(cfg, 16000, len(raw), desc.frame_len, desc.frame_hop)
+            direct, _ = sep.handle.run_pcm16([r[0] for r in raw], run_cfg)
+        finally:
+            sep.close()
+        assert len(row.sep_wav_file_names) == 3
+        mixq = np.stack([r[0].astype(np.float32) / np.float32(32768.0) for r in raw], axis=1)[None]
+        ow, _ = O.separate_and_stitch(mixq, O.ConformerParams(st), 16000, O.OracleCssCfg(activity_th=0.3), mvdr_cplx=np.complex128)
+        for i, f in enumerate(row.sep_wav_file_names):
+            assert os.path.basename(f) == f"sep_stream{i}.wav" and os.path.basename(os.path.dirname(f)) == row.session_id
+            got, sr = wavio.read_wav_pcm16(f)
+            assert sr == 16000 and np.array_equal(got, direct[i]) and np.abs(got).max() == 32439
+            ref = ow[i] * 0.99 / (np.max(np.abs(ow[i])) + 1e-7)
+            y = got.astype(np.float64) / 32767.0
+            gain = float(y @ ref / (ref @ ref))
+            assert abs(gain - 1) < 0.05 and rel_rms(y, gain * ref) < 5e-2, (row.session_id, i, gain)
+
+
+def test_session_loop_shards_by_session(tmp_path, tiny_models):
+    """pipeline.css_sessions (inference.py:37-107's CSS leg): rank r takes every world-th session, one resident model
+    per kind, each row produced by css_inference itself (PCM16 device edges); both virtual ranks, then the cache rule."""
+    import pandas as pd
+    css, wavio, pipe, sep_mod = pkg("css"), pkg("wavio"), pkg("pipeline"), pkg("separator")
+    models_dir, models = tiny_models
+    df = pd.DataFrame(_session_rows(tmp_path, wavio))
     cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
     parts = [pipe.css_sessions(str(tmp_path / "o"), models_dir, df, cfg, rank=r, world=2, device="cuda:0") for r in range(2)]
     assert [list(p.session_id) for p in parts] == [["S0_mc", "S2_sc"], ["S1_mc"]]
     for p in parts:
-        for _, row in p.iterrows():
-            assert len(row.sep_wav_file_names) == 3 and all(os.path.exists(f) for f in row.sep_wav_file_names)
-            y, sr = wavio.read_wav(row.sep_wav_file_names[0])
-            assert sr == 16000 and np.isfinite(y).all() and abs(np.abs(y).max() - 0.99) < 1e-3
+        assert list(p.columns) == list(df.columns) + ["sep_wav_file_names"]
+        _check_session_outputs(p, models, wavio, css, sep_mod)
+    cached = pipe.css_sessions(str(tmp_path / "o"), "no_models_needed_for_a_cache_hit", df, cfg, fetch_from_cache=True, rank=0, world=1)
+    assert [[os.path.basename(str(f)) for f in r] for r in cached.sep_wav_file_names] == [[f"sep_stream{i}.wav" for i in range(3)]] * 3
+
+
+def _session_worker(rank, world, tmp, models_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), "0"
+    import pandas as pd
+    css, pipe = pkg("css"), pkg("pipeline")
+    df = pd.read_pickle(os.path.join(tmp, "sessions.pkl"))
+    part = pipe.css_sessions(os.path.join(tmp, "o2"), models_dir, df, css.CssCfg(activity_th=0.3, show_progressbar=False))
+    part.to_pickle(os.path.join(tmp, f"part{rank}.pkl"))
+
+
+def test_session_loop_in_two_processes(tmp_path, tiny_models):
+    """The same loop as torchrun would start it: two processes, RANK / WORLD_SIZE / LOCAL_RANK from the environment
+    (utils/torch_utils.py:10-11), one GPU shared by both; together they cover every session exactly once."""
+    import pandas as pd
+    import torch.multiprocessing as mp
+    css, wavio, sep_mod = pkg("css"), pkg("wavio"), pkg("separator")
+    models_dir, models = tiny_models
+    df = pd.DataFrame(_session_rows(tmp_path, wavio))
+    df.to_pickle(tmp_path / "sessions.pkl")
+    mp.spawn(_session_worker, args=(2, str(tmp_path), models_dir), nprocs=2, join=True)
+    parts = [pd.read_pickle(tmp_path / f"part{r}.pkl") for r in range(2)]
+    assert sorted(sum((list(p.session_id) for p in parts), [])) == sorted(df.session_id)
+    for p in parts:
+        _check_session_outputs(p, models, wavio, css, sep_mod)
 
 
 def test_pcm16_wav_edges_on_device_are_bit_exact(tmp_path, tiny_models):
