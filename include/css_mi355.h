@@ -294,6 +294,17 @@ int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int3
  * pcm_host [batch][n_samples][n_ch] -> masks_host [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1
  * (2 <= T' <= 256), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
 int css_forward_host(css_handle_t h, const float* pcm_host, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks_host);
+/* The validation loss of the reference's training loop for a batch of equally long clips (css/training/train.py:411-481
+ * _calc_loss as train.py:529 eval_model calls it; no backward pass): forward as css_forward_host, |STFT| of microphone 0
+ * of the mixture and of the ground truths, PIT over the speaker outputs (css/training/losses.py:50-97 PitWrapper: the
+ * assignment of least mean loss), the noise loss, *loss = mean_b(spk_loss[b] + noise_weight * noise_loss[b]).
+ *   mix_host [batch][n][n_ch];  gt_spk_host [batch][S][n], gt_noise_host [batch][n]: the ground truths AT microphone 0
+ *   (train.py:421-425 slices them out of the batch's [.., Mics, ..] tensors);
+ *   loss_name 0 = 'masked_mag' (train.py:449), 1 = 'mask' (:464);  base_loss 0 = l1, 1 = mse (losses.py:100-106);
+ *   clip_gt: TrainCfg.clip_gt_to_mixture (train.py:431).  spk_loss / noise_loss [batch], perms [batch][S] may be NULL. */
+int css_validation_loss_host(css_handle_t h, const float* mix_host, const float* gt_spk_host, const float* gt_noise_host,
+                             int32_t batch, int64_t n_samples, int32_t n_ch, int32_t loss_name, int32_t base_loss, int32_t clip_gt,
+                             float noise_weight, float* spk_loss, float* noise_loss, int32_t* perms, float* loss);
 /* istft: Y [B][2F][T] planes (Re rows then Im rows, time fastest) -> wav [B][(T-1)*hop + frame_len]. */
 int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav);
 

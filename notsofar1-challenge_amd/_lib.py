@@ -117,6 +117,8 @@ SIGNATURES = {
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "css_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    "css_validation_loss_host": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_float, _P, _P, _P, C.POINTER(C.c_float)]),
     "css_buffer_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "css_read_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "css_write_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -479,6 +481,25 @@ class Handle:
         out = np.empty(((self.desc.num_spks + self.desc.num_nois) * self.desc.num_bins, b * max(t, 0)), dtype=np.float32)
         check(self.h, self.lib.css_forward_host(self.h, _np_ptr(pcm), b, n, c, _np_ptr(out)))
         return out
+
+    def validation_loss(self, mix: np.ndarray, gt_spk0: np.ndarray, gt_noise0: np.ndarray, loss_name: str = "masked_mag",
+                        base_loss: str = "mse", clip_gt_to_mixture: bool = False, noise_weight: float = 1.0):
+        """train.py:411 _calc_loss for a validation batch: mix [B, n, C], gt_spk0 [B, S, n], gt_noise0 [B, n] (ground
+        truths at microphone 0) -> (loss, spk_loss [B], noise_loss [B], perms [B, S])."""
+        mix = np.ascontiguousarray(mix, dtype=np.float32)
+        gs = np.ascontiguousarray(gt_spk0, dtype=np.float32)
+        gn = np.ascontiguousarray(gt_noise0, dtype=np.float32)
+        b, n, c = mix.shape
+        s = int(self.desc.num_spks)
+        assert gs.shape == (b, s, n) and gn.shape == (b, n)
+        spk, noi = np.empty(b, np.float32), np.empty(b, np.float32)
+        perms = np.empty((b, s), np.int32)
+        loss = C.c_float()
+        check(self.h, self.lib.css_validation_loss_host(
+            self.h, _np_ptr(mix), _np_ptr(gs), _np_ptr(gn), b, n, c, {"masked_mag": 0, "mask": 1}[loss_name],
+            {"l1": 0, "mse": 1}[base_loss], int(bool(clip_gt_to_mixture)), float(noise_weight), _np_ptr(spk), _np_ptr(noi),
+            _np_ptr(perms), C.byref(loss)))
+        return float(loss.value), spk, noi, perms
 
     def istft_host(self, planes: np.ndarray) -> np.ndarray:
         """planes [B, 2F, T] -> wav [B, (T-1)*hop + frame_len]."""

@@ -1558,10 +1558,12 @@ int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int3
 }
 
 // ConformerCssWrapper.forward (conformer_wrapper.py:58-77) for a batch of equally long clips, fused on the device:
-// the training loop's validation forward.  pcm [batch][n_samples][n_ch] -> masks
-// [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1, clip b in columns [b T', (b+1) T').
-int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks) {
-    if (!h || !pcm || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+// the training loop's validation forward.  pcm [batch][n_samples][n_ch] -> planes X [C][2F][batch * T']
+// and masks M [(S+1) F][batch * T'] in the handle's staging buffer, T' = (n_samples - frame_len) / hop + 1, clip b in
+// columns [b T', (b+1) T'); `extra_floats` more floats are reserved behind them (*extra).
+static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64_t n_samples, int32_t n_ch, size_t extra_floats,
+                          float** Xo, float** Mo, float** extra, int* To) {
+    if (!h || !pcm || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     const int F = h->d.num_bins, C = h->d.num_mics, N = h->d.frame_len, hop = h->d.frame_hop;
     const int nm = h->d.num_spks + h->d.num_nois;
     if (n_ch != C) return fail(h, CSS_ERR_SHAPE, "the model expects " + std::to_string(C) + " channels");
@@ -1575,7 +1577,7 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
     const size_t in_f = (size_t)batch * n_samples * C, cm_f = (size_t)batch * C * n_pad;
     const size_t x_f = (size_t)C * 2 * F * TT, m_f = (size_t)nm * F * TT;
     int rc;
-    if ((rc = ensure(h, h->stage, (in_f + cm_f + x_f + m_f + 64) * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->stage, (in_f + cm_f + x_f + m_f + extra_floats + 128) * sizeof(float))) != CSS_OK) return rc;
     float* in = (float*)h->stage.p;
     float* cm = in + (in_f + 15) / 16 * 16;
     float* X = cm + (cm_f + 15) / 16 * 16;
@@ -1592,9 +1594,84 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
     MaskIo io{X, TT, TT, T, T, M, TT};  // clip b is the "segment" starting at frame b*T
     for (int64_t s0 = 0; s0 < batch; s0 += cap)
         if ((rc = masknet_batch(h, io, s0, (int)std::min<int64_t>(cap, batch - s0))) != CSS_OK) return rc;
+    *Xo = X; *Mo = M; *To = T;
+    if (extra) *extra = M + (m_f + 15) / 16 * 16;
+    return CSS_OK;
+}
+
+int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks) {
+    if (!h || !masks) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    float *X, *M;
+    int T;
+    int rc = forward_staged(h, pcm, batch, n_samples, n_ch, 0, &X, &M, nullptr, &T);
+    if (rc != CSS_OK) return rc;
+    const size_t m_f = (size_t)(h->d.num_spks + h->d.num_nois) * h->d.num_bins * batch * T;
     HIPCHK(h, hipMemcpyAsync(masks, M, m_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+// css/training/train.py:411 _calc_loss for a validation batch (train.py:529 eval_model): forward, |STFT| of the mixture's
+// and the ground truths' reference channel, S x S base-loss matrix per clip -> PIT (losses.py:32-48: the assignment of
+// least mean loss; exhaustive over the <= 6 permutations, first minimum in lexicographic order), noise loss, weighted mean.
+int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_spk, const float* gt_noise, int32_t batch,
+                             int64_t n_samples, int32_t n_ch, int32_t loss_name, int32_t base_loss, int32_t clip_gt,
+                             float noise_weight, float* spk_loss, float* noise_loss, int32_t* perms, float* loss) {
+    if (!h || !gt_spk || !gt_noise || !loss) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (loss_name < 0 || loss_name > 1 || base_loss < 0 || base_loss > 1) return fail(h, CSS_ERR_INVALID_ARG, "unknown loss_name / base_loss");
+    const int F = h->d.num_bins, S = h->d.num_spks;
+    if (S > 3 || h->d.num_nois != 1) return fail(h, CSS_ERR_INVALID_ARG, "at most three speaker outputs and one noise output");
+    const int64_t n_pad = (n_samples + 31) / 32 * 32;
+    const int nsig = batch * (S + 1), chunks = val_loss_chunks(F);
+    const int64_t T64 = n_samples >= h->d.frame_len ? (n_samples - h->d.frame_len) / h->d.frame_hop + 1 : 0;
+    const size_t sig_f = (size_t)nsig * n_pad, g_f = (size_t)nsig * 2 * F * std::max<int64_t>(T64, 1), p_f = (size_t)batch * chunks * 16 * 2;
+    float *X, *M, *extra;
+    int T;
+    int rc = forward_staged(h, mix, batch, n_samples, n_ch, sig_f + g_f + p_f + 64, &X, &M, &extra, &T);
+    if (rc != CSS_OK) return rc;
+    float* sig = extra;                                   // [batch][S + 1][n_pad]: the speakers, then the noise
+    float* G = sig + (sig_f + 15) / 16 * 16;              // their planes [batch * (S + 1)][2F][T]
+    double* partial = reinterpret_cast<double*>(G + (g_f + 15) / 16 * 16);
+    HIPCHK(h, hipMemsetAsync(sig, 0, sig_f * sizeof(float), h->stream));
+    for (int b = 0; b < batch; ++b) {
+        HIPCHK(h, hipMemcpy2DAsync(sig + (size_t)b * (S + 1) * n_pad, (size_t)n_pad * sizeof(float), gt_spk + (size_t)b * S * n_samples,
+                                   (size_t)n_samples * sizeof(float), (size_t)n_samples * sizeof(float), S, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(sig + ((size_t)b * (S + 1) + S) * n_pad, gt_noise + (size_t)b * n_samples,
+                                 (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!launch_stft_fft(sig, n_pad, nsig, T, h->stft_tab, G, T, h->stream))
+        return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
+    launch_val_loss(X, M, G, batch, T, F, S, loss_name, base_loss, clip_gt ? 1 : 0, partial, h->stream);
+    std::vector<double> part((size_t)batch * chunks * 16);
+    HIPCHK(h, hipMemcpyAsync(part.data(), partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    const double inv = 1.0 / ((double)F * T);
+    double total = 0.0;
+    for (int b = 0; b < batch; ++b) {
+        double mat[9] = {0}, noise = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            const double* q = part.data() + ((size_t)b * chunks + c) * 16;
+            for (int i = 0; i < 9; ++i) mat[i] += q[i];
+            noise += q[9];
+        }
+        // the assignment of least mean loss: perm[a] = ground truth assigned to prediction a
+        int best_p[3] = {0, 1, 2}, p[3] = {0, 1, 2};
+        double best = 0.0;
+        bool have = false;
+        do {
+            double tot = 0.0;
+            for (int a = 0; a < S; ++a) tot += mat[a * 3 + p[a]];
+            if (!have || tot < best) { best = tot; have = true; for (int a = 0; a < S; ++a) best_p[a] = p[a]; }
+        } while (std::next_permutation(p, p + S));
+        const double sl = best * inv / S, nl = noise * inv;
+        if (spk_loss) spk_loss[b] = (float)sl;
+        if (noise_loss) noise_loss[b] = (float)nl;
+        if (perms) for (int a = 0; a < S; ++a) perms[b * S + a] = best_p[a];
+        total += sl + (double)noise_weight * nl;
+    }
+    *loss = (float)(total / batch);
     return CSS_OK;
 }
 

@@ -136,6 +136,14 @@ void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int ho
 void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// loss.hip -- validation loss of the training loop (train.py:411 _calc_loss): S x S base-loss sums + the noise term
+// ------------------------------------------------------------------------------------------------
+int val_loss_chunks(int F);
+// partial: B * val_loss_chunks(F) * 16 doubles (entries a * 3 + s and [15 -> 9]: see loss.hip)
+void launch_val_loss(const float* X, const float* masks, const float* G, int B, int T, int F, int S, int loss_name, int base,
+                     int clip, double* partial, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // mvdr.hip -- WTA masks, spatial covariance, MVDR solve, beamform + mask
 // ------------------------------------------------------------------------------------------------
 struct MvdrArgs {

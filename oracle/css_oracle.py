@@ -663,3 +663,46 @@ def separate_and_stitch(speech_mix: np.ndarray, params: ConformerParams, fs: int
     if taps is not None:
         taps["stft_stitched"] = stft_st
     return [wavs[k].astype(np.float32) for k in range(s)], side
+
+
+# ----------------------------------------------------------------------------------------------
+# validation loss of the training loop (css/training/train.py:411-470 _calc_loss, :529 eval_model)
+# ----------------------------------------------------------------------------------------------
+def validation_loss(params: ConformerParams, mix: np.ndarray, gt_spk0: np.ndarray, gt_noise0: np.ndarray,
+                    loss_name: str = "masked_mag", base_loss: str = "mse", clip_gt_to_mixture: bool = False,
+                    noise_weight: float = 1.0):
+    """mix [B, n, M]; gt_spk0 [B, S, n] and gt_noise0 [B, n]: the ground truths at the reference microphone
+    (train.py:421-425 takes mic 0 of the batch's ground-truth tensors).  -> (loss, spk_loss [B], noise_loss [B], perms).
+
+    train.py:413-420  forward and |STFT| of the mixture's mic 0; :427-438 optional clipping of the targets to the mixture;
+    :449-462 'masked_mag' (mask * |mix| against |gt|) or :464-476 'mask' (mask against |gt| / (|mix| + eps));
+    PIT over the speaker outputs (losses.py:50-97), plain loss for the noise output; :481 the weighted mean."""
+    eps = np.float32(np.finfo(np.float32).eps)
+    b_, n, m = mix.shape
+    s = gt_spk0.shape[1]
+    spk_loss, noise_loss, perms = [], [], []
+    for b in range(b_):
+        x = stft(mix[b])                                                       # [F, T, M]
+        masks = conformer_forward(params, features(x if m > 1 else x[:, :, 0]))   # [S + 1, F, T]
+        mixmag = np.abs(x[:, :, 0]).astype(np.float32)                          # [F, T]
+        gt = np.stack([np.abs(stft(gt_spk0[b, k][:, None])[:, :, 0]) for k in range(s)], axis=-1).astype(np.float32)   # [F, T, S]
+        gn = np.abs(stft(gt_noise0[b][:, None])[:, :, 0]).astype(np.float32)
+        if clip_gt_to_mixture:
+            gt = np.minimum(gt, mixmag[..., None])
+            gn = np.minimum(gn, mixmag)
+        pred = np.moveaxis(masks[:s], 0, 2)                                     # [F, T, S]
+        pn = masks[s:].sum(axis=0) if masks.shape[0] - s > 1 else masks[s]
+        if loss_name == "masked_mag":
+            pred, pn = pred * mixmag[..., None], pn * mixmag
+            tgt, tn = gt, gn
+        elif loss_name == "mask":
+            tgt, tn = gt / (mixmag[..., None] + eps), gn / (mixmag + eps)
+        else:
+            raise ValueError(f"Unknown loss name: {loss_name}!")
+        best, perm, _ = pit_perm(pred, tgt, "l1" if base_loss == "l1" else "mse")
+        d = pn.astype(np.float64) - tn.astype(np.float64)
+        spk_loss.append(best)
+        noise_loss.append(float(np.mean(np.abs(d)) if base_loss == "l1" else np.mean(d * d)))
+        perms.append(perm)
+    spk_loss, noise_loss = np.array(spk_loss), np.array(noise_loss)
+    return float(np.mean(spk_loss + noise_weight * noise_loss)), spk_loss, noise_loss, perms

@@ -223,3 +223,32 @@ def test_css_inference_against_the_captured_triple(tmp_path, mc_state, mix60):
     assert [rel(p) for p in res2["sep_wav_file_names"]] == t["cached_sep_wav_file_names"]
     res3 = CSS.css_inference(str(out_dir), "unused", session, CSS.CssCfg(pass_through_ch0=True), fetch_from_cache=False)
     assert [os.path.basename(p) for p in res3["sep_wav_file_names"]] == t["pass_through"]
+
+
+def test_validation_loss_vs_reference(L):
+    """css_validation_loss_host (train.py:411 _calc_loss on the device) against the reference's own _calc_loss +
+    PitWrapper: every loss / base-loss / clipping branch; per-sample speaker losses, target permutations, the scalar."""
+    from test_oracle_golden_r2 import loss_inputs
+    with open(os.path.join(GOLDEN, "val_loss.json")) as f:
+        g = json.load(f)
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=g["num_blocks"])
+    st = w.apply_golden_recipe(w.portable_state_dict(desc, g["weights_seed"]))
+    mix, gt_spk0, gt_noise0 = loss_inputs(g["seed"], g["batch"], g["n"])
+    sep = pkg("separator").HipSeparator(st, None, device=0)
+    try:
+        for mode in ("split_f16", "exact_f32"):
+            sep.handle.set_linear_mode(mode)
+            for case in g["cases"]:
+                loss, spk, noi, perms = sep.handle.validation_loss(mix, gt_spk0, gt_noise0, case["loss_name"], case["base_loss"],
+                                                                   case["clip_gt_to_mixture"], case["noise_weight"])
+                assert perms.tolist() == case["perms"], (mode, case)
+                assert np.allclose(spk, case["spk_loss"], rtol=5e-5), (mode, case, spk)
+                assert abs(loss / case["loss"] - 1) < 5e-5, (mode, case, loss)
+                ol, ospk, onoi, _ = O.validation_loss(O.ConformerParams(st), mix, gt_spk0, gt_noise0, case["loss_name"],
+                                                     case["base_loss"], case["clip_gt_to_mixture"], case["noise_weight"])
+                assert np.allclose(noi, onoi, rtol=5e-5) and abs(loss / ol - 1) < 5e-5
+        with pytest.raises(L.CssError):
+            sep.handle.validation_loss(mix[:, :, :1], gt_spk0, gt_noise0)      # one channel into the 7-channel model
+    finally:
+        sep.close()

@@ -185,3 +185,39 @@ def test_wav_codec_against_the_session_triple(tmp_path, mix60):
     back, _ = W.read_wav_pcm16(tmp_path / "css_inference" / "x" / "input_mixture.wav")
     key = [k for k in t["pcm16_sha256"] if k.endswith("input_mixture.wav")][0]
     assert sha(back.astype(np.int16)) == t["pcm16_sha256"][key] and len(back) == t["lengths"][key]
+
+
+def loss_inputs(seed=7, batch=3, n=24000, mics=7, spks=3):
+    """The portable generator of tests/golden/gen_golden_loss.py (same RandomState sequence)."""
+    rs = np.random.RandomState(seed)
+    src = rs.standard_normal((batch, spks, n)).astype(np.float32)
+    for b in range(batch):
+        for s in range(spks):
+            src[b, s] *= (0.2 + 0.8 * (np.sin(2 * np.pi * (np.arange(n) / n) * (1 + s + b)) > 0)).astype(np.float32) * 0.3
+    noise = (rs.standard_normal((batch, n)) * 0.05).astype(np.float32)
+    gains = rs.uniform(0.5, 1.0, size=(mics, spks)).astype(np.float32)
+    delays = rs.randint(0, 6, size=(mics, spks))
+    mix = np.zeros((batch, n, mics), np.float32)
+    for m in range(mics):
+        for s in range(spks):
+            mix[:, :, m] += gains[m, s] * np.roll(src[:, s], int(delays[m, s]), axis=-1)
+        mix[:, :, m] += noise * np.float32(1.0 + 0.1 * m)
+    gt_spk0 = np.stack([gains[0, s] * np.roll(src[:, s], int(delays[0, s]), axis=-1) for s in range(spks)], axis=1)
+    return mix, gt_spk0.astype(np.float32), noise
+
+
+def test_validation_loss_vs_reference():
+    """css/training/train.py:411 _calc_loss (the loss train.py:529 eval_model averages) with the reference's own
+    PitWrapper: every loss / base-loss / clipping branch, the per-sample speaker losses and target permutations."""
+    with open(os.path.join(GOLDEN, "val_loss.json")) as f:
+        g = json.load(f)
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=g["num_blocks"])
+    params = O.ConformerParams(w.apply_golden_recipe(w.portable_state_dict(desc, g["weights_seed"])))
+    mix, gt_spk0, gt_noise0 = loss_inputs(g["seed"], g["batch"], g["n"])
+    for case in g["cases"]:
+        loss, spk, noi, perms = O.validation_loss(params, mix, gt_spk0, gt_noise0, case["loss_name"], case["base_loss"],
+                                                  case["clip_gt_to_mixture"], case["noise_weight"])
+        assert [list(p) for p in perms] == case["perms"], case
+        assert np.allclose(spk, case["spk_loss"], rtol=2e-5), (case, spk)
+        assert abs(loss / case["loss"] - 1) < 2e-5, (case, loss)
