@@ -305,6 +305,17 @@ int css_forward_host(css_handle_t h, const float* pcm_host, int32_t batch, int64
 int css_validation_loss_host(css_handle_t h, const float* mix_host, const float* gt_spk_host, const float* gt_noise_host,
                              int32_t batch, int64_t n_samples, int32_t n_ch, int32_t loss_name, int32_t base_loss, int32_t clip_gt,
                              float noise_weight, float* spk_loss, float* noise_loss, int32_t* perms, float* loss);
+/* Downstream hand-off.  The reference writes the streams to wav files for Whisper to read back
+ * (asr/asr.py:58,73-74) and notes "potential optimization: drop silent parts to save ASR compute" (css/css.py:313).  After a
+ * css_run_device pass, stream `stream` of the caller's device buffer wav_dev [S][wav_ld] is cut to the frames the activity
+ * gate kept (css.py:303-312), each run widened by pad_frames, runs merged: regions_host [n_regions][2] are the sample
+ * ranges kept -- the time map back to the meeting -- and mel_host [n_mels][*n_mel_frames] receives Whisper's input
+ * features of their concatenation (whisper/audio.py log_mel_spectrogram: reflect-padded 400-point Hann STFT, hop 160,
+ * power, slaney mel bank with n_mels = 80 or 128, log10 floored at 1e-10, max - 8 clamp, (x + 4) / 4), computed on the
+ * device.  drop_silence = 0: one region, the whole stream.  Whisper is not under the reference tree: parity unpinned. */
+int css_handoff_logmel(css_handle_t h, const float* wav_dev, int64_t wav_ld, int32_t stream, int32_t n_mels, int32_t pad_frames,
+                       int32_t drop_silence, float* mel_host, int64_t mel_capacity_frames, int64_t* n_mel_frames,
+                       int64_t* regions_host, int32_t max_regions, int32_t* n_regions);
 /* istft: Y [B][2F][T] planes (Re rows then Im rows, time fastest) -> wav [B][(T-1)*hop + frame_len]. */
 int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav);
 

@@ -117,6 +117,8 @@ SIGNATURES = {
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "css_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    "css_handoff_logmel": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
+                                     C.POINTER(C.c_int64), _P, C.c_int32, C.POINTER(C.c_int32)]),
     "css_validation_loss_host": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, _P, _P, _P, C.POINTER(C.c_float)]),
     "css_buffer_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -481,6 +483,21 @@ class Handle:
         out = np.empty(((self.desc.num_spks + self.desc.num_nois) * self.desc.num_bins, b * max(t, 0)), dtype=np.float32)
         check(self.h, self.lib.css_forward_host(self.h, _np_ptr(pcm), b, n, c, _np_ptr(out)))
         return out
+
+    def handoff_logmel(self, wav_ptr: int, wav_ld: int, stream: int, n_mels: int = 80, pad_frames: int = 8,
+                       drop_silence: bool = True, max_regions: int = 4096):
+        """After run_device: (log-mel [n_mels, frames] of the stream's active regions, regions [n, 2] sample ranges)."""
+        p = self.get_plan()
+        cap = int(p.n_out) // 160 + 1
+        mel = np.empty((n_mels, cap), dtype=np.float32)
+        regions = np.zeros((max_regions, 2), dtype=np.int64)
+        nfr, nreg = C.c_int64(), C.c_int32()
+        flat = np.empty(n_mels * cap, dtype=np.float32)
+        check(self.h, self.lib.css_handoff_logmel(self.h, C.c_void_p(wav_ptr), int(wav_ld), int(stream), int(n_mels), int(pad_frames),
+                                                  int(bool(drop_silence)), _np_ptr(flat), cap, C.byref(nfr), _np_ptr(regions),
+                                                  max_regions, C.byref(nreg)))
+        del mel
+        return flat[:n_mels * nfr.value].reshape(n_mels, nfr.value).copy(), regions[:nreg.value].copy()
 
     def validation_loss(self, mix: np.ndarray, gt_spk0: np.ndarray, gt_noise0: np.ndarray, loss_name: str = "masked_mag",
                         base_loss: str = "mse", clip_gt_to_mixture: bool = False, noise_weight: float = 1.0):

@@ -81,7 +81,7 @@ struct css_ctx {
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host, w_on_device;   // segment weights of the session / what segw holds (uploaded when they change)
     DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, qkf, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
-        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc, level;
+        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc, level, mel_tab, mel_work;
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
     // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two or three chains drift out of
@@ -100,6 +100,7 @@ struct css_ctx {
     // finished ranges of the output leave while the last ranges are still being synthesised.
     // range check of the split-f16 operand format (split_f16.hpp): a device word set when the stitched activity or the
     // waveforms hold a non-finite value, mirrored into page-locked host memory at the end of every pass
+    int mel_bands = 0;                    // the filterbank mel_tab holds (0: none yet)
     unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
     unsigned int* range_flag_dev = nullptr;
     unsigned int* range_flag_host = nullptr;
@@ -498,7 +499,7 @@ int css_destroy(css_handle_t h) {
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->qkf, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
                       &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
-                      &h->in16, &h->pcm_f, &h->enc, &h->level};
+                      &h->in16, &h->pcm_f, &h->enc, &h->level, &h->mel_tab, &h->mel_work};
     for (int l = 1; l < css_ctx::MAX_LANES; ++l) {
         for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lqkf[l], &h->lctx[l]})
             if (b->p) hipFree(b->p);
@@ -1672,6 +1673,87 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
         total += sl + (double)noise_weight * nl;
     }
     *loss = (float)(total / batch);
+    return CSS_OK;
+}
+
+// the frames of stream `stream` that the activity gate kept (css.py:303-312) -> sample regions (the time
+// map back) -> their concatenation -> Whisper's log-mel features, all from device-resident samples.
+int css_handoff_logmel(css_handle_t h, const float* wav_dev, int64_t wav_ld, int32_t stream, int32_t n_mels, int32_t pad_frames,
+                       int32_t drop_silence, float* mel_host, int64_t mel_capacity_frames, int64_t* n_mel_frames,
+                       int64_t* regions_host, int32_t max_regions, int32_t* n_regions) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!wav_dev || !mel_host || !n_mel_frames || !regions_host || !n_regions || max_regions < 1)
+        return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (stream < 0 || stream >= h->d.num_spks || (n_mels != 80 && n_mels != 128) || pad_frames < 0)
+        return fail(h, CSS_ERR_INVALID_ARG, "stream out of range, or n_mels not 80 / 128");
+    if (!h->perms_done) return fail(h, CSS_ERR_STATE, "no finished pass in this session");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t TL = h->plan.mix_frames, n_out = h->plan.n_out;
+    const int hop = h->d.frame_hop, N = h->d.frame_len;
+    if (wav_ld < n_out) return fail(h, CSS_ERR_INVALID_ARG, "wav_ld shorter than the streams");
+    // ---- regions: maximal runs of active frames, widened by pad_frames, merged; frame t spans samples [t hop, t hop + N)
+    std::vector<uint8_t> act((size_t)TL);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(act.data(), (const uint8_t*)h->act_final.p + (size_t)stream * TL, (size_t)TL, hipMemcpyDeviceToHost));
+    std::vector<int64_t> reg;
+    if (!drop_silence) {
+        reg = {0, n_out};
+    } else {
+        for (int64_t t = 0; t < TL;) {
+            if (!act[(size_t)t]) { ++t; continue; }
+            int64_t e = t;
+            while (e < TL && act[(size_t)e]) ++e;
+            const int64_t a = std::max<int64_t>(t - pad_frames, 0) * hop, b = std::min<int64_t>((e - 1 + pad_frames) * hop + N, n_out);
+            if (!reg.empty() && a <= reg.back()) reg.back() = std::max(reg.back(), b);
+            else { reg.push_back(a); reg.push_back(b); }
+            t = e;
+        }
+    }
+    const int nr = (int)(reg.size() / 2);
+    *n_regions = nr;
+    if (nr > max_regions) return fail(h, CSS_ERR_INVALID_ARG, "more regions than max_regions: " + std::to_string(nr));
+    std::vector<int64_t> offs((size_t)std::max(nr, 1), 0);
+    int64_t n_act = 0;
+    for (int r = 0; r < nr; ++r) { offs[(size_t)r] = n_act; n_act += reg[2 * r + 1] - reg[2 * r]; regions_host[2 * r] = reg[2 * r]; regions_host[2 * r + 1] = reg[2 * r + 1]; }
+    const int64_t nfr = n_act / 160;                        // whisper: 1 + n // hop frames, the last one dropped
+    *n_mel_frames = nfr;
+    if (nfr == 0) return CSS_OK;
+    if (nfr > mel_capacity_frames) return fail(h, CSS_ERR_INVALID_ARG, "mel buffer too small: need " + std::to_string(nfr) + " frames");
+    // ---- tables (once per filterbank size)
+    const size_t dft_f = (size_t)402 * 416, melw_f = (size_t)128 * 201;
+    if ((rc = ensure(h, h->mel_tab, (dft_f + melw_f) * sizeof(float))) != CSS_OK) return rc;
+    float* dftm = (float*)h->mel_tab.p;
+    float* melw = dftm + dft_f;
+    if (h->mel_bands != n_mels) {
+        std::vector<float> t(dft_f + melw_f, 0.f);
+        handoff_build_dft(t.data());
+        handoff_build_mel(t.data() + dft_f, n_mels);
+        HIPCHK(h, hipMemcpy(dftm, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->mel_bands = n_mels;
+    }
+    // ---- work: region table | gathered samples | spectra [402][ld] | mel [n_mels][nfr] | max
+    const int64_t ld = (nfr + 3) / 4 * 4, total = n_act + 400 + 416;
+    const size_t tab_b = (size_t)nr * 3 * sizeof(int64_t) + 64;
+    const size_t need = tab_b + ((size_t)total + (size_t)402 * ld + (size_t)n_mels * nfr + 64) * sizeof(float);
+    if ((rc = ensure(h, h->mel_work, need)) != CSS_OK) return rc;
+    int64_t* regs_d = (int64_t*)h->mel_work.p;
+    int64_t* offs_d = regs_d + 2 * nr;
+    float* gath = (float*)((char*)h->mel_work.p + (tab_b + 63) / 64 * 64);
+    float* spec = gath + (total + 15) / 16 * 16;
+    float* mel = spec + (size_t)402 * ld;
+    int* gmax = (int*)(mel + (size_t)n_mels * nfr + 8);
+    HIPCHK(h, hipMemcpyAsync(regs_d, reg.data(), (size_t)nr * 2 * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(offs_d, offs.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    launch_handoff_gather(wav_dev + (size_t)stream * wav_ld, regs_d, offs_d, nr, n_act, gath, total, h->stream);
+    GemmArgs g{};
+    g.A = dftm; g.lda = 416; g.B = gath; g.ldb = 160; g.C = spec; g.ldc = ld;
+    g.M = 402; g.N = (int)nfr; g.K = 416; g.batch = 1; g.alpha = 1.f;
+    launch_gemm(g, h->stream);                              // exact float32 matrix cores: 402 x 416 per frame
+    launch_handoff_mel(spec, ld, nfr, melw, n_mels, mel, gmax, h->stream);
+    HIPCHK(h, hipMemcpyAsync(mel_host, mel, (size_t)n_mels * nfr * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
     return CSS_OK;
 }
 

@@ -136,6 +136,15 @@ void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int ho
 void launch_planes_to_rows(const float* planes, float* rows, int B, int F2, int64_t T, int KIp, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// handoff.hip -- active regions of a separated stream -> Whisper log-mel features on the device
+// ------------------------------------------------------------------------------------------------
+void handoff_build_dft(float* m);                 // [402][416]
+void handoff_build_mel(float* w, int n_mels);     // [n_mels][201]
+void launch_handoff_gather(const float* wav, const int64_t* regions, const int64_t* offs, int nr, int64_t n_act, float* out,
+                           int64_t total, hipStream_t s);
+void launch_handoff_mel(const float* spec, int64_t ld, int64_t nfr, const float* w, int n_mels, float* mel, int* gmax, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // loss.hip -- validation loss of the training loop (train.py:411 _calc_loss): S x S base-loss sums + the noise term
 // ------------------------------------------------------------------------------------------------
 int val_loss_chunks(int F);

@@ -706,3 +706,62 @@ def validation_loss(params: ConformerParams, mix: np.ndarray, gt_spk0: np.ndarra
         perms.append(perm)
     spk_loss, noise_loss = np.array(spk_loss), np.array(noise_loss)
     return float(np.mean(spk_loss + noise_weight * noise_loss)), spk_loss, noise_loss, perms
+
+
+# ----------------------------------------------------------------------------------------------
+# downstream hand-off: active regions + Whisper's log-mel front end.
+# whisper (openai-whisper, requirements.txt of the reference; asr/asr.py:58,73-74 calls it) is NOT under the reference
+# tree and not installed here: its published algorithm (whisper/audio.py log_mel_spectrogram; mel bank =
+# librosa.filters.mel(sr=16000, n_fft=400, n_mels), slaney scale / normalisation) is restated.  PARITY UNPINNED.
+# ----------------------------------------------------------------------------------------------
+def active_regions(act_final: np.ndarray, pad_frames: int, n_out: int, frame_hop: int = 256, frame_len: int = 512):
+    """act_final [T_long] bool (css.py:303-312) -> [n, 2] sample ranges: maximal runs of active frames, widened by
+    pad_frames on both sides, overlapping / touching runs merged; frame t spans samples [t hop, t hop + frame_len)."""
+    t, tl, out = 0, len(act_final), []
+    while t < tl:
+        if not act_final[t]:
+            t += 1
+            continue
+        e = t
+        while e < tl and act_final[e]:
+            e += 1
+        a = max(t - pad_frames, 0) * frame_hop
+        b = min((e - 1 + pad_frames) * frame_hop + frame_len, n_out)
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+        t = e
+    return np.array(out, dtype=np.int64).reshape(-1, 2)
+
+
+def _slaney_mel_bank(n_mels: int, sr: int = 16000, n_fft: int = 400) -> np.ndarray:
+    f_sp, min_log_hz, logstep = 200.0 / 3.0, 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    hz2mel = lambda f: np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+    mel2hz = lambda m: np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+    mel_f = mel2hz(np.linspace(hz2mel(np.float64(0.0)), hz2mel(np.float64(sr / 2)), n_mels + 2))
+    fft_f = np.linspace(0, sr / 2, 1 + n_fft // 2)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    w = np.maximum(0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def whisper_log_mel(audio: np.ndarray, n_mels: int = 80) -> np.ndarray:
+    """whisper/audio.py log_mel_spectrogram(audio, n_mels) without its 30 s padding: [n_mels, len(audio) // 160]."""
+    audio = np.asarray(audio, dtype=np.float32)
+    n = len(audio)
+    if n // 160 == 0:
+        return np.zeros((n_mels, 0), np.float32)
+    pad = np.pad(audio, 200, mode="reflect")
+    nfr = 1 + n // 160
+    win = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(400) / 400)).astype(np.float32)     # torch.hann_window(400)
+    frames = np.lib.stride_tricks.sliding_window_view(pad, 400)[::160][:nfr] * win
+    spec = np.fft.rfft(frames.astype(np.float64), axis=1)[:-1]                             # stft[..., :-1]
+    power = (np.abs(spec) ** 2).astype(np.float32).T                                       # [201, frames]
+    mel = _slaney_mel_bank(n_mels) @ power
+    log_spec = np.log10(np.maximum(mel, 1e-10))
+    log_spec = np.maximum(log_spec, log_spec.max() - 8.0)
+    return ((log_spec + 4.0) / 4.0).astype(np.float32)

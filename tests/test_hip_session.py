@@ -201,3 +201,51 @@ def test_pcm16_wav_edges_on_device_are_bit_exact(tmp_path, tiny_models):
     wavio.write_pcm16_samples(tmp_path / "s.wav", pcm16[0], 16000)
     back = wavio.read_wav_pcm16(tmp_path / "s.wav")
     assert back[1] == 16000 and np.array_equal(back[0], pcm16[0])
+
+
+def test_device_handoff_to_whisper_front_end(tiny_models):
+    """SURVEY.md 8f N4 (css.py:313 "drop silent parts to save ASR compute"): after a device-resident pass, each
+    stream's active regions -- the time map -- and Whisper's log-mel features of their concatenation, computed on the
+    GPU, against the oracle's restatement of whisper/audio.py on the same samples (parity unpinned: whisper is not
+    under the reference tree)."""
+    import torch
+    css, sep_mod, L = pkg("css"), pkg("separator"), pkg("_lib")
+    _, models = tiny_models
+    st, desc = models["mc"]
+    mix = pkg("synth").synth_meeting(20.0, 7, seed=12)
+    sep = sep_mod.HipSeparator(st, None, device=0)
+    try:
+        h = sep.handle
+        # a threshold inside the range of this model's activity values, so that the gate really toggles
+        probe_cfg = css.make_run_cfg(css.CssCfg(activity_th=0.0, show_progressbar=False), 16000, 7)
+        n = mix.shape[1]
+        plan = L.plan(desc, probe_cfg, n)
+        pcm = torch.from_numpy(np.ascontiguousarray(mix[0])).cuda()
+        wav = torch.empty((3, int(plan.n_out)), dtype=torch.float32, device="cuda")
+        h.run_device(pcm.data_ptr(), n, 7, probe_cfg, wav.data_ptr(), int(plan.n_out))
+        act = h.read(L.BUF_ACTIVITY)
+        th = float(np.median(act))
+        run_cfg = css.make_run_cfg(css.CssCfg(activity_th=th, show_progressbar=False), 16000, 7)
+        h.run_device(pcm.data_ptr(), n, 7, run_cfg, wav.data_ptr(), int(plan.n_out))
+        torch.cuda.synchronize()
+        act_f = h.read(L.BUF_ACT_FINAL).astype(bool)            # [S, T_long]
+        host = wav.cpu().numpy()
+        assert 0.05 < act_f.mean() < 0.95
+        for k in range(3):
+            for n_mels, pad in ((80, 8), (128, 0)):
+                mel, regions = h.handoff_logmel(wav.data_ptr(), int(plan.n_out), k, n_mels=n_mels, pad_frames=pad)
+                want = O.active_regions(act_f[k], pad, int(plan.n_out))
+                assert np.array_equal(regions, want) and len(regions) >= 1
+                assert (regions[1:, 0] > regions[:-1, 1]).all() and regions[-1, 1] <= plan.n_out
+                cut = np.concatenate([host[k, a:b] for a, b in regions])
+                ref = O.whisper_log_mel(cut, n_mels)
+                assert mel.shape == ref.shape == (n_mels, len(cut) // 160)
+                assert np.abs(mel - ref).max() < 2e-3 and np.sqrt(np.mean((mel - ref) ** 2)) < 2e-4, (k, n_mels)
+            full, whole = h.handoff_logmel(wav.data_ptr(), int(plan.n_out), k, drop_silence=False)
+            assert whole.tolist() == [[0, int(plan.n_out)]] and full.shape == (80, int(plan.n_out) // 160)
+            assert np.abs(full - O.whisper_log_mel(host[k], 80)).max() < 2e-3
+            assert full.shape[1] > mel.shape[1] * 0 + 1          # (the gated version is shorter whenever the gate is off somewhere)
+        with pytest.raises(L.CssError):
+            h.handoff_logmel(wav.data_ptr(), int(plan.n_out), 3)
+    finally:
+        sep.close()
