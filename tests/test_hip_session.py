@@ -224,8 +224,9 @@ def test_device_handoff_to_whisper_front_end(tiny_models):
         wav = torch.empty((3, int(plan.n_out)), dtype=torch.float32, device="cuda")
         h.run_device(pcm.data_ptr(), n, 7, probe_cfg, wav.data_ptr(), int(plan.n_out))
         act = h.read(L.BUF_ACTIVITY)
-        th = float(np.median(act))
-        run_cfg = css.make_run_cfg(css.CssCfg(activity_th=th, show_progressbar=False), 16000, 7)
+        th = float(np.percentile(act, 70))
+        run_cfg = css.make_run_cfg(css.CssCfg(activity_th=th, show_progressbar=False, activity_dilation_sec=0.05,
+                                              activity_erosion_sec=0.02), 16000, 7)
         h.run_device(pcm.data_ptr(), n, 7, run_cfg, wav.data_ptr(), int(plan.n_out))
         torch.cuda.synchronize()
         act_f = h.read(L.BUF_ACT_FINAL).astype(bool)            # [S, T_long]
