@@ -383,11 +383,14 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
     if (taps != 33 || (D != 256 && D != 512)) return false;
     const int runs = (T + RUN - 1) / RUN;
     const size_t lds = (size_t)(RUN + 32) * D * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    // The LDS reservation is a per-device function attribute: set (a table lookup on the host) on the launch's own device
+    // every time, not behind a process-wide flag that a second GPU or a second thread's first launch would miss; if the
+    // device refuses, the caller falls back to the two-kernel form.
+    const void* fn = D == 512 ? reinterpret_cast<const void*>(&conv_module_kernel<2, 33, RUN, 2>)
+                              : reinterpret_cast<const void*>(&conv_module_kernel<1, 33, RUN, 2>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
     }
     if (D == 512)
         hipLaunchKernelGGL((conv_module_kernel<2, 33, RUN, 2>), dim3(nseg * runs), dim3(1024), lds, s, x_in, x_out, ln_w, ln_b, pw, dw_wt,
