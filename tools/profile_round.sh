@@ -1,17 +1,26 @@
 #!/bin/bash
 # Collects everything profiles/ holds for one round (run on the GPU box through gpurun):
-#   bash tools/profile_round.sh r01
+#   bash tools/profile_round.sh r02
 # -> gpurun_out/<tag>_* ; copy the summaries into profiles/ afterwards.
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python bench.py --steps 20 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o p -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
-python tools/summarize_prof.py gpurun_out/${tag}_prof/p_kernel_trace.csv > gpurun_out/${tag}_kernel_stats.md
-cp gpurun_out/${tag}_prof/p_kernel_stats.csv gpurun_out/${tag}_rocprofv3_kernel_stats.csv
+o=gpurun_out
+python bench.py --steps 20 --warmup 3 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof -o p -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-long > $o/${tag}_bench_under_rocprof.json 2>/dev/null
+python tools/summarize_prof.py $o/${tag}_prof/p_kernel_trace.csv > $o/${tag}_kernel_stats.md
+cp $o/${tag}_prof/p_kernel_stats.csv $o/${tag}_rocprofv3_kernel_stats.csv
 # PMC: separate passes, --kernel-trace only (FETCH_SIZE and WRITE_SIZE cannot share a pass)
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/${tag}_pmc1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc2 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc3 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-CSS_TRAFFIC_JSON=gpurun_out/${tag}_gemm_traffic.json python tools/summarize_pmc.py gpurun_out/${tag}_pmc1 gpurun_out/${tag}_pmc2 gpurun_out/${tag}_pmc3 > gpurun_out/${tag}_pmc.md
-python tools/parity_margins.py > gpurun_out/${tag}_parity_margins.txt 2>/dev/null
-head -c 1500 gpurun_out/${tag}_bench.json; echo; head -30 gpurun_out/${tag}_pmc.md
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $o/${tag}_pmc1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-long > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/${tag}_pmc2 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-long > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/${tag}_pmc3 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-long > /dev/null 2>&1
+CSS_TRAFFIC_JSON=$o/${tag}_gemm_traffic.json python tools/summarize_pmc.py $o/${tag}_pmc1 $o/${tag}_pmc2 $o/${tag}_pmc3 > $o/${tag}_pmc.md
+python tools/parity_margins.py > $o/${tag}_parity_margins.txt 2>/dev/null
+python tools/shard_overhead_probe.py 60 > $o/${tag}_shard_overhead.md 2>/dev/null
+python tools/shard_overhead_probe.py 1800 >> $o/${tag}_shard_overhead.md 2>/dev/null
+# the N > 1 code path as separate processes on this one GPU (RCCL refuses two ranks per device: gloo carries the pieces)
+for w in 2 8; do
+  CSS_BENCH_ONE_DEVICE=1 CSS_BENCH_BACKEND=gloo CSS_BENCH_CHECK=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $w \
+    --master-addr 127.0.0.1 --master-port $((29600 + w)) bench.py --gpus $w --steps 2 --warmup 1 > $o/${tag}_multiprocess_w$w.log 2>&1
+done
+rm -rf $o/${tag}_prof $o/${tag}_pmc1/*/*.db 2>/dev/null
+head -c 1200 $o/${tag}_bench.json; echo; head -20 $o/${tag}_pmc.md; cat $o/${tag}_shard_overhead.md; tail -3 $o/${tag}_multiprocess_w2.log; tail -3 $o/${tag}_multiprocess_w8.log
