@@ -243,6 +243,8 @@ def main():
         dist.barrier()
         if rank == 0:
             print(json.dumps(result), flush=True)
+        del out, out_dev
+        be.close()
         sep.close()
         dist.destroy_process_group()
         return

@@ -121,6 +121,14 @@ class HipShardBackend:
     def on_stream(self):
         return self.torch.cuda.stream(self.stream)
 
+    def close(self):
+        """Release the work tensors BEFORE the handle is destroyed: they were allocated while the handle's stream was
+        current, and torch's allocator would otherwise touch that stream after css_destroy has destroyed it."""
+        self._scratch.clear()
+        self._keep = None
+        self.torch.cuda.synchronize(self.dev)
+        self.torch.cuda.empty_cache()
+
     def begin(self, pcm, n, c, run_cfg, sample_range=None, slice_only=False):
         """pcm: a device tensor [n, c] (resident input), or a float32 numpy array in host memory, of which only
         `sample_range` (default: everything) is uploaded; slice_only: the array holds just that range."""

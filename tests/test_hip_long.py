@@ -155,6 +155,8 @@ def _two_rank_worker(rank, world, port, seconds, out_dir):
             got = out.cpu().numpy()
         ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
         np.save(os.path.join(out_dir, f"same_{rank}.npy"), np.array([np.array_equal(ref, got)]))
+        del out
+        be.close()
         sep.close()
     finally:
         dist.destroy_process_group()

@@ -95,6 +95,8 @@ def virtual_rank_run(PAR, L, h, pcm, run_cfg, world, poison=False):
     with be.on_stream():
         out = ss.join_shards(torch.stack(pieces[2])) if world > 1 else pieces[2][0][:, :ss.n_out]
         out = out.cpu()
+    pieces.clear()
+    be.close()
     return out.numpy()
 
 

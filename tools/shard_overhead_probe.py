@@ -65,4 +65,6 @@ print(f"\n## device work of the exchanges' unpack steps, 8-rank plan (us per ste
 print(f"- PIT costs  [{world} x {ss.max_b + 1} x 9] f64 -> costs buffer: {ev[0].elapsed_time(ev[1]) * 100:.1f} us")
 print(f"- activity   [{world} x 3 x {ss.max_t}] u8 -> activity bits:   {ev[1].elapsed_time(ev[2]) * 100:.1f} us")
 print(f"- waveforms  [{world} x 3 x {ss.max_len}] f32 -> [3 x {ss.n_out}]:  {ev[2].elapsed_time(ev[3]) * 100:.1f} us")
+del out, c, a, s, costs, acts, shards
+be.close()
 sep.close()
