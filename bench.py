@@ -181,9 +181,12 @@ def main():
         plan = L.plan(desc, run_cfg, n)
         nseg = int(plan.num_segments)
         per_rank = -(-nseg // world) + 1
-        sep = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=max(args.max_batch, per_rank))
+        # the handle works on a stream torch owns: collectives, packing copies and the kernels are ordered on it
+        ts = torch.cuda.Stream(device=dev)
+        sep = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=max(args.max_batch, per_rank),
+                               stream=int(ts.cuda_stream))
         h = sep.handle
-        be = PAR.HipShardBackend(h, dev, comm_dev)
+        be = PAR.HipShardBackend(h, dev, comm_dev, torch_stream=ts)
         me = PAR.make_shard_plan(nseg, int(plan.mix_frames), int(plan.stft_frames), T, hop, desc.frame_hop, rank, world)
         s_lo, s_hi = me.pcm_range(desc.frame_len, n)
         # this rank's samples and its range of the result, in page-locked host memory

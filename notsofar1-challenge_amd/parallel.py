@@ -106,15 +106,23 @@ class HipShardBackend:
     """Stage calls of one rank on its GPU (the C ABI's css_stage_* entry points), plus torch views of the two device
     buffers the exchanges read and write.  Everything is enqueued on the handle's own HIP stream."""
 
-    def __init__(self, handle, torch_device, comm_device=None):
+    def __init__(self, handle, torch_device, comm_device=None, torch_stream=None):
         """`comm_device`: where the process group exchanges tensors -- the GPU itself for "nccl" (RCCL over
-        xGMI, the default), torch.device("cpu") for "gloo" (functional testing of the multi-process path)."""
+        xGMI, the default), torch.device("cpu") for "gloo" (functional testing of the multi-process path).
+        `torch_stream`: the torch.cuda.Stream the handle was created on (css_create's `stream` argument) -- the
+        preferred arrangement for long-lived processes: torch owns the stream, so its caching allocators (device and
+        page-locked host memory remember the streams they were used on) never outlive it.  Default: the handle's own
+        stream, wrapped; then call close() before the handle is destroyed."""
         import torch
         self.h = handle
         self.dev = torch_device
         self.comm_dev = comm_device if comm_device is not None else torch_device
         self.torch = torch
-        self.stream = torch.cuda.ExternalStream(handle.stream_ptr(), device=torch_device)
+        if torch_stream is not None:
+            assert int(torch_stream.cuda_stream) == handle.stream_ptr(), "the handle was not created on this stream"
+            self.stream = torch_stream
+        else:
+            self.stream = torch.cuda.ExternalStream(handle.stream_ptr(), device=torch_device)
         self._scratch = {}
         self._keep = None
 
