@@ -189,11 +189,11 @@ class HipShardBackend:
             t = self._scratch[key] = self.torch.empty(tuple(shape), dtype=dtype, device=self.dev)
         return t
 
-    def index_tensor(self, name, values: np.ndarray):
-        key = (name, values.shape, hash(values.tobytes()))
+    def index_tensor(self, key, make):
+        """index maps of the joins: built (on the host, by `make()`) and uploaded once per session shape"""
         t = self._scratch.get(key)
         if t is None:
-            t = self._scratch[key] = self.torch.from_numpy(values).to(self.dev)
+            t = self._scratch[key] = self.torch.from_numpy(make()).to(self.dev)
         return t
 
 
@@ -222,10 +222,12 @@ class ShardedSession:
 
     def _gather_index(self, name, lo_hi, width, total):
         """position of element e (owned by the rank whose [lo, hi) holds it) inside the gathered [world, width] pieces"""
-        idx = np.zeros(total, dtype=np.int64)
-        for r, (lo, hi) in enumerate(lo_hi):
-            idx[lo:hi] = r * width + np.arange(hi - lo)
-        return self.be.index_tensor(name, idx)
+        def make():
+            idx = np.zeros(total, dtype=np.int64)
+            for r, (lo, hi) in enumerate(lo_hi):
+                idx[lo:hi] = r * width + np.arange(hi - lo)
+            return idx
+        return self.be.index_tensor((name, self.world, self.nseg, self.TL, width, total), make)
 
     # phase 1: everything per segment, then the raw PIT costs of the owned boundaries
     def segments_and_costs(self):

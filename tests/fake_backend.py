@@ -105,8 +105,8 @@ class OracleStageBackend:
             self._scratch[key] = torch.zeros(tuple(shape), dtype=dtype)
         return self._scratch[key]
 
-    def index_tensor(self, name, values):
-        return torch.from_numpy(values)
+    def index_tensor(self, key, make):
+        return torch.from_numpy(make())
 
     def pit_scan(self):
         import itertools
