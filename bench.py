@@ -314,35 +314,6 @@ def main():
     result["pcm16_edges"] = rec(timed(lambda: h.run_pcm16(planes, run_cfg), steps=5, warmup=1),
                                 "css_run_pcm16: 7 int16 planes in host memory -> 3 peak-normalised PCM16 streams in host memory")
 
-    # ---- throughput with two meetings in flight (two handles of the same model, one host thread each): the PCIe legs
-    # and the latency-bound tail of one pass run beside the mask estimator of the other.  Not the headline -- a pass
-    # of `value` starts when the previous one has delivered -- but what a session loop over many recordings gets.
-    import threading
-    sep2 = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=args.max_batch)
-    h2 = sep2.handle
-    pcm_pin2, out_pin2 = L.pinned_copy(pcm_pin), L.pinned_empty((S, int(plan.n_out)), np.float32)
-    per_thread = max(args.steps // 2, 2)
-
-    def worker(hh, pp, oo, count):
-        for _ in range(count):
-            hh.run(pp, run_cfg, out=oo)
-
-    for hh, pp, oo in ((h, pcm_pin, out_pin), (h2, pcm_pin2, out_pin2)):
-        worker(hh, pp, oo, 2)
-    th = [threading.Thread(target=worker, args=a) for a in ((h, pcm_pin, out_pin, per_thread), (h2, pcm_pin2, out_pin2, per_thread))]
-    t0 = time.perf_counter()
-    for t_ in th:
-        t_.start()
-    for t_ in th:
-        t_.join()
-    h.sync(); h2.sync()
-    ms2 = 1e3 * (time.perf_counter() - t0) / (2 * per_thread)
-    result["two_in_flight"] = {**rec(ms2, "two handles, two host threads, css_run host -> host: wall time per meeting"),
-                               "vs_device_resident": round(ms2 / ms_dev, 4)}
-    assert np.array_equal(out_pin, out_pin2)
-    sep2.close()
-    del pcm_pin2, out_pin2
-
     # ---- roofline of the dominant kernel (the Linear-layer GEMM): live HIP-event timing of every launch, one lane
     def profiled_pass():
         h.set_profile(True)
