@@ -285,7 +285,7 @@ def main():
     })
     stage = h.timings()
     result["stage_ms"] = {k: round(v, 3) for k, v in stage.items()
-                          if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total")}
+                          if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total", "host_enqueue", "host_total")}
 
     # ---- the same pass with input and output resident in HBM (what the PCIe legs cost), and from pageable memory
     pcm_dev = torch.from_numpy(np.ascontiguousarray(mix[0])).to(dev)

@@ -110,6 +110,8 @@ typedef struct CssTimings {
     float gemm_ms;          /* sum of the durations of the MFMA GEMM launches inside masknet          */
     int64_t gemm_launches;
     double gemm_flops;      /* algorithmic FLOPs of those launches (2*M*N*K each)                     */
+    float host_enqueue;     /* host wall time from the call to the last enqueue (before the final wait), ms */
+    float host_total;       /* host wall time of the whole call, ms                                         */
 } CssTimings;
 
 /* Identifiers of device buffers readable / writable through css_read_buffer / css_write_buffer

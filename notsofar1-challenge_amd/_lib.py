@@ -65,7 +65,7 @@ class CssKernelStat(C.Structure):
 class CssTimings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("upload", "stft", "features", "masknet", "mvdr", "stitch", "istft",
                                           "download", "total", "gemm_ms")] + \
-               [("gemm_launches", C.c_int64), ("gemm_flops", C.c_double)]
+               [("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("host_enqueue", C.c_float), ("host_total", C.c_float)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/css_mi355.h declares

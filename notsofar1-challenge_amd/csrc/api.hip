@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <functional>
 #include <string>
 #include <vector>
@@ -1079,6 +1080,7 @@ static hipEvent_t pool_event(css_ctx* h) {
 static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
     if (!h) return CSS_ERR_INVALID_ARG;
+    const auto host_t0 = std::chrono::steady_clock::now();
     if ((rc = begin_impl(h, n, n_ch, cfg)) != CSS_OK) return rc;
     const CssPlan& pl = h->plan;
     if (io.cap < pl.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(pl.n_out) + " samples per stream");
@@ -1299,10 +1301,14 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     if (out_done) HIPCHK(h, hipStreamWaitEvent(h->stream, out_done, 0));
     hipEventRecord(h->ev[7], h->stream);
+    const auto host_t1 = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    const auto host_t2 = std::chrono::steady_clock::now();
     auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
     CssTimings& t = h->tim;
+    t.host_enqueue = std::chrono::duration<float, std::milli>(host_t1 - host_t0).count();
+    t.host_total = std::chrono::duration<float, std::milli>(host_t2 - host_t0).count();
     // (the stages overlap: masknet = begin of the first chain .. end of the last, stitch / istft = the LAST unit's tail)
     t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = 0.f; t.stitch = ms(4, 5);
     t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.CssModelDesc) == 13 * 4
     assert C.sizeof(L.CssRunCfg) == 8 * 4 + 2 * 4 + 3 * 8
     assert C.sizeof(L.CssPlan) == 5 * 8 + 2 * 4
-    assert C.sizeof(L.CssTimings) == 10 * 4 + 8 + 8
+    assert C.sizeof(L.CssTimings) == 10 * 4 + 8 + 8 + 2 * 4
 
 
 def test_blob_size_agrees_with_packer(L):
