@@ -3,9 +3,9 @@
 // The reference evaluates the transform as a convolution with a DFT kernel (a direct O(N^2) sum); round 1 mirrored
 // that as a GEMM on the float32 matrix cores (13.8 GFLOP per minute of 7-channel audio, 180 us).  The transform is
 // memory-sized work -- 27 MB of samples in, 54 MB of planes out per minute -- so it is done here the cheap way:
-// a block owns 32 consecutive frames of one channel, reads their samples as contiguous runs (window applied on the
-// way in), packs each real frame into 256 complex points, runs four radix-4 Stockham stages over all 32 frames in LDS,
-// separates the real spectrum (bins 0 .. 256) and writes it transposed -- time fastest, 128-byte runs -- into the
+// a block owns 16 consecutive frames of one channel, reads their samples as contiguous runs (window applied on the
+// way in), packs each real frame into 256 complex points, runs four radix-4 Stockham stages over all 16 frames in LDS,
+// separates the real spectrum (bins 0 .. 256) and writes it transposed -- time fastest, 64-byte runs -- into the
 // planes X[c][Re f | Im f][t] every later stage reads.  The rounding is that of an FFT (~log2 N ulps against ~sqrt N for
 // the direct sum; both ~1e-7 relative to the frame's largest bin, tests/test_hip_parity.py holds the planes to 1e-6
 // against the oracle and 2e-6 against the reference).  The imaginary parts of the DC and Nyquist bins are exact zeros
@@ -19,9 +19,10 @@ namespace css {
 
 constexpr int FFT_N = 512;            // frame length
 constexpr int FFT_H = 256;            // packed complex length = hop
-constexpr int FFT_TB = 32;            // frames per block
-constexpr int FFT_FS = FFT_H + 1;     // frame stride in LDS (complex elements): odd, so 32 frames hit 32 distinct bank pairs
-constexpr int FFT_THREADS = 512;
+constexpr int FFT_TB = 16;            // frames per block: 66 KB of LDS, two blocks per CU cover each other's load / store phases
+                                      // (32 frames: 128-byte store runs, but one block per CU -- 67 us against 58 us per minute of audio)
+constexpr int FFT_FS = FFT_H + 1;     // frame stride in LDS (complex elements): odd, so the frames of a store pass hit distinct bank pairs
+constexpr int FFT_THREADS = 256;
 
 // tables: window[512] | tw256[256] (cos, -sin of 2 pi m / 256) | tw512[257] (cos, -sin of 2 pi k / 512)
 size_t stft_table_floats() { return FFT_N + 2 * FFT_H + 2 * (FFT_H + 1); }
@@ -103,9 +104,10 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
     //   E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / (2i),  X[k] = E + e^{-2 pi i k / 512} O
     const int F = FFT_H + 1;
     const int tl = tid & (FFT_TB - 1);
+    static_assert(FFT_TB == 16 || FFT_TB == 32, "store phase indexing");
     const bool store = t0 + tl < nf;
     float* oc = out + (int64_t)c * 2 * F * row_ld + t0 + tl;
-    for (int f = tid >> 5; f < F; f += FFT_THREADS / FFT_TB) {
+    for (int f = tid / FFT_TB; f < F; f += FFT_THREADS / FFT_TB) {
         const float2 z0 = src[tl * FFT_FS + (f & 255)];
         const float2 z1 = src[tl * FFT_FS + ((256 - f) & 255)];
         float re, im;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
 bool launch_stft_fft(const float* x, int64_t x_stride, int C, int nf, const float* tables, float* out, int64_t row_ld,
                      hipStream_t s) {
     if (nf <= 0 || C <= 0) return true;
-    const size_t lds = (size_t)2 * FFT_TB * FFT_FS * sizeof(float2);   // 131.6 KB
+    const size_t lds = (size_t)2 * FFT_TB * FFT_FS * sizeof(float2);   // 65.8 KB
     // (the attribute is per device: set it on every launch -- a host-side table lookup -- rather than behind a
     // process-wide flag that a second device, or a second thread's first launch, would miss)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
