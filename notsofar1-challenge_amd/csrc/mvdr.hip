@@ -36,7 +36,8 @@ __device__ __forceinline__ int valid_frames(int64_t stft_frames, int64_t seg, in
 // winner into four lists (wave ballots), the 16 lanes of group k walk list k -- every lane busy on every step, a third
 // of the float64 work of the mask-major loop -- and keep two accumulator sets, the weighted sum and the plain sum; the
 // plain sums of the four groups add up to sum_t P_t (a frame with tied winners is in each of their lists, but counts
-// towards the plain sum only in the first one).  The 16 partial sums are combined with four DPP steps (row16_sum).
+// towards the plain sum only in the first one).  The 16 lanes' partial sums are combined by a four-step DPP
+// reduce-scatter and leave through LDS as 49 consecutive doubles per mask.
 // ------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
@@ -44,6 +45,13 @@ __device__ __forceinline__ double dpp_add(double v) {
     const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
     const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return v + __hiloint2double(hi2, lo2);
+}
+// the partner lane's value under DPP control CTRL
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false));
 }
 // sum over the 16 lanes of a DPP row; every lane ends up with the total
 __device__ __forceinline__ double row16_sum(double v) {
@@ -67,11 +75,11 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     if (f >= F) return;   // (whole waves; no block-wide barrier below)
     const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
     const int64_t st = seg * (int64_t)a.hop;
-    // wave-private tile: x[14][T] (rows c: Re, 7 + c: Im), m[4][T], then the four frame lists (uint16) and 4 x 49 doubles
-    float* xs = scm_lds + (size_t)wave * ((14 + 4) * T + 2 * T + 4 * NPACK * 2);
+    // wave-private tile: x[14][T] (rows c: Re, 7 + c: Im), m[4][T], then the four frame lists (uint16) and 4 x 98 doubles
+    float* xs = scm_lds + (size_t)wave * ((14 + 4) * T + 2 * T + 4 * 2 * NPACK * 2);
     float* ms = xs + 14 * T;
     unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * T);    // [4][T]
-    double* plain = reinterpret_cast<double*>(ms + 4 * T + 2 * T);            // [4][NPACK] (8-byte aligned: T is even or padded below)
+    double* tot = reinterpret_cast<double*>(ms + 4 * T + 2 * T);              // [4][2 * NPACK] group totals (8-byte aligned)
     // ---- the bin's rows, contiguous along time: every load of the 18 rows is in flight before the first LDS store
     // (row by row, a wave waited out 18 memory round trips; T <= 256 = 4 x 64 lanes)
     {
@@ -97,6 +105,10 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#if defined(SCM_ABL) && SCM_ABL == 3   /* tools: the load phase alone */
+    if (xs[lane] == 12345.f) a.scm[0] = 1.0;
+    return;
+#endif
     // ---- frames by winner: list j holds the frames mask j wins (bit 15: the frame's first winner)
     const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
     int cnt[4] = {0, 0, 0, 0};
@@ -128,7 +140,11 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     double acc[NPACK], pl[NPACK];
 #pragma unroll
     for (int i = 0; i < NPACK; ++i) { acc[i] = 0.0; pl[i] = 0.0; }
+#if defined(SCM_ABL) && SCM_ABL == 1   /* tools/scm_bench.hip: no group loop (loads + lists + reductions only) */
+    const int nk = 0;
+#else
     const int nk = k == 0 ? cnt[0] : (k == 1 ? cnt[1] : (k == 2 ? cnt[2] : cnt[3]));
+#endif
     for (int i = l16; i < nk; i += 16) {
         const unsigned e = lists[k * T + i];
         const int t = e & 0x7fff;
@@ -156,29 +172,80 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
             }
         }
     }
-    // ---- reduce over the group's 16 lanes; the plain sums of the four groups meet in LDS
+#if defined(SCM_ABL) && SCM_ABL == 2   /* tools: no reductions / output */
+    if (acc[3] == 12345.0) a.scm[0] = pl[5];
+    return;
+#endif
+    // ---- reduce-scatter over the group's 16 lanes: four DPP exchanges, each halving the number of values a lane keeps
+    // (summing all 98 values into all 16 lanes cost 4 x 98 exchanges and 16 copies of every total; this costs
+    // 49 + 25 + 13 + 7 and leaves each total in one lane).  A lane keeps the lower or upper half of its values by one bit
+    // of its position; its partner keeps the other half and sends the half this lane keeps.
+    // value list: acc[0..48] then pl[0..48]; after the steps lane l holds the totals of original indices
+    //   j + 49 b0 + 25 b1 + 13 b2 + 7 b3,  j = 0..6,  b0 = l16 >= 8, b1 = (l16 & 7) >= 4, b2 = bit 1, b3 = bit 0
+    double v1[49], v2[25], v3[13], v4[7];
+    {
+        const bool up = l16 >= 8;            // partner: 15 - l16 (row_mirror)
 #pragma unroll
-    for (int i = 0; i < NPACK; ++i) {
-        acc[i] = row16_sum(acc[i]);
-        const double v = row16_sum(pl[i]);
-        if (l16 == (i & 15)) plain[k * NPACK + i] = v;
+        for (int j = 0; j < 49; ++j) {
+            const double keep = up ? pl[j] : acc[j], send = up ? acc[j] : pl[j];
+            v1[j] = keep + dpp_get<0x140>(send);
+        }
+    }
+    {
+        const bool up = (l16 & 7) >= 4;      // partner: 7 - (l16 & 7) inside the half row (row_half_mirror)
+#pragma unroll
+        for (int j = 0; j < 25; ++j) {
+            const double lo = v1[j], hi = j + 25 < 49 ? v1[j + 25] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            v2[j] = keep + dpp_get<0x141>(send);
+        }
+    }
+    {
+        const bool up = (l16 & 2) != 0;      // partner: l16 ^ 2 (quad_perm [2,3,0,1])
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const double lo = v2[j], hi = j + 13 < 25 ? v2[j + 13] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            v3[j] = keep + dpp_get<0x4E>(send);
+        }
+    }
+    {
+        const bool up = (l16 & 1) != 0;      // partner: l16 ^ 1 (quad_perm [1,0,3,2])
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const double lo = v3[j], hi = j + 7 < 13 ? v3[j + 7] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            v4[j] = keep + dpp_get<0xB1>(send);
+        }
+    }
+    // the totals meet in LDS: tot[k][0..48] weighted sums, tot[k][49..97] plain sums
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int base = (l16 >= 8 ? 49 : 0);
+        const int o1 = ((l16 & 7) >= 4 ? 25 : 0), o2 = ((l16 & 2) ? 13 : 0), o3 = ((l16 & 1) ? 7 : 0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            // position inside the 49-value half after steps 2..4; slots past a half's end were padding (zero sums)
+            const int q3 = j + o3, q2 = q3 + o2, q1 = q2 + o1;
+            const bool real = q3 < 13 && q2 < 25 && q1 < 49;
+            if (real) tot[k * 98 + base + q1] = v4[j];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (k >= nm) return;
-    double* out = a.scm + ((seg * nm + k) * (int64_t)F + f) * NPACK;
-#pragma unroll
-    for (int i = 0; i < NPACK; ++i) {
-        if (l16 != (i & 15)) continue;   // the 49 results leave through all 16 lanes
-        double v = acc[i] + 1e-10 * ((plain[i] + plain[NPACK + i]) + (plain[2 * NPACK + i] + plain[3 * NPACK + i]));
+    // ---- Phi_k = weighted + 1e-10 * (sum of the four plain sums) (+ 1e-15 on the diagonal), 49 consecutive doubles per mask
+    for (int e = lane; e < nm * NPACK; e += 64) {
+        const int kk = e / NPACK, i = e - kk * NPACK;
+        double v = tot[kk * 98 + i] + 1e-10 * ((tot[49 + i] + tot[98 + 49 + i]) + (tot[2 * 98 + 49 + i] + tot[3 * 98 + 49 + i]));
         if (i < NC) v += 1e-15;  // Ri += 1e-15 * I   (mvdr_util.py:63-65)
-        out[i] = v;
+        a.scm[((seg * nm + kk) * (int64_t)F + f) * NPACK + i] = v;
     }
 }
 
 void launch_scm(const MvdrArgs& a, hipStream_t s) {
-    // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 49 doubles
-    const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * NPACK * 2) * sizeof(float);
+    // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 98 doubles
+    const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * 2 * NPACK * 2) * sizeof(float);
     hipLaunchKernelGGL(scm_kernel, dim3((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), dim3(64 * SCM_WAVES), per_wave * SCM_WAVES, s, a);
 }
 
