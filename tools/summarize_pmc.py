@@ -42,9 +42,9 @@ for k, r in m.iterrows():
 # HBM traffic per launch of the dominant kernel for bench.py's roofline.traffic (FETCH_SIZE doubled as the guide
 # prescribes for gfx950's wide reads, + WRITE_SIZE), launch-weighted over the Linear-layer GEMM instantiations
 import json, os
-# (the <128, 2> instantiation = the full-batch launches of bench.py's single-lane profile pass, which is what
-#  roofline.achieved is measured on; the two-lane half-batch launches run the <64, 1> instantiation)
-g = m[m.index.str.contains("gemm_split_wd_kernel<128, 2>", regex=False)]
+# (the full-batch launches of bench.py's single-lane profile pass, which is what roofline.achieved is measured on:
+#  117 row tiles x N / 128 column tiles = 468 / 936 / 1404 workgroups; the three-lane launches have a third of that)
+g = m[m.index.str.contains("gemm_split_wd_kernel", regex=False) & (m.index.str.extract(r"g=(\d+)", expand=False).astype(float) >= 400)]
 if len(g):
     wgt = g["n"]
     out = {"kernel": "css::gemm_split_wd_kernel", "launches": int(wgt.sum()),
