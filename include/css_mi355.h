@@ -179,7 +179,8 @@ enum css_tuning {
     CSS_TUNE_TAIL_PIECES = 0,   /* pieces the last frame range is synthesised and downloaded in (1..4, default 1)          */
     CSS_TUNE_OUT_MAPPED = 1,    /* 1 (default): the overlap-add kernel writes page-locked output over PCIe itself; 0: DMA  */
     CSS_TUNE_TAIL_PER_UNIT = 2, /* 1: stitch / synthesise after every lane's unit; 0 (default): once per batch             */
-    CSS_TUNE_COUNT = 3
+    CSS_TUNE_MVDR_ON_LANES = 3, /* 1 (default): covariances / MVDR / stitching costs at the end of each lane's chain; 0: after  */
+    CSS_TUNE_COUNT = 4
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,
@@ -283,6 +284,11 @@ int css_stage_stitch_gate(css_handle_t h, int64_t t_lo, int64_t t_hi);
  * last block hold one frame's contribution each; adding the overlapping blocks of adjacent shards
  * reproduces css_stage_istft bit for bit (a two-term float sum commutes). */
 int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld);
+/* Exchange 3 of a segment-sharded meeting (parallel.py): gathered_dev [world][S][shard_ld] holds every rank's
+ * css_stage_istft_partial shard (rank r: output blocks t_lo[r] .. t_hi[r]); out_dev [S][out_ld] receives the stitched
+ * streams -- a rank's inner blocks as they are, the block at a seam as the sum of its two neighbours' partial blocks. */
+int css_stage_join_shards(css_handle_t h, const float* gathered_dev, int32_t world, int64_t shard_ld, const int64_t* t_lo,
+                          const int64_t* t_hi, float* out_dev, int64_t out_ld);
 int css_sync(css_handle_t h);
 
 /* Separator-protocol helpers operating on caller data (host pointers):

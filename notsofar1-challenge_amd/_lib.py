@@ -112,6 +112,7 @@ SIGNATURES = {
     "css_stage_pit_scan": (C.c_int, [_P]),
     "css_stage_stitch": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_istft": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_join_shards": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int64]),
     "css_sync": (C.c_int, [_P]),
     "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -301,7 +302,7 @@ class Handle:
 
     def set_tuning(self, which, value: int):
         """which: "tail_pieces" | "out_mapped" | "tail_per_unit" (include/css_mi355.h css_tuning)"""
-        idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2}[which] if isinstance(which, str) else int(which)
+        idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2, "mvdr_on_lanes": 3}[which] if isinstance(which, str) else int(which)
         check(self.h, self.lib.css_set_tuning(self.h, idx, int(value)))
 
     def lanes(self) -> int:
@@ -434,6 +435,12 @@ class Handle:
 
     def stage_istft_partial(self, lo, hi, shard_ptr: int, shard_ld: int):
         check(self.h, self.lib.css_stage_istft_partial(self.h, lo, hi, C.c_void_p(shard_ptr), shard_ld))
+
+    def stage_join_shards(self, gathered_ptr: int, world: int, shard_ld: int, t_lo, t_hi, out_ptr: int, out_ld: int):
+        lo = np.ascontiguousarray(t_lo, dtype=np.int64)
+        hi = np.ascontiguousarray(t_hi, dtype=np.int64)
+        check(self.h, self.lib.css_stage_join_shards(self.h, C.c_void_p(gathered_ptr), int(world), int(shard_ld), _np_ptr(lo), _np_ptr(hi),
+                                                     C.c_void_p(out_ptr), int(out_ld)))
 
     def stage_masknet(self, lo, hi):
         check(self.h, self.lib.css_stage_masknet(self.h, lo, hi))

@@ -114,7 +114,7 @@ struct css_ctx {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 1, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 1, 0, 1};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -1032,6 +1032,22 @@ int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* s
     return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo, h->stream);
 }
 
+int css_stage_join_shards(css_handle_t h, const float* gathered_dev, int32_t world, int64_t shard_ld, const int64_t* t_lo,
+                          const int64_t* t_hi, float* out_dev, int64_t out_ld) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!gathered_dev || !t_lo || !t_hi || !out_dev || world < 1 || world > 64) return fail(h, CSS_ERR_INVALID_ARG, "bad argument (world <= 64)");
+    if (out_ld < h->plan.n_out) return fail(h, CSS_ERR_INVALID_ARG, "out_ld shorter than the streams");
+    const int hop = h->d.frame_hop;
+    for (int k = 0; k < world; ++k)
+        if (t_lo[k] < 0 || t_hi[k] < t_lo[k] || t_hi[k] > h->plan.mix_frames || (t_hi[k] - t_lo[k] + 1) * hop > shard_ld)
+            return fail(h, CSS_ERR_INVALID_ARG, "rank frame range out of bounds / shard_ld too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_join_shards(gathered_dev, shard_ld, t_lo, t_hi, world, h->d.num_spks, hop, h->plan.n_out, out_dev, out_ld, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
 int css_sync(css_handle_t h) {
     if (!h) return CSS_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1183,6 +1199,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         for (size_t k = k0; k < k1; ++k) HIPCHK(h, hipStreamWaitEvent(ts, units[k].m, 0));
         struct { int64_t seg_lo; int64_t n; } u{units[k0].seg_lo, units[k1 - 1].seg_lo + units[k1 - 1].n - units[k0].seg_lo};
         const int64_t b_lo = std::max<int64_t>(u.seg_lo - 1, 0), b_hi = u.seg_lo + u.n - 1;
+        if (!h->tune[CSS_TUNE_MVDR_ON_LANES]) {   // beamformer and costs here, after the lanes, instead of on them
+            mvdr_on(h, u.seg_lo, u.seg_lo + u.n, ts);
+            pit_costs_on(h, b_lo, b_hi, ts);
+        }
         // (the boundaries' costs were computed on the lanes, behind each unit's beamformer)
         pit_scan_on(h, b_lo, b_hi, ts);
         const int64_t t_hi = last ? TL : std::min<int64_t>((u.seg_lo + u.n) * hop, TL);   // no later segment covers these
@@ -1262,12 +1282,12 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         for (size_t k = first; k < ui; ++k)
             if (units[k].seg_lo == seg_lo && units[k].n == cnt) u = &units[k];
         if (!u) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
-        mvdr_on(h, seg_lo, seg_lo + cnt, st);
+        if (h->tune[CSS_TUNE_MVDR_ON_LANES]) mvdr_on(h, seg_lo, seg_lo + cnt, st);
         HIPCHK(h, hipEventRecord(u->v, st));
         // raw stitching costs of this unit's boundaries (losses.py:50-71); the first one joins the previous unit's last
         // segment, whose masks / separated spectra are final once that unit's beamformer is
         if (u != &units[0]) HIPCHK(h, hipStreamWaitEvent(st, (u - 1)->v, 0));
-        pit_costs_on(h, std::max<int64_t>(seg_lo - 1, 0), seg_lo + cnt - 1, st);
+        if (h->tune[CSS_TUNE_MVDR_ON_LANES]) pit_costs_on(h, std::max<int64_t>(seg_lo - 1, 0), seg_lo + cnt - 1, st);
         HIPCHK(h, hipEventRecord(u->m, st));
         return CSS_OK;
     };

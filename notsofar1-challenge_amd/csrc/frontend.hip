@@ -101,16 +101,24 @@ __global__ __launch_bounds__(256) void pcm_peak_kernel(const T* __restrict__ x, 
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak, __float_as_uint(m * scale));
+    // one atomic per BLOCK, and only when it can raise the peak: thousands of waves hitting one word cost ~11 ns each
+    // (8192 of them made this 10 MB scan take 97 us)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float b = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * scale;
+        if (b > __uint_as_float(__hip_atomic_load(peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(peak, __float_as_uint(b));
+    }
 }
 
 void launch_pcm_peak_f32(const float* x, int64_t count, unsigned int* peak, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(pcm_peak_kernel<float>, dim3((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, s, x, count, 1.0f, peak);
+    hipLaunchKernelGGL(pcm_peak_kernel<float>, dim3((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 512)), dim3(256), 0, s, x, count, 1.0f, peak);
 }
 void launch_pcm_peak_i16(const int16_t* x, int64_t count, unsigned int* peak, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256 + 1, 2048)), dim3(256), 0, s, x, count, 1.0f / 32768.0f, peak);
+    hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256 + 1, 512)), dim3(256), 0, s, x, count, 1.0f / 32768.0f, peak);
 }
 
 void launch_pcm16_to_channel_major(const int16_t* planes, float* pcm_cm, int64_t n, int C, int64_t n_pad, int64_t i_lo,
@@ -317,6 +325,40 @@ void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int ho
     if (total <= 0) return;
     const dim3 grid((unsigned)((total + 255) / 256), B), block(256);
     hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, level);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Waveform shards of a segment-sharded meeting -> the stitched streams (parallel.py exchange 3).  gathered [world][S][ld]:
+// rank r's shard holds output blocks t_lo[r] .. t_hi[r] (one hop each); the block at a seam is in both neighbours'
+// shards, one frame's contribution each, and is their sum (rank order: a two-term float sum commutes, so the result is
+// the single-GPU pass's bit for bit).  Ranks without frames have t_hi == t_lo and are skipped.
+// ------------------------------------------------------------------------------------------------
+struct JoinRanks { int64_t t_lo[64], t_hi[64]; int world; };
+__global__ void join_shards_kernel(const float* __restrict__ g, int64_t ld, JoinRanks rk, int S, int hop, int64_t n_out,
+                                   float* __restrict__ out, int64_t out_ld) {
+    const int64_t n4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int sp = blockIdx.y;
+    if (n4 >= n_out) return;
+    const int64_t q = n4 / hop;
+    const int r = (int)(n4 - q * hop);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < rk.world; ++k) {
+        if (rk.t_hi[k] <= rk.t_lo[k] || q < rk.t_lo[k] || q > rk.t_hi[k]) continue;
+        const float4 a = *reinterpret_cast<const float4*>(g + ((int64_t)k * S + sp) * ld + (q - rk.t_lo[k]) * hop + r);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    float* o = out + (int64_t)sp * out_ld + n4;
+    if (n4 + 4 <= n_out) *reinterpret_cast<float4*>(o) = v;
+    else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int i = 0; n4 + i < n_out; ++i) o[i] = e[i]; }
+}
+
+void launch_join_shards(const float* gathered, int64_t ld, const int64_t* t_lo, const int64_t* t_hi, int world, int S, int hop,
+                        int64_t n_out, float* out, int64_t out_ld, hipStream_t s) {
+    JoinRanks rk{};
+    rk.world = world;
+    for (int k = 0; k < world; ++k) { rk.t_lo[k] = t_lo[k]; rk.t_hi[k] = t_hi[k]; }
+    const int64_t groups = (n_out + 3) / 4;
+    hipLaunchKernelGGL(join_shards_kernel, dim3((unsigned)((groups + 255) / 256), S), dim3(256), 0, s, gathered, ld, rk, S, hop, n_out, out, out_ld);
 }
 
 // ------------------------------------------------------------------------------------------------

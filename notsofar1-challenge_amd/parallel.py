@@ -181,6 +181,12 @@ class HipShardBackend:
     def istft_partial(self, lo, hi, out):
         self.h.stage_istft_partial(lo, hi, out.data_ptr(), out.stride(0))
 
+    def join_shards(self, all_shards, plans, out):
+        """gathered [world, S, ld] -> out [S, n_out] in one launch (css_stage_join_shards)"""
+        assert all_shards.is_contiguous() and out.stride(1) == 1
+        self.h.stage_join_shards(all_shards.data_ptr(), len(plans), all_shards.shape[2], [p.t_lo for p in plans],
+                                 [p.t_hi for p in plans], out.data_ptr(), out.stride(0))
+
     def scratch(self, name, shape, dtype):
         """persistent work tensors (send / receive pieces, index maps): allocated once per shape"""
         key = (name, tuple(shape), dtype)
@@ -286,6 +292,9 @@ class ShardedSession:
         with self._ctx():
             if out is None:
                 out = torch.empty((self.S, self.n_out), dtype=all_shards.dtype, device=all_shards.device)
+            if hasattr(self.be, "join_shards"):      # the HIP backend: one kernel over the output
+                self.be.join_shards(all_shards, self.plans, out)
+                return out
             live = [p for p in self.plans if p.num_frames > 0]
             for k, p in enumerate(live):
                 sh = all_shards[p.rank]

@@ -18,18 +18,18 @@ sep = SEP.HipSeparator(state, None, device=0, max_batch_segments=128); h = sep.h
 plan = L.plan(desc, run_cfg, n)
 pcm = L.pinned_copy(np.ascontiguousarray(mix[0])); out = L.pinned_empty((3, int(plan.n_out)), np.float32)
 pd = torch.from_numpy(np.ascontiguousarray(mix[0])).cuda(); wd = torch.empty((3, int(plan.n_out)), device="cuda")
-def timed(fn, steps=20):
+def timed(fn, steps=20 if seconds <= 120 else 4):
     for _ in range(3): fn()
     h.sync(); t0 = time.perf_counter()
     for _ in range(steps): fn()
     h.sync(); return 1e3 * (time.perf_counter() - t0) / steps
-variants = [dict(lanes=l, tail_pieces=p, out_mapped=m, tail_per_unit=u)
-            for l, p, m, u in [(3, 1, 0, 0), (3, 2, 0, 0), (3, 4, 0, 0), (3, 2, 1, 0), (3, 1, 1, 0), (3, 1, 0, 1), (4, 2, 0, 0), (2, 2, 0, 0)]]
+variants = [dict(lanes=l, tail_pieces=p, out_mapped=m, tail_per_unit=u, mvdr_on_lanes=v)
+            for l, p, m, u, v in [(3, 1, 1, 0, 1), (3, 1, 1, 0, 0), (3, 1, 0, 0, 1), (3, 1, 0, 0, 0), (3, 2, 0, 0, 0), (3, 1, 1, 1, 1), (2, 1, 1, 0, 1), (4, 1, 1, 0, 1)]]
 res = {i: [] for i in range(len(variants))}; dev = {i: [] for i in range(len(variants))}
 for r in range(rounds):
     for i, v in enumerate(variants):
         h.set_lanes(v["lanes"])
-        for k in ("tail_pieces", "out_mapped", "tail_per_unit"): h.set_tuning(k, v[k])
+        for k in ("tail_pieces", "out_mapped", "tail_per_unit", "mvdr_on_lanes"): h.set_tuning(k, v[k])
         res[i].append(timed(lambda: h.run(pcm, run_cfg, out=out)))
         dev[i].append(timed(lambda: h.run_device(pd.data_ptr(), n, 7, run_cfg, wd.data_ptr(), int(plan.n_out))))
 print(f"| variant | host -> host ms (rounds) | device-resident ms | ratio |\n|---|---|---|---|")
