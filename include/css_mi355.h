@@ -177,7 +177,7 @@ int css_get_lanes(css_handle_t h);
  * measured best on the 60 s / 30 min meetings (tools/ab_tuning.py runs the alternatives on one box). */
 enum css_tuning {
     CSS_TUNE_TAIL_PIECES = 0,   /* pieces the last frame range is synthesised and downloaded in (1..4, default 1)          */
-    CSS_TUNE_OUT_MAPPED = 1,    /* 1 (default): the overlap-add kernel writes page-locked output over PCIe itself; 0: DMA  */
+    CSS_TUNE_OUT_MAPPED = 1,    /* 1: the overlap-add kernel writes page-locked output over PCIe itself; 0 (default): DMA  */
     CSS_TUNE_TAIL_PER_UNIT = 2, /* 1: stitch / synthesise after every lane's unit; 0 (default): once per batch             */
     CSS_TUNE_MVDR_ON_LANES = 3, /* 1 (default): covariances / MVDR / stitching costs at the end of each lane's chain; 0: after  */
     CSS_TUNE_COUNT = 4

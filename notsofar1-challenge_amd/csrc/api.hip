@@ -114,7 +114,7 @@ struct css_ctx {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 1, 0, 1};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
