@@ -107,9 +107,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-#ifndef CSS_ABL_NO_GLOAD
         if (kt + 1 < nk) { CSS_GLOAD((kt + 1) * BK) }
-#endif
         const float* as = lds + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + c) * LDS_LD + 4 * h;
         const float* bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * 64 + c) * LDS_LD + 4 * h;
 #pragma unroll
@@ -129,12 +127,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
             CSS_MFMA_STEP(x) CSS_MFMA_STEP(y) CSS_MFMA_STEP(z) CSS_MFMA_STEP(w)
 #undef CSS_MFMA_STEP
         }
-#ifndef CSS_ABL_NO_LSTORE
         if (kt + 1 < nk) CSS_LSTORE(buf ^ 1)
-#endif
-#ifndef CSS_ABL_NO_BARRIER
         __syncthreads();
-#endif
     }
 #undef CSS_GLOAD
 #undef CSS_LSTORE

@@ -45,10 +45,6 @@ __device__ __forceinline__ void slab_mfma(const float* as, const float* bs, f32x
             ah1 = CSS_LDH(as + 32 * LDS_LD + kk * 8);
             al1 = CSS_LDH(as + 32 * LDS_LD + kk * 8 + 16);
         }
-#ifdef CSS_ABL_NO_MFMA
-        asm volatile("" ::"v"(ah0), "v"(al0), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1), "v"(ah1), "v"(al1));
-        if (false)
-#endif
         {
         CSS_MFMA16(ah0, bh0, acc00);
         CSS_MFMA16(ah0, bh1, acc01);
@@ -150,37 +146,18 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_split_kernel(GemmArgs g, int
     CSS_LSTORE(R, 0)
     __syncthreads();
     // invariant at the top of step kt: LDS[kt & 1] holds slab kt, stage S (even kt) / R (odd kt) holds slab kt + 1
-    // (CSS_ABL_NO_*: ablation switches for tools/gemm_split_ablation.sh -- wrong results, timing only)
-#ifdef CSS_ABL_NO_GLOAD
-#define CSS_GLOAD_L(P, k0)
-#else
-#define CSS_GLOAD_L(P, k0) CSS_GLOAD(P, k0)
-#endif
-#ifdef CSS_ABL_NO_LSTORE
-#define CSS_LSTORE_L(P, buf)
-#else
-#define CSS_LSTORE_L(P, buf) CSS_LSTORE(P, buf)
-#endif
-#ifdef CSS_ABL_NO_BARRIER
-#define CSS_SYNC_L()
-#else
-#define CSS_SYNC_L() __syncthreads()
-#endif
     for (int kt = 0;;) {
-        CSS_GLOAD_L(R, CSS_KOFF(kt + 2))
+        CSS_GLOAD(R, CSS_KOFF(kt + 2))
         slab_mfma<TM>(as0, bs0, acc00, acc01, acc10, acc11, cor00, cor01, cor10, cor11);
-        CSS_LSTORE_L(S, 1)
-        CSS_SYNC_L();
+        CSS_LSTORE(S, 1)
+        __syncthreads();
         if (++kt >= nk) break;
-        CSS_GLOAD_L(S, CSS_KOFF(kt + 2))
+        CSS_GLOAD(S, CSS_KOFF(kt + 2))
         slab_mfma<TM>(as0 + STAGE, bs0 + STAGE, acc00, acc01, acc10, acc11, cor00, cor01, cor10, cor11);
-        CSS_LSTORE_L(R, 0)
-        CSS_SYNC_L();
+        CSS_LSTORE(R, 0)
+        __syncthreads();
         if (++kt >= nk) break;
     }
-#undef CSS_GLOAD_L
-#undef CSS_LSTORE_L
-#undef CSS_SYNC_L
 #undef CSS_KOFF
 #undef CSS_GLOAD
 #undef CSS_LSTORE

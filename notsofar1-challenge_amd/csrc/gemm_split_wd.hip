@@ -87,26 +87,13 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     f16x8 ah1_0, ah1_1, ah1_2, ah1_3, ah1_4, ah1_5, ah1_6, ah1_7, al1_0, al1_1, al1_2, al1_3, al1_4, al1_5, al1_6, al1_7;
     f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};   // row tiles x this wave's 32 columns
     f32x16 cor0 = {0}, cor1 = {0}, cor2 = {0}, cor3 = {0};   // the 2^-11-scaled cross terms
-#ifdef CSS_ABL_ASAME   /* ablation (tools only): every A slab load re-reads slab 0 / 1 */
-#define CSS_KOFF(kt_) (((kt_) & 1) * BK)
-#else
 #define CSS_KOFF(kt_) (((kt_) * BK) < klast ? ((kt_) * BK) : klast)
-#endif
-#ifdef CSS_ABL_WSAME   /* ablation (tools only): every weight load re-reads slab 0 / 1 */
-#define CSS_KT(kt_) ((kt_) & 1)
-#else
 #define CSS_KT(kt_) ((kt_) < nk ? (kt_) : nk - 1)
-#endif
 #define CSS_G1(i, st, k0) if constexpr (i < NLA) stg##st##_##i = *reinterpret_cast<const float4*>(pa##i + (k0));
 #define CSS_GLOAD(st, k0) CSS_I4(CSS_G1, st, k0)
 #define CSS_L1(i, st, buf) \
     if constexpr (i < NLA) *reinterpret_cast<float4*>(lds + (buf) * STAGE + (lr + i * LROWS) * LDS_LD + lc) = stg##st##_##i;
-#ifdef CSS_ABL_NO_LSTORE   /* ablation (tools only): one LDS store per step keeps the loads alive */
-#define CSS_LSTORE(st, buf) { float4 k_ = stg##st##_0; if constexpr (NLA > 1) { k_.x += stg##st##_1.x; } if constexpr (NLA > 2) { k_.y += stg##st##_2.x + stg##st##_3.x; } \
-        *reinterpret_cast<float4*>(lds + (buf) * STAGE + lr * LDS_LD + lc) = k_; }
-#else
 #define CSS_LSTORE(st, buf) CSS_I4(CSS_L1, st, buf)
-#endif
 #define CSS_W1(i, st, q_) wr##st##_##i = (q_)[i * 64];
 #define CSS_WLOAD(st, kt_) { const float4* q_ = pw + (int64_t)(kt_) * 4 * 64; CSS_I4(CSS_W1, st, q_) }
     const float* as0 = lds + (wm * (BM / WMV) + c) * LDS_LD + 4 * h;
@@ -116,22 +103,11 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
         ah##st##_##o = CSS_LDH(as0 + (buf) * STAGE + (o & 3) * 32 * LDS_LD + (o >> 2) * 8);                   \
         CSS_A1_LO(o, st, buf)                                                                                 \
     }
-#ifdef CSS_ABL_HALF_AREAD   /* ablation (tools only): half of the LDS operand reads (lo = hi) */
-#define CSS_A1_LO(o, st, buf) al##st##_##o = ah##st##_##o;
-#else
 #define CSS_A1_LO(o, st, buf) al##st##_##o = CSS_LDH(as0 + (buf) * STAGE + (o & 3) * 32 * LDS_LD + (o >> 2) * 8 + 16);
-#endif
 #define CSS_AREAD(st, buf) CSS_I8(CSS_A1, st, buf)
-#ifdef CSS_ABL_NO_AREAD   /* ablation (tools only): operands are read once, before the loop */
-#define CSS_AREAD_LOOP(st, buf)
-#else
 #define CSS_AREAD_LOOP(st, buf) CSS_AREAD(st, buf)
-#endif
     // the 6 * TM MFMAs of one slab; each accumulator is touched every TM-th MFMA
 #define CSS_M1(t, st, kk, part, w_, dst) if constexpr (t < TM) CSS_MFMA16(part##st##_##kk##t, w_, dst##t);
-#ifdef CSS_ABL_MFMA_THIRD   /* ablation (tools only): the hi*hi MFMAs alone, a third of the matrix work */
-#define CSS_SLAB_COR(st, o0, o1, o2, o3) cor0[0] += wl_[0];
-#else
 #define CSS_SLAB_COR(st, o0, o1, o2, o3)                                                              \
         if constexpr (0 < TM) CSS_MFMA16(ah##st##_##o0, wl_, cor0);                                   \
         if constexpr (1 < TM) CSS_MFMA16(ah##st##_##o1, wl_, cor1);                                   \
@@ -141,7 +117,6 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
         if constexpr (1 < TM) CSS_MFMA16(al##st##_##o1, wh_, cor1);                                   \
         if constexpr (2 < TM) CSS_MFMA16(al##st##_##o2, wh_, cor2);                                   \
         if constexpr (3 < TM) CSS_MFMA16(al##st##_##o3, wh_, cor3);
-#endif
 #define CSS_SLAB_KK(st, ws, kk, o0, o1, o2, o3, wi0, wi1)                                                \
     {                                                                                                 \
         const f16x8 wh_ = __builtin_bit_cast(f16x8, wr##ws##_##wi0);                                  \
@@ -167,11 +142,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM - 2 * TM - NLA, 0); \
     __builtin_amdgcn_sched_barrier(0);   /* the barrier stays behind the last MFMA: the pipe drains while waiting */
 
-#ifdef CSS_ABL_NO_BARRIER   /* ablation (tools only; results are then wrong) */
-#define CSS_LOOP_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
 #define CSS_LOOP_BARRIER() __syncthreads()
-#endif
     // epilogue operands (column bias, residual) are requested now and used after the K loop (gemm_common.hpp)
     const int mrow = m0 + wm * (BM / WMV) + 4 * h, ncol = n0 + wn * 32 + c;
     TilePre pre0, pre1, pre2, pre3;
@@ -192,9 +163,6 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     CSS_LSTORE(1, 1)
     __syncthreads();
     CSS_AREAD(0, 0)
-#ifdef CSS_ABL_NO_AREAD
-    CSS_AREAD(1, 0)
-#endif
     __syncthreads();   // every wave holds slab 0 in registers before slab 2 overwrites LDS[0]
     // invariant at the top of step kt: operand set kt % 2 = slab kt, LDS[(kt + 1) % 2] = slab kt + 1, stage kt % 2 =
     // slab kt + 2, weight sets kt % 3 and (kt + 1) % 3 = weights kt, kt + 1.  The weights are requested TWO slabs ahead
@@ -225,14 +193,6 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     const int act = g.act, bias_m = g.bias_along_m, so = g.split_out;
     const int64_t ldc = g.ldc, ldr = g.ldr;
     const float alpha = g.alpha;
-#ifdef CSS_ABL_NO_EMIT   /* ablation (tools only): one store per wave keeps the accumulators alive, nothing else is written */
-    {
-        float keep_ = 0.f;
-        for (int e = 0; e < 16; ++e) keep_ += acc0[e] + acc1[e] + acc2[e] + acc3[e] + cor0[e] + cor1[e] + cor2[e] + cor3[e];
-        if (lane == 0) C[(int64_t)min(m0 + wm * (BM / WMV), M - 1) * g.ldc + min(n0 + wn * 32, N - 1)] = keep_;
-    }
-    return;
-#endif
     // wide epilogue (gemm_common.hpp): each wave's finished tiles pass through its own [32][LDS_LD] patch of the slab
     // buffers, which nobody reads any more after the loop's last barrier
     float* patch = lds + wave * (32 * LDS_LD);

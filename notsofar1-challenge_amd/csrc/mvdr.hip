@@ -105,10 +105,6 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#if defined(SCM_ABL) && SCM_ABL == 3   /* tools: the load phase alone */
-    if (xs[lane] == 12345.f) a.scm[0] = 1.0;
-    return;
-#endif
     // ---- frames by winner: list j holds the frames mask j wins (bit 15: the frame's first winner)
     const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
     int cnt[4] = {0, 0, 0, 0};
@@ -140,11 +136,7 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     double acc[NPACK], pl[NPACK];
 #pragma unroll
     for (int i = 0; i < NPACK; ++i) { acc[i] = 0.0; pl[i] = 0.0; }
-#if defined(SCM_ABL) && SCM_ABL == 1   /* tools/scm_bench.hip: no group loop (loads + lists + reductions only) */
-    const int nk = 0;
-#else
     const int nk = k == 0 ? cnt[0] : (k == 1 ? cnt[1] : (k == 2 ? cnt[2] : cnt[3]));
-#endif
     for (int i = l16; i < nk; i += 16) {
         const unsigned e = lists[k * T + i];
         const int t = e & 0x7fff;
@@ -172,10 +164,6 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
             }
         }
     }
-#if defined(SCM_ABL) && SCM_ABL == 2   /* tools: no reductions / output */
-    if (acc[3] == 12345.0) a.scm[0] = pl[5];
-    return;
-#endif
     // ---- reduce-scatter over the group's 16 lanes: four DPP exchanges, each halving the number of values a lane keeps
     // (summing all 98 values into all 16 lanes cost 4 x 98 exchanges and 16 copies of every total; this costs
     // 49 + 25 + 13 + 7 and leaves each total in one lane).  A lane keeps the lower or upper half of its values by one bit

@@ -1,5 +1,5 @@
 // Stand-alone timing of css::launch_scm (and the other MVDR-stage kernels) on the 60 s meeting's shapes (tools only).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSCM_ABL=n] tools/scm_bench.hip notsofar1-challenge_amd/csrc/mvdr.hip -Inotsofar1-challenge_amd/csrc -o /tmp/scm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/scm_bench.hip notsofar1-challenge_amd/csrc/mvdr.hip -Inotsofar1-challenge_amd/csrc -o /tmp/scm_bench
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
