@@ -180,7 +180,8 @@ enum css_tuning {
     CSS_TUNE_OUT_MAPPED = 1,    /* 1: the overlap-add kernel writes page-locked output over PCIe itself; 0 (default): DMA  */
     CSS_TUNE_TAIL_PER_UNIT = 2, /* 1: stitch / synthesise after every lane's unit; 0 (default): once per batch             */
     CSS_TUNE_MVDR_ON_LANES = 3, /* 1 (default): covariances / MVDR / stitching costs at the end of each lane's chain; 0: after  */
-    CSS_TUNE_COUNT = 4
+    CSS_TUNE_PIPELINE_DEVICE = 4, /* 1: css_run_device also takes the unit pipeline; 0 (default): the plain stage sequence    */
+    CSS_TUNE_COUNT = 5
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

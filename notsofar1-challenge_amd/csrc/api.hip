@@ -114,7 +114,7 @@ struct css_ctx {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -1084,6 +1084,32 @@ static hipEvent_t pool_event(css_ctx* h) {
     return h->ev_pool[h->ev_pool_used++];
 }
 
+// stage times of the pass just synchronised (HIP events on the handle's streams) and the per-family kernel profile
+using HostClock = std::chrono::steady_clock::time_point;
+static int finish_timings(css_ctx* h, HostClock t0, HostClock t1, HostClock t2, bool staged) {
+    auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
+    CssTimings& t = h->tim;
+    t.host_enqueue = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    t.host_total = std::chrono::duration<float, std::milli>(t2 - t0).count();
+    // (pipelined pass: the stages overlap -- masknet = first chain's begin .. last chain's end, beamformer included;
+    //  stitch / istft = the LAST batch's tail)
+    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = staged ? ms(3, 4) : 0.f; t.stitch = ms(4, 5);
+    t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
+    t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
+    for (int c = 0; c < CSS_PROF_COUNT; ++c) { h->prof_ms[c] = 0.f; h->prof_launches[c] = 0; }
+    if (h->profile_gemm) {
+        for (size_t i = 0; i < h->prof_used; ++i) {
+            float v = 0.f;
+            hipEventElapsedTime(&v, h->prof_events[i].a, h->prof_events[i].b);
+            h->prof_ms[h->prof_events[i].cat] += v;
+            h->prof_launches[h->prof_events[i].cat] += 1;
+        }
+        t.gemm_ms = h->prof_ms[CSS_PROF_LINEAR];
+        t.gemm_launches = h->prof_launches[CSS_PROF_LINEAR];
+    }
+    return CSS_OK;
+}
+
 // One pass of css/css.py:110 separate_and_stitch as a pipeline.  The recording's segments go through the mask estimator
 // in batches, each cut into lanes (css_ctx::lanes); a (batch, lane) UNIT owns the frames no earlier unit reads.
 //   in    its samples cross PCIe on the copy stream as one piece; the lane's chain waits for that piece only, transforms
@@ -1119,6 +1145,27 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     const int16_t* planes_dev = io.planes_host ? (const int16_t*)h->in16.p : nullptr;
     hipEventRecord(h->ev[1], h->stream);
     hipEventRecord(h->ev[2], h->stream);   // the analysis transform is part of the lanes' chains (CssTimings.stft = 0)
+
+    // ---- nothing to hide: with the samples already in HBM the plain stage sequence (whole transform, estimator with
+    // its lanes, beamformer, costs, scan, overlap-add, gate, synthesis on one stream) measures 2 % ahead of the unit
+    // pipeline below (profiles/r02_shard_overhead.md: 5.35 vs 5.43 ms per 60 s meeting, 143.0 vs 146.2 ms per 30 min)
+    if (io.pcm_dev && io.wav_dev && !h->tune[CSS_TUNE_PIPELINE_DEVICE]) {
+        launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->stream);
+        if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
+        if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
+        if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
+        if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
+        if ((rc = css_stage_pit_scan(h)) != CSS_OK) return rc;
+        if ((rc = css_stage_stitch(h, 0, TL)) != CSS_OK) return rc;
+        if ((rc = istft_impl(h, 0, TL, 0, TL + 1, io.wav_dev, io.cap, 0, h->stream)) != CSS_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        hipEventRecord(h->ev[7], h->stream);
+        const auto host_t1 = std::chrono::steady_clock::now();
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        const auto host_t2 = std::chrono::steady_clock::now();
+        return finish_timings(h, host_t0, host_t1, host_t2, true);
+    }
 
     // ---- units, their frames and samples
     struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x, v, m; };   // pieces landed, planes, beamformer, costs
@@ -1325,26 +1372,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     const auto host_t2 = std::chrono::steady_clock::now();
-    auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
-    CssTimings& t = h->tim;
-    t.host_enqueue = std::chrono::duration<float, std::milli>(host_t1 - host_t0).count();
-    t.host_total = std::chrono::duration<float, std::milli>(host_t2 - host_t0).count();
-    // (the stages overlap: masknet = begin of the first chain .. end of the last, stitch / istft = the LAST unit's tail)
-    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = 0.f; t.stitch = ms(4, 5);
-    t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
-    t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
-    for (int c = 0; c < CSS_PROF_COUNT; ++c) { h->prof_ms[c] = 0.f; h->prof_launches[c] = 0; }
-    if (h->profile_gemm) {
-        for (size_t i = 0; i < h->prof_used; ++i) {
-            float v = 0.f;
-            hipEventElapsedTime(&v, h->prof_events[i].a, h->prof_events[i].b);
-            h->prof_ms[h->prof_events[i].cat] += v;
-            h->prof_launches[h->prof_events[i].cat] += 1;
-        }
-        t.gemm_ms = h->prof_ms[CSS_PROF_LINEAR];
-        t.gemm_launches = h->prof_launches[CSS_PROF_LINEAR];
-    }
-    return CSS_OK;
+    return finish_timings(h, host_t0, host_t1, host_t2, false);
 }
 
 // The pass, and -- when an operand left the split-f16 range (a split GEMM saw a non-finite accumulator) -- the same pass

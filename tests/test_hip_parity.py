@@ -399,6 +399,18 @@ def test_full_size_60s_properties(L, CSS, sep_mc, mix60):
     assert np.array_equal(results[2], w1)
     assert np.array_equal(results[3], w1)
 
+    # css_run_device (samples and waveforms in HBM): the plain stage sequence by default, the unit pipeline on request;
+    # both are the host-to-host pass's result, bit for bit
+    pcm_dev = torch.from_numpy(np.ascontiguousarray(mix60[0])).cuda()
+    wav_dev = torch.empty((3, int(plan.n_out)), dtype=torch.float32, device="cuda")
+    for pipelined in (0, 1):
+        h.set_tuning("pipeline_device", pipelined)
+        wav_dev.zero_()
+        h.run_device(pcm_dev.data_ptr(), mix60.shape[1], 7, run_cfg, wav_dev.data_ptr(), int(plan.n_out))
+        torch.cuda.synchronize()
+        assert np.array_equal(wav_dev.cpu().numpy(), w1), pipelined
+    h.set_tuning("pipeline_device", 0)
+
     # gain linearity: the features are scale-invariant up to their eps clamps and the beamformer is linear,
     # so x -> 0.5 x halves the output (up to float32-rounding-level winner-take-all flips)
     wh = h.run(0.5 * mix60[0], run_cfg)
