@@ -191,18 +191,24 @@ def main():
         s_lo, s_hi = me.pcm_range(desc.frame_len, n)
         # this rank's samples and its range of the result, in page-locked host memory
         pcm_slice = L.pinned_copy(np.ascontiguousarray(mix[0, s_lo:s_hi]))
+        # every rank finishes the samples of its own range (gather="range": one 256-sample block per stream crosses each
+        # seam) and writes them to its page-locked host buffer -- the ranks' buffers together are the meeting's result
         o_lo = me.sample_lo
-        o_hi = int(plan.n_out) if rank == world - 1 else me.t_hi * desc.frame_hop
+        o_hi = (int(plan.n_out) if me.t_hi == int(plan.mix_frames) else me.t_hi * desc.frame_hop) if me.num_frames else o_lo
         out_host = torch.empty((S, max(o_hi - o_lo, 1)), dtype=torch.float32, pin_memory=True)
-        out_dev = torch.empty((S, int(plan.n_out)), dtype=torch.float32, device=dev)
+
+        # the rank's samples cross PCIe in growing pieces; all but the first hide under the stages of the pieces before
+        groups, cuts = PAR.upload_schedule(me, T, hop, desc.frame_len, n)
 
         def step():
-            be.begin(pcm_slice, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True)
-            out = PAR.sharded_separate_and_stitch(be, S, T, hop, desc.frame_hop, rank, world, dist, out=out_dev)
+            be.begin(pcm_slice, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True, cuts=cuts)
+            own, rng = PAR.sharded_separate_and_stitch(be, S, T, hop, desc.frame_hop, rank, world, dist, gather="range",
+                                                       segment_groups=groups)
+            assert rng == (o_lo, o_hi), (rng, o_lo, o_hi)
             with be.on_stream():
                 if o_hi > o_lo:
-                    out_host[:, :o_hi - o_lo].copy_(out[:, o_lo:o_hi], non_blocking=True)
-            return out
+                    out_host[:, :o_hi - o_lo].copy_(own, non_blocking=True)
+            return own
 
         def barrier():
             h.sync()
@@ -223,9 +229,13 @@ def main():
         assert torch.isfinite(out_host).all()
         if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
             ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
-            same = bool(np.array_equal(ref, out.cpu().numpy())) and \
-                bool(np.array_equal(ref[:, o_lo:o_hi], out_host[:, :o_hi - o_lo].numpy()))
-            log(f"[rank {rank}] sharded == fused single-GPU result, bit for bit: {same}")
+            same = bool(np.array_equal(ref[:, o_lo:o_hi], out_host[:, :o_hi - o_lo].numpy()))
+            be.begin(pcm_slice, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True)
+            full = PAR.sharded_separate_and_stitch(be, S, T, hop, desc.frame_hop, rank, world, dist)   # gather="all"
+            same = same and bool(np.array_equal(ref, full.cpu().numpy()))
+            del full
+            log(f"[rank {rank}] sharded == fused single-GPU result, bit for bit (own range [{o_lo}, {o_hi}) and the "
+                f"all-gathered whole): {same}")
             assert same
         result.update({
             "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -233,8 +243,10 @@ def main():
             "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({nseg} segments of 3 s / 1.5 s hop), "
                                    f"Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR, host PCM -> host waveforms",
                        "segments": nseg, "segments_per_rank": me.seg_hi - me.seg_lo,
-                       "sharding": f"{world} ranks x segment ranges (one halo segment per seam), three all-gathers over "
-                                   f"{'RCCL' if backend == 'nccl' else backend}: PIT costs, activity bits, waveform shards"},
+                       "sharding": f"{world} ranks x segment ranges (one halo segment per seam), each rank uploads its own "
+                                   f"samples and downloads its own range of the result; three small all-gathers over "
+                                   f"{'RCCL' if backend == 'nccl' else backend}: PIT costs (72 B / boundary), activity bits "
+                                   f"(3 B / frame), one 256-sample seam block per stream and rank"},
         })
         if rank == 0:
             # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)
@@ -246,7 +258,7 @@ def main():
         dist.barrier()
         if rank == 0:
             print(json.dumps(result), flush=True)
-        del out, out_dev
+        del out
         be.close()
         sep.close()
         dist.destroy_process_group()

@@ -256,6 +256,11 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
  * the frames this rank will pass to css_stage_stft_range. */
 int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     int64_t s_lo, int64_t s_hi);
+/* Further samples [s_lo, s_hi) of the same host recording for the session css_begin_range opened (pcm_host again points
+ * at sample 0; page-locked memory makes the copy asynchronous).  They cross PCIe on the handle's copy stream while the
+ * stages of the samples already there run; css_stage_stft_range waits for exactly the pieces its frames read.  The level
+ * (CSS_BUF_LEVEL) is complete once every piece's frames have been transformed. */
+int css_upload_range(css_handle_t h, const float* pcm_host, int64_t s_lo, int64_t s_hi);
 /* ConformerCssWrapper.stft (conformer_wrapper.py:106, feature.py:88) over the whole recording. */
 int css_stage_stft(css_handle_t h);
 /* Same for frames [t_lo, t_hi) only (a rank that owns a slice of the meeting transforms just the

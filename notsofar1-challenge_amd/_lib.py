@@ -101,6 +101,7 @@ SIGNATURES = {
     "css_get_plan": (C.c_int, [_P, C.POINTER(CssPlan)]),
     "css_begin": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int]),
     "css_begin_range": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), C.c_int64, C.c_int64]),
+    "css_upload_range": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "css_stage_stft": (C.c_int, [_P]),
     "css_stage_stft_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_stitch_masks": (C.c_int, [_P, C.c_int64, C.c_int64]),
@@ -407,19 +408,28 @@ class Handle:
             ptr = _np_ptr(self._pcm_keep)
         check(self.h, self.lib.css_begin(self.h, ptr, n, c, C.byref(cfg.c), int(device)))
 
-    def begin_range(self, pcm: np.ndarray, n: int, c: int, cfg: RunCfg, s_lo: int, s_hi: int, slice_only: bool = False):
+    def begin_range(self, pcm: np.ndarray, n: int, c: int, cfg: RunCfg, s_lo: int, s_hi: int, slice_only: bool = False,
+                    base_sample: Optional[int] = None):
         """Session over a host recording of n samples of which only samples [s_lo, s_hi) are uploaded (a rank's slice).
-        slice_only: `pcm` holds just those samples (the library is handed the address sample 0 would have and never
-        reads outside the range)."""
+        slice_only: `pcm` holds just a slice starting at sample `base_sample` (default s_lo) of the recording (the library
+        is handed the address sample 0 would have and never reads outside [s_lo, s_hi))."""
         assert pcm.dtype == np.float32 and pcm.flags.c_contiguous
         self._pcm_keep = pcm
         base = pcm.ctypes.data
         if slice_only:
-            assert pcm.shape[0] == s_hi - s_lo
-            base -= int(s_lo) * c * 4
+            b0 = int(s_lo) if base_sample is None else int(base_sample)
+            assert b0 <= s_lo and s_hi - b0 <= pcm.shape[0]
+            base -= b0 * c * 4
         else:
             assert pcm.shape[0] == n
         check(self.h, self.lib.css_begin_range(self.h, C.c_void_p(base), n, c, C.byref(cfg.c), int(s_lo), int(s_hi)))
+
+    def upload_range(self, pcm: np.ndarray, c: int, s_lo: int, s_hi: int, base_sample: int = 0):
+        """Further samples [s_lo, s_hi) of the recording begin_range opened, asynchronously on the copy stream;
+        `pcm[0]` is sample `base_sample` of the recording."""
+        assert pcm.dtype == np.float32 and pcm.flags.c_contiguous and base_sample <= s_lo and s_hi - base_sample <= pcm.shape[0]
+        base = pcm.ctypes.data - int(base_sample) * c * 4
+        check(self.h, self.lib.css_upload_range(self.h, C.c_void_p(base), int(s_lo), int(s_hi)))
 
     def stage_stft(self):
         check(self.h, self.lib.css_stage_stft(self.h))

@@ -117,6 +117,10 @@ struct css_ctx {
     int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
+    // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
+    // the handle's stream wait for exactly the pieces its frames read
+    struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
+    std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
     size_t ev_pool_used = 0;
 
@@ -572,6 +576,8 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     h->T_ld = (p.mix_frames + 3) / 4 * 4;
     h->stft_done = h->perms_done = h->have_override = false;
     h->has_session = true;
+    h->uploads.clear();
+    h->ev_pool_used = 0;
     h->tim = CssTimings{};
     h->prof_used = 0;
     h->gemm_flops = 0.0;
@@ -650,6 +656,31 @@ int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     return CSS_OK;
 }
 
+static hipEvent_t pool_event(css_ctx* h);
+
+int css_upload_range(css_handle_t h, const float* pcm_host, int64_t s_lo, int64_t s_hi) {
+    int rc = check_session(h);
+    if (rc) return rc;
+    if (!pcm_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (h->pcm_src != (const float*)h->pcm_in.p || !h->pcm_in.p) return fail(h, CSS_ERR_STATE, "the session was not opened by css_begin_range");
+    if (s_lo < 0 || s_hi > h->plan.n_samples || s_lo > s_hi) return fail(h, CSS_ERR_INVALID_ARG, "sample range out of bounds");
+    if (s_hi == s_lo) return CSS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    // behind whatever the handle's stream had enqueued when the session began (the previous session's readers of pcm_in)
+    hipEvent_t landed = pool_event(h);
+    if (h->uploads.empty()) {
+        hipEvent_t opened = pool_event(h);
+        HIPCHK(h, hipEventRecord(opened, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, opened, 0));
+    }
+    if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->copy_stream)) != CSS_OK) return rc;
+    launch_pcm_peak_f32(h->pcm_src + s_lo * h->n_ch, (s_hi - s_lo) * h->n_ch, h->peak_dev, h->copy_stream);
+    HIPCHK(h, hipEventRecord(landed, h->copy_stream));
+    h->uploads.push_back({s_lo, s_hi, landed});
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
 // Analysis transform of frames [t_lo, t_hi) on stream `st`: channel-major copy of exactly the samples these frames read
 // (from the sample-major float PCM, or straight from the session's PCM16 planes), then DFT-matrix x frames.
 // The analysis transform stays on the exact float32 MFMA path in either mode: the 7x7 MVDR solve amplifies
@@ -683,6 +714,12 @@ int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     const int F = h->d.num_bins;
     if (h->plan.stft_frames < h->plan.mix_frames && !h->stft_done)  // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+    {   // pieces of the recording still crossing PCIe (css_upload_range): wait for the ones these frames read
+        const int64_t f_hi = std::min<int64_t>(t_hi, h->plan.stft_frames);
+        const int64_t i_lo = t_lo * h->d.frame_hop, i_hi = f_hi > t_lo ? (f_hi - 1) * h->d.frame_hop + h->d.frame_len : i_lo;
+        for (const auto& u : h->uploads)
+            if (u.s_lo < i_hi && i_lo < u.s_hi) HIPCHK(h, hipStreamWaitEvent(h->stream, u.landed, 0));
+    }
     if ((rc = stft_frames(h, t_lo, t_hi, nullptr, h->stream)) != CSS_OK) return rc;
     hipEventRecord(h->ev[2], h->stream);
     HIPCHK(h, hipGetLastError());

@@ -11,15 +11,18 @@ not depend on the number of ranks:
   ceil(T/hop) - 1 halo segments before S_r that still cover the rank's first frames (ONE segment with the
   shipped 3 s / 1.5 s configuration).
 
-Exchanges (all tiny except the last; `torch.distributed`, backend "nccl" = RCCL on ROCm, "gloo" in CPU tests):
+Exchanges (all tiny; `torch.distributed`, backend "nccl" = RCCL on ROCm, "gloo" in CPU tests):
   1. raw 3x3 PIT cost matrices of the boundaries each rank owns (all-gather, 72 B per boundary); every
      rank then replays the sequential permutation scan of css.py:266-285 identically, on its GPU;
   2. thresholded activity bits of the frames each rank owns (all-gather, 3 B per frame), because the
      dilate/erode gate (css.py:305-308) looks 36 frames to either side;
-  3. the separated-waveform shards (all-gather, 3 x 4 B per sample): each rank inverse-transforms only
-     its own frames, so adjacent shards overlap by one hop (256 samples) where the two-frame
-     overlap-add crosses the rank boundary; the stitch adds the two partial blocks (a two-term
-     float sum commutes, so the result is bit-identical to the single-GPU run).
+  3. the waveform seam: each rank inverse-transforms only its own frames, so its shard ends with one output block
+     (one hop, 256 samples) that belongs to the NEXT rank's range -- the second half of its last frame.  Those blocks
+     are exchanged (all-gather, 3 x 256 x 4 B per rank) and each rank adds its left neighbour's onto the head of its
+     shard (a two-term float sum commutes, so the result is bit-identical to the single-GPU run).  A rank then holds the
+     finished samples of its own range (`gather="range"`: what a serving process writes out); `gather="all"`
+     all-gathers the whole shards instead (3 x 4 B per sample) and every rank assembles the full waveforms, as
+     css.py:110 returns them.
 
 Nothing of this touches the host between the upload of a rank's samples and the download of the result: the
 pieces are zero-copy torch views of the handle's own device buffers (costs, activity bits), the collectives and
@@ -94,6 +97,24 @@ def all_plans(num_segments, mix_frames, stft_frames, seg_frames, hop_frames, hop
             for r in range(world)]
 
 
+def upload_schedule(me: ShardPlan, seg_frames: int, hop_frames: int, frame_len: int, n_samples: int, first: int = 32,
+                    growth: int = 8):
+    """Groups of a rank's segments whose samples cross PCIe piece by piece, so that the upload of all but the first
+    group hides under the stages of the groups before it: `first` segments, then `growth` times as many, ... (a segment
+    costs ~10 times as long to compute as to upload).  Returns (segment_groups [(lo, hi), ...], cuts): `cuts` are the
+    sample positions where the pieces end (HipShardBackend.begin) and `segment_groups` goes to ShardedSession."""
+    groups, cuts, lo, size = [], [], me.seg_lo, max(int(first), 1)
+    while lo < me.seg_hi:
+        hi = min(lo + size, me.seg_hi)
+        if me.seg_hi - hi < first // 2:   # no crumbs at the end
+            hi = me.seg_hi
+        groups.append((lo, hi))
+        if hi < me.seg_hi:
+            cuts.append(min(((hi - 1) * hop_frames + seg_frames - 1) * me.hop_samples + frame_len, n_samples))
+        lo, size = hi, size * growth
+    return groups, cuts
+
+
 class _DeviceArray:
     """A device buffer of the handle as something torch.as_tensor can wrap without copying."""
 
@@ -137,14 +158,20 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.dev)
         self.torch.cuda.empty_cache()
 
-    def begin(self, pcm, n, c, run_cfg, sample_range=None, slice_only=False):
+    def begin(self, pcm, n, c, run_cfg, sample_range=None, slice_only=False, cuts=None):
         """pcm: a device tensor [n, c] (resident input), or a float32 numpy array in host memory, of which only
-        `sample_range` (default: everything) is uploaded; slice_only: the array holds just that range."""
+        `sample_range` (default: everything) is uploaded; slice_only: the array holds just that range.  `cuts`: sample
+        positions inside the range at which the upload is cut into pieces (upload_schedule): the first piece is uploaded
+        on the handle's stream, the others follow on its copy stream while the stages of the earlier pieces run."""
         self._keep = pcm
         if hasattr(pcm, "data_ptr"):
             self.h.begin(pcm.data_ptr(), n, c, run_cfg, device=True)
         elif sample_range is not None:
-            self.h.begin_range(pcm, n, c, run_cfg, sample_range[0], sample_range[1], slice_only)
+            lo, hi = sample_range
+            edges = [lo] + [int(x) for x in (cuts or []) if lo < x < hi] + [hi]
+            self.h.begin_range(pcm, n, c, run_cfg, edges[0], edges[1], slice_only, base_sample=lo)
+            for a, b in zip(edges[1:-1], edges[2:]):
+                self.h.upload_range(pcm, c, a, b, base_sample=lo if slice_only else 0)
         else:
             self.h.begin(pcm, n, c, run_cfg, device=False)
 
@@ -210,10 +237,11 @@ class ShardedSession:
     chains them over torch.distributed; tests chain them for several virtual ranks in one process."""
 
     def __init__(self, backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int, rank: int,
-                 world: int):
+                 world: int, segment_groups=None):
         import torch
         self.torch = torch
         self.be, self.S, self.rank, self.world = backend, num_spks, rank, world
+        self.seg_frames, self.hop_frames, self.segment_groups = seg_frames, hop_frames, segment_groups
         plan = backend.plan()
         self.nseg, self.TL, self.n_out = int(plan.num_segments), int(plan.mix_frames), int(plan.n_out)
         self.plans = all_plans(self.nseg, self.TL, int(plan.stft_frames), seg_frames, hop_frames, hop_samples, world)
@@ -239,9 +267,18 @@ class ShardedSession:
     def segments_and_costs(self):
         me, be, torch = self.me, self.be, self.torch
         with self._ctx():
-            be.stft_range(me.f_lo, me.f_hi)
-            be.masknet(me.seg_lo, me.seg_hi)
-            be.mvdr(me.seg_lo, me.seg_hi)
+            # group by group (upload_schedule): a group's frames are transformed as soon as ITS samples have landed
+            groups = self.segment_groups or [(me.seg_lo, me.seg_hi)]
+            assert groups[0][0] == me.seg_lo and groups[-1][1] == me.seg_hi and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+            f_prev = me.f_lo
+            for a, b in groups:
+                f_hi = me.f_hi if b == me.seg_hi else min((b - 1) * self.hop_frames + self.seg_frames, me.f_hi)
+                if f_hi > f_prev:
+                    be.stft_range(f_prev, f_hi)
+                    f_prev = f_hi
+                if b > a:
+                    be.masknet(a, b)
+                    be.mvdr(a, b)
             be.pit_costs(me.b_lo, me.b_hi)
             if self.world == 1:
                 return None
@@ -285,6 +322,36 @@ class ShardedSession:
             be.istft_partial(me.t_lo, me.t_hi, shard)
             return shard
 
+    def own_range(self):
+        """samples [lo, hi) of the output this rank finishes (the last rank also owns the closing half frame)"""
+        me = self.me
+        if me.num_frames == 0:
+            return me.sample_lo, me.sample_lo
+        return me.sample_lo, (self.n_out if me.t_hi == self.TL else me.t_hi * self.hop_samples)
+
+    def seam_piece(self, shard):
+        """The block past this rank's own range -- its last frame's second half, which the next rank adds [S, hop]."""
+        torch, hop, me = self.torch, self.hop_samples, self.me
+        with self._ctx():
+            send = self.be.scratch("send_seam", (self.S, hop), torch.float32)
+            if me.num_frames:
+                send.copy_(shard[:, me.num_frames * hop:(me.num_frames + 1) * hop])
+            else:
+                send.zero_()
+            return send
+
+    def finish_range(self, shard, all_seams):
+        """Adds the left neighbour's seam block onto the head of this rank's shard; returns the finished samples of
+        own_range() as a view of the shard [S, hi - lo]."""
+        hop, me = self.hop_samples, self.me
+        lo, hi = self.own_range()
+        with self._ctx():
+            left = [p for p in self.plans[:self.rank] if p.num_frames > 0]
+            if me.num_frames and left:
+                assert tuple(all_seams.shape) == (self.world, self.S, hop), all_seams.shape
+                shard[:, :hop].add_(all_seams[left[-1].rank])
+            return shard[:, :hi - lo]
+
     def join_shards(self, all_shards, out=None):
         """Place every rank's shard at its sample offset: a rank's inner output blocks are its own, the block at a seam
         is the sum of the left rank's last and the right rank's first block (one frame's contribution each)."""
@@ -321,11 +388,17 @@ def _all_gather(dist, send, world, comm_dev):
 
 
 def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int,
-                                rank: int, world: int, dist=None, out=None):
-    """Runs one rank's share of a session that `backend.begin(...)` has opened and returns the full
-    separated waveforms [S, n_out] (a tensor on the backend's device), identical on every
-    rank and identical to the single-rank result.  Asynchronous on the backend's stream."""
-    ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world)
+                                rank: int, world: int, dist=None, out=None, gather: str = "all", segment_groups=None):
+    """Runs one rank's share of a session that `backend.begin(...)` has opened.  Asynchronous on the backend's stream.
+
+    gather="all" (default): returns the full separated waveforms [S, n_out] (a tensor on the backend's device),
+    identical on every rank and identical to the single-rank result -- what css.py:110 returns.
+    gather="range": returns (wav, (lo, hi)): the finished samples [lo, hi) of this rank's own range, [S, hi - lo]; the
+    ranges of the ranks tile [0, n_out) and their concatenation is the single-rank result, bit for bit.  Only one
+    256-sample block per stream crosses between neighbours.
+    segment_groups: upload_schedule's groups when the session's samples arrive piece by piece (HipShardBackend.begin(cuts=))."""
+    assert gather in ("all", "range"), gather
+    ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world, segment_groups)
     comm_dev = getattr(backend, "comm_dev", None)
     ctx = ss._ctx()
     with ctx:
@@ -336,6 +409,12 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
         if world > 1:
             act = _all_gather(dist, act, world, comm_dev if comm_dev is not None else act.device)
         shard = ss.gate_and_istft(act)
+        if gather == "range":
+            seams = None
+            if world > 1:
+                seam = ss.seam_piece(shard)
+                seams = _all_gather(dist, seam, world, comm_dev if comm_dev is not None else seam.device)
+            return ss.finish_range(shard, seams), ss.own_range()
         if world == 1:
             if out is None:
                 return shard[:, :ss.n_out]

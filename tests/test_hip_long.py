@@ -154,8 +154,19 @@ def _two_rank_worker(rank, world, port, seconds, out_dir):
         with be.on_stream():
             got = out.cpu().numpy()
         ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
-        np.save(os.path.join(out_dir, f"same_{rank}.npy"), np.array([np.array_equal(ref, got)]))
-        del out
+        same = np.array_equal(ref, got)
+        # as bench.py --gpus N runs it: the samples in pieces (the later ones on the copy stream, under the stages of the
+        # earlier ones), every rank finishing only its own range of the result
+        groups, cuts = PAR.upload_schedule(me, 186, 93, 512, n, first=3, growth=2)
+        assert len(groups) >= 2 and len(cuts) == len(groups) - 1
+        h.run(np.ascontiguousarray(mix[0, ::-1]), run_cfg)     # other samples in the device copy than this session's
+        be.begin(piece, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True, cuts=cuts)
+        own, (lo, hi) = PAR.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist, gather="range", segment_groups=groups)
+        with be.on_stream():
+            same = same and np.array_equal(ref[:, lo:hi], own.cpu().numpy())
+        np.save(os.path.join(out_dir, f"same_{rank}.npy"), np.array([same]))
+        np.save(os.path.join(out_dir, f"range_{rank}.npy"), np.array([lo, hi]))
+        del out, own
         be.close()
         sep.close()
     finally:
@@ -170,6 +181,8 @@ def test_two_process_sharded_run_on_one_gpu(tmp_path):
     mp.spawn(_two_rank_worker, args=(2, port, 45.0, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert bool(np.load(tmp_path / f"same_{r}.npy")[0]), f"rank {r}: sharded result differs from the fused pass"
+    (lo0, hi0), (lo1, hi1) = (tuple(int(v) for v in np.load(tmp_path / f"range_{r}.npy")) for r in range(2))
+    assert lo0 == 0 and hi0 == lo1 and hi1 > lo1        # the two own ranges tile the output
 
 
 def test_rccl_takes_the_exchange_tensors():

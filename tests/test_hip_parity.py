@@ -95,6 +95,17 @@ def virtual_rank_run(PAR, L, h, pcm, run_cfg, world, poison=False):
     with be.on_stream():
         out = ss.join_shards(torch.stack(pieces[2])) if world > 1 else pieces[2][0][:, :ss.n_out]
         out = out.cpu()
+        if world > 1:   # gather="range": a rank finishes its own samples with its left neighbour's seam block alone
+            edge = 0
+            for r in range(world):
+                sr = PAR.ShardedSession(be, S, T, hop, 256, r, world)
+                seams = torch.stack([PAR.ShardedSession(be, S, T, hop, 256, q, world).seam_piece(pieces[2][q]).clone()
+                                     for q in range(world)])
+                lo, hi = sr.own_range()
+                own = sr.finish_range(pieces[2][r].clone(), seams).cpu()
+                assert lo == edge and tuple(own.shape) == (S, hi - lo) and torch.equal(own, out[:, lo:hi]), (r, lo, hi)
+                edge = hi
+            assert edge == out.shape[1]
     pieces.clear()
     be.close()
     return out.numpy()

@@ -86,6 +86,11 @@ def _worker(rank, world, port, out_dir, n_samples):
         be.begin(mix[0], mix.shape[1], 7)
         out = par.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist)
         np.save(os.path.join(out_dir, f"w{world}_r{rank}.npy"), out.numpy())
+        # the same session again, every rank finishing only its own sample range (one 256-sample block per seam exchanged)
+        be.begin(mix[0], mix.shape[1], 7)
+        own, (lo, hi) = par.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist, gather="range")
+        np.save(os.path.join(out_dir, f"w{world}_r{rank}_own.npy"), own.numpy())
+        np.save(os.path.join(out_dir, f"w{world}_r{rank}_range.npy"), np.array([lo, hi]))
         np.save(os.path.join(out_dir, f"w{world}_r{rank}_nseg.npy"), np.array([be.calls["masknet_segments"]]))
     finally:
         dist.destroy_process_group()
@@ -118,4 +123,13 @@ def test_sharded_driver_over_gloo_matches_single_rank(tmp_path, world):
         assert got.shape == single.shape
         assert np.array_equal(got, single), f"rank {r}: sharded result differs from the single-rank result"
         total_segments += int(np.load(tmp_path / f"w{world}_r{r}_nseg.npy")[0])
-    assert total_segments == oside["plan"].num_segments + (world - 1)   # exactly one halo segment per seam
+    assert total_segments == 2 * (oside["plan"].num_segments + (world - 1))   # exactly one halo segment per seam (two runs)
+    # gather="range": the ranks' own ranges tile the output and are the single-rank samples, bit for bit
+    edge = 0
+    for r in range(world):
+        lo, hi = (int(v) for v in np.load(tmp_path / f"w{world}_r{r}_range.npy"))
+        assert lo == edge and hi >= lo
+        own = np.load(tmp_path / f"w{world}_r{r}_own.npy")
+        assert own.shape == (3, hi - lo) and np.array_equal(own, single[:, lo:hi]), f"rank {r}: own range differs"
+        edge = hi
+    assert edge == single.shape[1]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few css_run passes (page-locked host buffers) for rocprofv3 --kernel-trace --memory-copy-trace; tools/timeline.py
-reads the CSVs.    python tools/trace_pass.py [seconds] [passes] [device|host]"""
+reads the CSVs.    python tools/trace_pass.py [seconds] [passes] [device|host] [lanes]"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -17,6 +17,7 @@ mix = SYN.synth_meeting(seconds, 7, seed=1); n = mix.shape[1]
 run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
 sep = SEP.HipSeparator(state, None, device=0, max_batch_segments=128); h = sep.handle
 plan = L.plan(desc, run_cfg, n)
+if len(sys.argv) > 4: h.set_lanes(int(sys.argv[4]))
 pcm = L.pinned_copy(np.ascontiguousarray(mix[0])); out = L.pinned_empty((3, int(plan.n_out)), np.float32)
 if mode == "device":
     pd = torch.from_numpy(np.ascontiguousarray(mix[0])).cuda(); wd = torch.empty((3, int(plan.n_out)), device="cuda")
