@@ -153,7 +153,7 @@ __device__ __forceinline__ void emit_tile_pre(const f32x16& acc, const TilePre& 
 // The same epilogue with 16-byte stores.  In the accumulator layout a lane owns ONE column of 16 rows, so the plain
 // epilogue issues 16 four-byte (or 32 two-byte) store instructions per tile, and on this hardware the epilogue of a
 // launch is bound by store ISSUE, not bandwidth (MI355X_MICROARCH.md: ~7 B/clk/CU for narrow row-per-lane stores;
-// tools/gemm_wd_epilogue_ablation.sh: the epilogue is 5.5 of the 9 us a K = 32 launch takes).  The finished tile
+// a round-1 timing probe: the epilogue is 5.5 of the 9 us a K = 32 launch takes).  The finished tile
 // therefore takes a turn through a wave-private LDS patch [32][LDS_LD] and leaves as 4 float4 row segments per lane
 // (split columns: 4 x {8-byte hi, 8-byte lo}).  Requires N % 4 == 0 for the columns of this tile.
 __device__ __forceinline__ void emit_tile_pre_wide(const f32x16& acc, const TilePre& p, int mb0, int h, int c, int nb, int M,

@@ -5,7 +5,7 @@
 //
 // Why: in gemm_split.hip both operands go global -> registers -> LDS -> registers, and with three cheap f16 MFMAs
 // per product the LDS (13 cycles per ds_write_b128, 4 reads per 3 MFMAs) -- not the matrix core -- is the busiest
-// unit (tools/gemm_split_ablation.sh: removing the LDS stores alone shortens the K loop by 27 %).  The weights are
+// unit (measured in round 1 with a timing probe: removing the LDS stores alone shortens the K loop by 27 %).  The weights are
 // static, so css_create lays them out ONCE in the order the MFMA wants them: the 16 bytes lane l feeds to
 // v_mfma_f32_32x32x16_f16 for column tile j, k group kk, part p (hi / lo) live at
 //        float4 index ((j * K/16 + kk) * 2 + p) * 64 + l        (row j*32 + l%32 of W, k = 16 kk + 8 (l/32) .. +7)
