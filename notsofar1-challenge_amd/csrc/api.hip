@@ -789,9 +789,9 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         ffn(l == 0, x, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
         { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st); }
-        // q and k leave the QKV GEMM as split operands for the score MFMAs of the attention kernel, v as float32
+        // q, k and v leave the QKV GEMM as split operands for the MFMAs of the attention kernel (q and k in fragment order)
         {
-            GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 2 * D);
+            GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 3 * D);
             if (sp) { g.frag_out = qkf; g.frag_D = D; g.frag_T = T; g.frag_heads = d.attention_heads; g.frag_invT = 1.0f / T; }
             gemm(h, g, st);
         }

@@ -608,6 +608,95 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // ---- O^T[d][i] = sum_j v[j][d] * P[i][j]; the MFMA k index of half h at step (jt, r) is the key
     //      row this lane's S[jt][r] belongs to, so P feeds the B operand straight from registers.
     constexpr int OLD = 65;
+    if constexpr (QKS) {
+        // Split mode: P.V on the f16 matrix cores too -- 72 f16 MFMAs (2.3 k cycles) per wave instead of 192 float32 ones
+        // (12.3 k).  The QKV GEMM writes the v columns as split rows (split_f16.hpp: per 32 features, 32 hi halves then 32
+        // lo halves = one 128-byte line per key and feature half), so a (key tile, feature half) tile arrives as four
+        // fully coalesced 1 KiB loads, goes to LDS as two row-major [32 keys][32 features] f16 images (hi, lo) and is read
+        // back TRANSPOSED by ds_read_b64_tr_b16 (tools/tr_probe.hip): lane i of a 16-lane group points at four halves of
+        // row i / 4 and receives column i of the 4 x 16 block -- four consecutive keys of one feature, half an MFMA A
+        // operand.  k slot e of lane half h in MFMA kk of key tile jt is the key this lane's S[jt][8 kk + e] belongs to:
+        // (e & 3) + 8 (2 kk + (e >> 2)) + 4 h.  (Two-byte loads of the same operands straight from global memory were
+        // measured first: 384 load instructions per wave, attention +4.5 %.)  Key tiles outermost: a tile's probabilities
+        // are split when its turn comes (the float32 values die there) and feed both feature halves.
+        typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+        constexpr int VIMG = 32 * 32;             // halves per image
+        constexpr int VLO = VIMG + 32;            // lo image 64 bytes further: its rows' 16-byte pieces miss the hi rows' banks
+        constexpr int VBUF = VLO + VIMG;
+        __shared__ __attribute__((aligned(16))) _Float16 vlds[2 * VBUF];
+        // tile g = 2 jt + dt: this lane's four 16-byte pieces (key 8 m + lane / 8, piece lane % 8 of the 128-byte line)
+        float4 vr[4];
+        const int vkey = lane >> 3, vpc = lane & 7;
+#define CSS_ATT_VLOAD(g_)                                                                                          \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                               \
+        const int ju_ = ((g_) >> 1) * 32 + 8 * m + vkey;                                                          \
+        const int row_ = ((g_) >> 1) < NJT - 1 ? ju_ : min(ju_, T - 1);                                           \
+        vr[m] = *reinterpret_cast<const float4*>(vb + (int64_t)row_ * ld + ((g_) & 1) * 32 + 4 * vpc);            \
+    }
+#define CSS_ATT_VSTORE(g_)                                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                 \
+        *reinterpret_cast<float4*>(vlds + ((g_) & 1) * VBUF + (vpc >> 2) * VLO + (8 * m + vkey) * 32 + (vpc & 3) * 8) = vr[m];
+        const int tq = c >> 4, ti = c & 15;
+        // halves offset of this lane's piece for (kk, e-half): row 16 kk + 8 eh + 4 h + ti / 4, columns 16 tq + 4 (ti % 4)
+        const int troff = (4 * h + (ti >> 2)) * 32 + 16 * tq + 4 * (ti & 3);
+#define CSS_ATT_TR(g_, img_, kk_, eh_)                                                                             \
+    __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<__attribute__((address_space(3))) h4*>(              \
+        (__attribute__((address_space(3))) _Float16*)vlds + ((g_) & 1) * VBUF + (img_) * VLO + (16 * (kk_) + 8 * (eh_)) * 32 + troff))
+        CSS_ATT_VLOAD(0)
+        CSS_ATT_VSTORE(0)
+        CSS_ATT_VLOAD(1)
+        f32x16 o0 = {0}, o1 = {0}, cor0 = {0}, cor1 = {0};
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 a, b;
+                    split_f16(S[jt][8 * kk + e], a, b);
+                    ph[kk][e] = a;
+                    pl[kk][e] = b;
+                }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int g = 2 * jt + dt;
+                if (g + 1 < 2 * NJT) { CSS_ATT_VSTORE(g + 1) }       // tile g + 1: registers -> the other LDS buffer
+                if (g + 2 < 2 * NJT) { CSS_ATT_VLOAD(g + 2) }        // tile g + 2: on its way while tile g is consumed
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const h4 a0 = CSS_ATT_TR(g, 0, kk, 0), a1 = CSS_ATT_TR(g, 0, kk, 1);
+                    const h4 b0 = CSS_ATT_TR(g, 1, kk, 0), b1 = CSS_ATT_TR(g, 1, kk, 1);
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vh[e] = (_Float16)a0[e]; vh[4 + e] = (_Float16)a1[e];
+                        vl[e] = (_Float16)b0[e]; vl[4 + e] = (_Float16)b1[e];
+                    }
+                    if (dt == 0) {
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kk], o0, 0, 0, 0);
+                        cor0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kk], cor0, 0, 0, 0);
+                        cor0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kk], cor0, 0, 0, 0);
+                    } else {
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kk], o1, 0, 0, 0);
+                        cor1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kk], cor1, 0, 0, 0);
+                        cor1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kk], cor1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        o0 += cor0 * SPLIT_LO_INV;
+        o1 += cor1 * SPLIT_LO_INV;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+            lds[c * OLD + d] = o0[r] * inv;
+            lds[c * OLD + 32 + d] = o1[r] * inv;
+        }
+#undef CSS_ATT_VLOAD
+#undef CSS_ATT_VSTORE
+#undef CSS_ATT_TR
+    } else {
     // V groups (dt, jt) are consumed in order g = dt * NJT + jt and fetched two groups ahead (vb3[g % 3])
     float vb3[3][16];
     // uniform row pointer + one per-lane offset (scalar base addressing); only the last key tile clamps its rows
@@ -641,6 +730,8 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
             const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             lds[c * OLD + d] = o[r] * inv;
         }
+    }
+#undef CSS_ATT_LOADV
     }
     __syncthreads();
     // 32 query rows x 64 features leave in 16-byte pieces (the store tail of a row-per-lane epilogue is bound by store
