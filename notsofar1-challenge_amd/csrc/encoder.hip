@@ -412,8 +412,12 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
 // offsets a 32-query tile can see (never the reference's [T,T,64] gather), staged through LDS to
 // apply the per-row skew B[i][j] = R[i][i - j - r0].
 // ------------------------------------------------------------------------------------------------
+// Two waves per SIMD: the kernel is a chain of dependent MFMA groups, LDS round trips and loads with little to overlap
+// inside one wave, so a second resident wave is worth more than the third operand buffer it costs (NTB 3 -> 2 keeps the
+// register count at 234 for six key tiles; measured: attention 0.71 -> 0.67 ms per pass).  Eight key tiles (T up to 256)
+// would spill at that bound and keep one wave.
 template <int NJT, bool QKS, bool FRAG>
-__global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
+__global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
                                                          const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen,
                                                          int split_out) {
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // only ever needs three consecutive offset tiles, and the window slides down by one tile per key tile, so
     // the ring replaces the full [32][217] table (29 KB, 5 waves per CU) by 12.5 KB (register-limited 8 per CU).
     constexpr int LDR = 98;
-    __shared__ float lds[32 * LDR];
+    __shared__ __attribute__((aligned(16))) float lds[32 * LDR];
     const int qt = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const int ld = 3 * D;
@@ -491,10 +495,9 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
     // whole tile schedule static (a run-time RT0 tripled the code size through duplicated branches).
     constexpr int RT0 = NJT;
     // Operand tiles are consumed in a fixed order -- offset tiles RT0, RT0-1, RT0-2, then key tile jt followed by
-    // offset tile RT0-3-jt while that exists -- and fetched TWO steps ahead into three rotating register buffers
-    // (tb[step % 3]; `step` is a compile-time constant after unrolling, so no copies: the earlier cur = nxt copy made
-    // the wave wait for a tile one step after requesting it, and with one wave per SIMD the L2 latency of every one
-    // of the 2 NJT + 1 tiles was exposed).
+    // offset tile RT0-3-jt while that exists -- and fetched one step ahead into two rotating register buffers
+    // (tb[step % NTB]; `step` is a compile-time constant after unrolling, so no copies).  With one wave per SIMD the
+    // tiles were fetched two steps ahead into three buffers; the second resident wave now covers the L2 latency.
     // A one-tile segment (T <= 32, NJT = 1) sees only the offset tiles 1 and 0 (offsets below -(T - 1) belong to masked
     // keys), so its prologue has two offset tiles, not three: NPRO offset tiles, then NJT key tiles with NI offset tiles
     // interleaved.
@@ -522,15 +525,16 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
             CSS_ATT_LOAD8(dst, k_row(step_jt(s_)))                                                         \
         }                                                                                                  \
     }
-    float4 tb[3][8];
+    constexpr int NTB = 2;   // operand buffers: tile step + NTB - 1 is requested while tile step is consumed
+    float4 tb[NTB][8];
     f32x16 S[NJT];
     int step = 0;
 #define CSS_ATT_STEP(acc)                                                                                  \
     {                                                                                                      \
-        if (step + 2 < NS) { CSS_ATT_LOAD_STEP(tb[(step + 2) % 3], min(step + 2, NS - 1)) }                \
+        if (step + NTB - 1 < NS) { CSS_ATT_LOAD_STEP(tb[(step + NTB - 1) % NTB], min(step + NTB - 1, NS - 1)) } \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the MFMAs (the scheduler sinks it) */ \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                       \
-        CSS_ATT_MFMA32(acc, tb[step % 3])                                                                  \
+        CSS_ATT_MFMA32(acc, tb[step % NTB])                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         ++step;                                                                                            \
     }
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
             lds[c * LDR + slot_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];             \
     }
     CSS_ATT_LOAD_STEP(tb[0], 0)
-    CSS_ATT_LOAD_STEP(tb[1], 1)
+    if constexpr (NTB > 2) { CSS_ATT_LOAD_STEP(tb[1], 1) }
 #pragma unroll
     for (int u = 0; u < NPRO; ++u) {
         const int rt = RT0 - u;
@@ -623,7 +627,10 @@ __global__ __launch_bounds__(64) void relpos_attn_kernel(const float* __restrict
         constexpr int VIMG = 32 * 32;             // halves per image
         constexpr int VLO = VIMG + 32;            // lo image 64 bytes further: its rows' 16-byte pieces miss the hi rows' banks
         constexpr int VBUF = VLO + VIMG;
-        __shared__ __attribute__((aligned(16))) _Float16 vlds[2 * VBUF];
+        // the two tile buffers live where the position ring was (its last reader is behind the barrier above; the output
+        // tile goes there again after the last tile has been read)
+        static_assert(2 * VBUF * sizeof(_Float16) <= sizeof(lds), "V tile buffers must fit in the ring");
+        _Float16* vlds = reinterpret_cast<_Float16*>(lds);
         // tile g = 2 jt + dt: this lane's four 16-byte pieces (key 8 m + lane / 8, piece lane % 8 of the 128-byte line)
         float4 vr[4];
         const int vkey = lane >> 3, vpc = lane & 7;
