@@ -11,7 +11,7 @@ using namespace css;
 int main(int argc, char** argv) {
     struct Shape { int N, K; const char* name; int res; };
     Shape shapes[] = {{1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 512, "attn-out", 1}};
-    int Ms[] = {5022, 2604, 11904, 5952};
+    int Ms[] = {7440, 2480, 22506, 7502};   // 40 segments on one lane / per lane of three; 121 segments likewise
     int tiles[] = {32, 64, 96, 128};
     size_t maxe = 24000ull * 1536;
     float *A, *B, *Bt, *As, *C[2], *R;
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
                 go(3); hipDeviceSynchronize();
                 hipEventRecord(e0, st[0]);
                 if (dual) hipStreamWaitEvent(st[1], e0, 0);
+                // (dual = 2: three streams would need a third; two are enough to see blocks of different launches share CUs)
                 go(it);
                 if (dual) { hipEventRecord(ej, st[1]); hipStreamWaitEvent(st[0], ej, 0); }
                 hipEventRecord(e1, st[0]); hipEventSynchronize(e1);
