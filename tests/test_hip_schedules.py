@@ -1,0 +1,83 @@
+"""Every way the library schedules one meeting must give the same bits: the host -> host unit pipeline (css_run), the
+plain stage sequence and the unit pipeline on resident samples (css_run_device), the sharded driver for several virtual
+ranks (full and own-range results, samples uploaded whole or piece by piece) -- over seeded random meeting lengths,
+batch sizes and lane counts, ragged tails included.  A 2-block model keeps it to seconds.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from test_hip_parity import virtual_rank_run
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(3.02, 64, 3), (3.6, 64, 3), (7.7, 4, 2), (11.3, 64, 3), (19.01, 5, 3), (26.5, 7, 4), (33.3, 64, 1), (47.9, 16, 3),
+         (61.7, 13, 2), (95.2, 32, 3)]
+
+
+@pytest.fixture(scope="module")
+def model():
+    W = pkg("weights")
+    desc = W.ModelDesc(num_blocks=2)
+    return W.apply_golden_recipe(W.portable_state_dict(desc, 21)), desc
+
+
+@pytest.mark.parametrize("seconds,max_batch,lanes", CASES)
+def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes):
+    import torch
+    L, CSS, PAR = pkg("_lib"), pkg("css"), pkg("parallel")
+    st, desc = model
+    mix = pkg("synth").synth_meeting(seconds, 7, seed=int(seconds * 10))
+    n = mix.shape[1] - (int(seconds * 1000) % 200)          # ragged: not a whole number of frames
+    pcm = np.ascontiguousarray(mix[0, :n])
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch)
+    try:
+        h = sep.handle
+        h.set_lanes(lanes)
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+        plan = L.plan(desc, run_cfg, n)
+        ref = h.run(pcm, run_cfg).copy()                                         # pageable host memory
+        assert np.isfinite(ref).all() and ref.shape == (3, plan.n_out)
+        pin, out = L.pinned_copy(pcm), L.pinned_empty((3, int(plan.n_out)), np.float32)
+        assert np.array_equal(h.run(pin, run_cfg, out=out), ref)                 # page-locked: asynchronous PCIe legs
+        pd = torch.from_numpy(pcm).cuda()
+        wd = torch.empty((3, int(plan.n_out)), dtype=torch.float32, device="cuda")
+        for pipelined in (0, 1):
+            h.set_tuning("pipeline_device", pipelined)
+            wd.zero_()
+            h.run_device(pd.data_ptr(), n, 7, run_cfg, wd.data_ptr(), int(plan.n_out))
+            torch.cuda.synchronize()
+            assert np.array_equal(wd.cpu().numpy(), ref), ("css_run_device", pipelined)
+        h.set_tuning("pipeline_device", 0)
+        for tail_per_unit, pieces in ((1, 1), (0, 2)):
+            h.set_tuning("tail_per_unit", tail_per_unit)
+            h.set_tuning("tail_pieces", pieces)
+            assert np.array_equal(h.run(pin, run_cfg, out=out), ref), ("tuning", tail_per_unit, pieces)
+        h.set_tuning("tail_per_unit", 0)
+        h.set_tuning("tail_pieces", 1)
+        nseg = int(plan.num_segments)
+        for world in sorted({2, min(3, nseg), min(5, nseg)}):
+            if world < 2:
+                continue
+            assert np.array_equal(virtual_rank_run(PAR, L, h, pcm, run_cfg, world), ref), world    # full and own-range
+        # one rank of two with its samples arriving in pieces (copy stream) under the stages of the earlier pieces
+        if nseg >= 6:
+            dev = torch.device("cuda", 0)
+            be = PAR.HipShardBackend(h, dev)
+            me = PAR.make_shard_plan(nseg, int(plan.mix_frames), int(plan.stft_frames), 186, 93, 256, 1, 2)
+            lo, hi = me.pcm_range(512, n)
+            groups, cuts = PAR.upload_schedule(me, 186, 93, 512, n, first=2, growth=2)
+            h.run(np.ascontiguousarray(pcm[::-1]), run_cfg)                      # other samples in the device copy
+            piece = L.pinned_copy(np.ascontiguousarray(pcm[lo:hi]))
+            be.begin(piece, n, 7, run_cfg, sample_range=(lo, hi), slice_only=True, cuts=cuts)
+            ss = PAR.ShardedSession(be, 3, 186, 93, 256, 1, 2, groups)
+            ss.segments_and_costs()
+            with be.on_stream():
+                masks_piecewise = h.read(L.BUF_MASKS).copy()
+            be.begin(piece, n, 7, run_cfg, sample_range=(lo, hi), slice_only=True)
+            PAR.ShardedSession(be, 3, 186, 93, 256, 1, 2).segments_and_costs()
+            masks_whole = h.read(L.BUF_MASKS)
+            cols = slice(me.seg_lo * 186, me.seg_hi * 186)
+            assert np.array_equal(masks_piecewise[:, cols], masks_whole[:, cols])
+            be.close()
+    finally:
+        sep.close()
