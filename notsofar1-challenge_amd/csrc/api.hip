@@ -119,6 +119,10 @@ struct css_ctx {
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
     // the handle's stream wait for exactly the pieces its frames read
+    // css_run_enqueue / css_wait: passes enqueued and not yet waited for; `lanes_done` marks the end of the last one's
+    // per-segment work (what another handle's queued pass may be told to start behind)
+    int queued = 0;
+    hipEvent_t lanes_done = nullptr;
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
     std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -515,6 +519,7 @@ int css_destroy(css_handle_t h) {
         if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->lanes_done) hipEventDestroy(h->lanes_done);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); hipStreamDestroy(h->tail_stream); }
     if (h->range_flag_dev) hipFree(h->range_flag_dev);
@@ -590,7 +595,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if ((rc = ensure(h, h->buf, (size_t)(bytes), ##__VA_ARGS__)) != CSS_OK) return rc;
     hipEventRecord(h->ev[0], h->stream);
     HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));
+    if (!h->queued) HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));   // queued passes accumulate
     ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
     ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
     if ((rc = ensure_activations(h, std::min<int64_t>(h->max_batch, nseg), T)) != CSS_OK) return rc;
@@ -1103,6 +1108,8 @@ struct RunIo {
     int16_t* wav16_host = nullptr;               // [S][cap] peak-normalised PCM16
     float* peaks_host = nullptr;
     int64_t cap = 0;
+    bool enqueue_only = false;                   // css_run_enqueue: return once everything is on the streams
+    hipEvent_t after = nullptr;                  // the segments' kernels start behind this event (another handle's lanes)
 };
 
 // device address of page-locked (hipHostMalloc / css_host_alloc / registered) host memory, nullptr for pageable memory
@@ -1375,6 +1382,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         HIPCHK(h, hipEventRecord(u->m, st));
         return CSS_OK;
     };
+    if (io.after) HIPCHK(h, hipStreamWaitEvent(h->stream, io.after, 0));   // (the uploads above do not wait for it)
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         first = ui;
         if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post)) != CSS_OK) return rc;
@@ -1388,6 +1396,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     h->stft_done = h->perms_done = true;
     hipEventRecord(h->ev[3], h->stream);
     hipEventRecord(h->ev[4], h->stream);
+    if (h->lanes_done) HIPCHK(h, hipEventRecord(h->lanes_done, h->stream));
     // ---- join: the main stream continues after the tail (and the last download)
     hipEvent_t tail_done = pool_event(h);
     HIPCHK(h, hipEventRecord(tail_done, h->tail_stream));
@@ -1406,6 +1415,11 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     if (out_done) HIPCHK(h, hipStreamWaitEvent(h->stream, out_done, 0));
     hipEventRecord(h->ev[7], h->stream);
     const auto host_t1 = std::chrono::steady_clock::now();
+    if (io.enqueue_only) {   // css_wait synchronises, reads the range word and the timings of the last queued pass
+        h->queued += 1;
+        HIPCHK(h, hipGetLastError());
+        return CSS_OK;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     const auto host_t2 = std::chrono::steady_clock::now();
@@ -1415,7 +1429,9 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
 // The pass, and -- when an operand left the split-f16 range (a split GEMM saw a non-finite accumulator) -- the same pass
 // again on the exact float32 kernels (css_set_range_fallback(h, 0): CSS_ERR_RANGE instead).
 static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
-    int rc = run_once(h, n, n_ch, cfg, io);
+    int rc;
+    if (h && h->queued && (rc = css_wait(h)) != CSS_OK) return rc;   // queued passes first (and their range verdict)
+    rc = run_once(h, n, n_ch, cfg, io);
     if (rc != CSS_OK) return rc;
     h->range_last = 0;
     if (!*h->range_flag_host || !h->split) return CSS_OK;
@@ -1436,6 +1452,37 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
     if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap;
     return run_impl(h, n_samples, n_ch, cfg, io);
+}
+
+int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                    float* wav_host, int64_t cap, css_handle_t after) {
+    if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (after == h) return fail(h, CSS_ERR_INVALID_ARG, "a handle's own passes are ordered anyway: pass another handle or NULL");
+    if (after && after->device != h->device) return fail(h, CSS_ERR_INVALID_ARG, "`after` lives on another device");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->lanes_done) HIPCHK(h, hipEventCreateWithFlags(&h->lanes_done, hipEventDisableTiming));
+    RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
+    io.after = (after && after->queued > 0) ? after->lanes_done : nullptr;
+    return run_once(h, n_samples, n_ch, cfg, io);
+}
+
+int css_wait(css_handle_t h) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (!h->queued) return CSS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    h->queued = 0;
+    finish_timings(h, t0, t0, t1, false);
+    h->range_last = 0;
+    if (*h->range_flag_host && h->split) {   // the inputs are the caller's: nothing to repeat here
+        h->range_last = 1;
+        return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range in one of the queued passes: "
+                                      "repeat them with css_run (automatic float32 repeat) or in CSS_LINEAR_EXACT_F32");
+    }
+    return CSS_OK;
 }
 
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,

@@ -1,0 +1,19 @@
+import glob, os, sys
+import pandas as pd
+d = sys.argv[1]
+kt = pd.read_csv(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0])
+_m = glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True)
+mc = pd.read_csv(_m[0]) if _m else pd.DataFrame(columns=["Start_Timestamp", "End_Timestamp", "Direction"])
+kt["name"] = kt["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("css::", "").str.replace(r"<.*", "", regex=True).str.replace("void ", "")
+end = kt["End_Timestamp"].max()
+t0 = end - 22_000_000   # last 22 ms
+k = kt[kt["Start_Timestamp"] >= t0]; m = mc[mc["Start_Timestamp"] >= t0]
+rel = lambda x: (x - t0) / 1e3
+print("copies:")
+for _, r in m.sort_values("Start_Timestamp").iterrows():
+    print(f"  {r['Direction'][12:]:16s} {rel(r['Start_Timestamp']):9.1f} -> {rel(r['End_Timestamp']):9.1f}")
+print("markers per queue (features = start of a lane chain, wave_ola = end of a tail):")
+for q, g in k.groupby("Queue_Id"):
+    g = g.sort_values("Start_Timestamp")
+    marks = g[g["name"].isin(["features_kernel", "wave_ola_kernel", "stft_fft_kernel", "beamform_kernel"])]
+    print(f" queue {q}: {len(g)} kernels;", " ".join(f"{r['name'][:4]}@{rel(r['Start_Timestamp']):.0f}" for _, r in marks.iterrows()))
