@@ -203,15 +203,14 @@ int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, in
 int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
             float* wav_host, int64_t wav_capacity_per_stream);
 /* A queue of sessions: css_run without the closing host synchronisation.  The call returns once the pass is on the
- * handle's streams; pcm_host must stay valid and wav_host untouched until css_wait(h) returns.  Passes queued on ONE handle
- * run one after the other.  With TWO handles used in turn (own buffers, so nothing of one session can be overwritten by
- * the next), `after` = the other handle makes this pass's per-segment kernels start when that handle's last queued pass
- * has finished its own -- while this pass's samples are already crossing PCIe and the other's stitching, synthesis and
- * download still run: both PCIe legs of a session hide under its neighbours' kernels (tests/test_hip_session.py,
- * bench.py "queued_sessions").  No automatic float32 repeat here: css_wait returns CSS_ERR_RANGE if a queued pass left the
- * split-f16 range (css_set_range_fallback does not apply).  `after` may be NULL. */
+ * handle's streams; pcm_host must stay valid and wav_host untouched until css_wait(h) returns.  With page-locked buffers
+ * (css_host_alloc) consecutive queued passes OVERLAP: pass P's samples cross PCIe (into the half of the sample buffer the
+ * pass before last used) while pass P - 1's estimator runs, and P - 1's stitching, synthesis and download (zero-copy
+ * into wav_host) run beside P's estimator -- both PCIe legs of a session hide under its neighbours' kernels, results bit
+ * for bit those of css_run (tests/test_hip_session.py, bench.py).  With pageable output the passes simply queue up.
+ * No automatic float32 repeat here: css_wait returns CSS_ERR_RANGE if a queued pass left the split-f16 range. */
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
-                    float* wav_host, int64_t cap, css_handle_t after);
+                    float* wav_host, int64_t cap);
 /* Blocks until every pass queued on h has finished (results in their wav_host buffers); CssTimings describe the last. */
 int css_wait(css_handle_t h);
 /* Same with input and output resident in HBM (pcm_dev [n_samples][n_ch], wav_dev [S][n_out]). */

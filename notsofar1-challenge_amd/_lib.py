@@ -87,7 +87,7 @@ SIGNATURES = {
     "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
     "css_pit_scan": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
-    "css_run_enqueue": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
+    "css_run_enqueue": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_wait": (C.c_int, [_P]),
     "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
@@ -325,19 +325,18 @@ class Handle:
         check(self.h, self.lib.css_run(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), out.strides[0] // 4))
         return out[:, :p.n_out]
 
-    def run_enqueue(self, pcm: np.ndarray, cfg: RunCfg, out: np.ndarray, after: Optional["Handle"] = None) -> np.ndarray:
-        """css_run without the closing synchronisation (a queue of sessions): `pcm` (float32 [n, C], C-contiguous,
-        ideally page-locked) must stay alive and `out` untouched until wait().  `after`: another handle whose last queued
-        pass's per-segment kernels this pass's start behind (two handles used in turn hide each session's PCIe legs under
-        its neighbours' kernels).  Returns the view of `out` that wait() makes valid."""
+    def run_enqueue(self, pcm: np.ndarray, cfg: RunCfg, out: np.ndarray) -> np.ndarray:
+        """css_run without the closing synchronisation (a queue of sessions): `pcm` (float32 [n, C], C-contiguous) must
+        stay alive and `out` untouched until wait().  With page-locked buffers (pinned_empty / pinned_copy) consecutive
+        queued passes overlap: a session's PCIe legs hide under its neighbours' kernels.  Returns the view of `out` that
+        wait() makes valid."""
         assert pcm.dtype == np.float32 and pcm.flags.c_contiguous and pcm.ndim == 2
         n, c = pcm.shape
         p = plan(self.desc, cfg, n)
         assert out.dtype == np.float32 and out.ndim == 2 and out.shape[0] == self.desc.num_spks and out.shape[1] >= p.n_out \
             and out.strides[1] == 4
         self._queued_keep = getattr(self, "_queued_keep", []) + [(pcm, out, cfg)]
-        check(self.h, self.lib.css_run_enqueue(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), out.strides[0] // 4,
-                                               after.h if after is not None else None))
+        check(self.h, self.lib.css_run_enqueue(self.h, _np_ptr(pcm), n, c, C.byref(cfg.c), _np_ptr(out), out.strides[0] // 4))
         return out[:, :p.n_out]
 
     def wait(self):

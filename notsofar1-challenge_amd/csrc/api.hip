@@ -119,10 +119,16 @@ struct css_ctx {
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
     // the handle's stream wait for exactly the pieces its frames read
-    // css_run_enqueue / css_wait: passes enqueued and not yet waited for; `lanes_done` marks the end of the last one's
-    // per-segment work (what another handle's queued pass may be told to start behind)
+    // css_run_enqueue / css_wait: passes enqueued and not yet waited for
     int queued = 0;
-    hipEvent_t lanes_done = nullptr;
+    // queued passes overlap: pass P's samples cross PCIe while pass P - 1's kernels run, and P - 1's stitching / synthesis /
+    // download run beside P's estimator.  The sample buffer and the level word alternate (pass parity); `pcm_free[b]` =
+    // the last transform of the pass that used sample buffer b; `tail_end` = the end of the last queued pass's tail
+    int64_t pass_no = 0;
+    hipEvent_t pcm_free[2] = {nullptr, nullptr};
+    hipEvent_t tail_end = nullptr;
+    bool tail_pending = false;
+    bool piped_now = false;   // run_once -> begin_impl: the level word is cleared on the copy stream, not here
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
     std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -519,7 +525,8 @@ int css_destroy(css_handle_t h) {
         if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->lanes_done) hipEventDestroy(h->lanes_done);
+    if (h->tail_end) hipEventDestroy(h->tail_end);
+    for (auto& e : h->pcm_free) if (e) hipEventDestroy(e);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); hipStreamDestroy(h->tail_stream); }
     if (h->range_flag_dev) hipFree(h->range_flag_dev);
@@ -594,7 +601,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
 #define ENS(buf, bytes, ...)                                              \
     if ((rc = ensure(h, h->buf, (size_t)(bytes), ##__VA_ARGS__)) != CSS_OK) return rc;
     hipEventRecord(h->ev[0], h->stream);
-    HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
+    if (!h->piped_now) HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
     if (!h->queued) HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));   // queued passes accumulate
     ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
     ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
@@ -630,7 +637,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
 static int upload_pcm(css_handle_t h, const float* pcm_host, int64_t s_lo, int64_t s_hi, hipStream_t st) {
     if (s_hi <= s_lo) return CSS_OK;
     const size_t row = (size_t)h->n_ch * sizeof(float);
-    HIPCHK(h, hipMemcpyAsync((char*)h->pcm_in.p + (size_t)s_lo * row, (const char*)pcm_host + (size_t)s_lo * row,
+    HIPCHK(h, hipMemcpyAsync((char*)const_cast<float*>(h->pcm_src) + (size_t)s_lo * row, (const char*)pcm_host + (size_t)s_lo * row,
                              (size_t)(s_hi - s_lo) * row, hipMemcpyHostToDevice, st));
     return CSS_OK;
 }
@@ -653,8 +660,8 @@ int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     int rc = begin_impl(h, n_samples, n_ch, cfg);
     if (rc != CSS_OK) return rc;
     if ((rc = ensure(h, h->pcm_in, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
-    if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->stream)) != CSS_OK) return rc;
     h->pcm_src = (const float*)h->pcm_in.p;
+    if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->stream)) != CSS_OK) return rc;
     launch_pcm_peak_f32(h->pcm_src + s_lo * n_ch, (s_hi - s_lo) * n_ch, h->peak_dev, h->stream);
     hipEventRecord(h->ev[1], h->stream);
     HIPCHK(h, hipGetLastError());
@@ -866,7 +873,8 @@ static int64_t batch_len(int64_t n, int64_t cap) {
 // the fused path puts the analysis transform of the frames that lane is the first to read there (run_impl).
 using LanePrep = std::function<int(int64_t, int, hipStream_t)>;
 using LanePost = LanePrep;   // post(first segment, count, stream): enqueued at the END of each lane's chain
-static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const LanePrep& prep, const LanePost& post) {
+static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const LanePrep& prep, const LanePost& post,
+                         hipEvent_t before_head = nullptr) {
     const int L = h->d.num_blocks;
     const int sp = h->split ? 1 : 0;
     int rc;
@@ -879,7 +887,13 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
     const LaneSplit ls = lane_split(h, nb);
     if (ls.nl == 1) {
         if ((rc = prep(s0, nb, h->stream)) != CSS_OK) return rc;
-        if ((rc = masknet_lane(h, io, s0, nb, 0, -1, L + 1)) != CSS_OK) return rc;
+        if (before_head) {   // the mask head and what follows write buffers an earlier pass's tail may still read
+            if ((rc = masknet_lane(h, io, s0, nb, 0, -1, L)) != CSS_OK) return rc;
+            HIPCHK(h, hipStreamWaitEvent(h->stream, before_head, 0));
+            if ((rc = masknet_lane(h, io, s0, nb, 0, L, L + 1)) != CSS_OK) return rc;
+        } else if ((rc = masknet_lane(h, io, s0, nb, 0, -1, L + 1)) != CSS_OK) {
+            return rc;
+        }
         return post(s0, nb, h->stream);
     }
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));    // everything the estimator reads is ordered before this
@@ -892,6 +906,7 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
     for (int ph = -1; ph <= L; ++ph)
         for (int l = 0; l < ls.nl; ++l) {
             const int lo = l * ls.per, n = std::min(ls.per, nb - lo);
+            if (n > 0 && ph == L && before_head) HIPCHK(h, hipStreamWaitEvent(l ? h->lane_stream[l] : h->stream, before_head, 0));
             if (n > 0 && (rc = masknet_lane(h, io, s0 + lo, n, l, ph, ph + 1, true)) != CSS_OK) return rc;
         }
     for (int l = 0; l < ls.nl; ++l) {
@@ -1109,7 +1124,6 @@ struct RunIo {
     float* peaks_host = nullptr;
     int64_t cap = 0;
     bool enqueue_only = false;                   // css_run_enqueue: return once everything is on the streams
-    hipEvent_t after = nullptr;                  // the segments' kernels start behind this event (another handle's lanes)
 };
 
 // device address of page-locked (hipHostMalloc / css_host_alloc / registered) host memory, nullptr for pageable memory
@@ -1167,7 +1181,20 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     int rc;
     if (!h) return CSS_ERR_INVALID_ARG;
     const auto host_t0 = std::chrono::steady_clock::now();
-    if ((rc = begin_impl(h, n, n_ch, cfg)) != CSS_OK) return rc;
+    // page-locked output (css_host_alloc): its device address, for the zero-copy output path
+    float* wav_mapped = nullptr;
+    if (io.wav_host && (h->tune[CSS_TUNE_OUT_MAPPED] || io.enqueue_only)) {
+        if (h->mapped_key != io.wav_host) { h->mapped_key = io.wav_host; h->mapped_val = mapped_host(io.wav_host); }
+        wav_mapped = (float*)h->mapped_val;
+    }
+    // queued passes OVERLAP when the output is page-locked (see css_ctx::pass_no); otherwise they just queue up
+    const bool piped = io.enqueue_only && io.pcm_host && wav_mapped;
+    const int par = piped ? (int)(h->pass_no & 1) : 0;
+    h->peak_dev = (unsigned int*)h->level.p + 8 * par;
+    h->piped_now = piped;
+    rc = begin_impl(h, n, n_ch, cfg);
+    h->piped_now = false;
+    if (rc != CSS_OK) return rc;
     const CssPlan& pl = h->plan;
     if (io.cap < pl.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(pl.n_out) + " samples per stream");
     const int64_t nseg = pl.num_segments, TL = pl.mix_frames;
@@ -1176,8 +1203,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     const bool from_host = io.pcm_host || io.planes_host;
     h->ev_pool_used = 0;
     if (io.pcm_host) {
-        if ((rc = ensure(h, h->pcm_in, (size_t)n * n_ch * sizeof(float))) != CSS_OK) return rc;
-        h->pcm_src = (const float*)h->pcm_in.p;
+        const size_t need = ((size_t)n * n_ch * sizeof(float) + 255) / 256 * 256;
+        if ((rc = ensure(h, h->pcm_in, piped ? 2 * need : need)) != CSS_OK) return rc;
+        // (queued passes alternate between the two halves of the allocation, whatever their lengths)
+        h->pcm_src = (const float*)((const char*)h->pcm_in.p + (piped && par ? h->pcm_in.cap / 2 / 256 * 256 : 0));
     } else if (io.planes_host) {
         if ((rc = ensure(h, h->in16, (size_t)n * n_ch * sizeof(int16_t))) != CSS_OK) return rc;
         for (int c = 0; c < n_ch; ++c)
@@ -1239,10 +1268,20 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         }
     }
     // ---- everything starts after whatever the previous pass left on the three streams
-    hipEvent_t start = pool_event(h);
-    HIPCHK(h, hipEventRecord(start, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, start, 0));
-    HIPCHK(h, hipStreamWaitEvent(h->tail_stream, start, 0));
+    if (!piped) {
+        hipEvent_t start = pool_event(h);
+        HIPCHK(h, hipEventRecord(start, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, start, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, start, 0));
+    } else {
+        // the samples go into the buffer the pass before last used: free once that pass has transformed its frames; the
+        // level word of this parity is cleared here, in front of the pieces' peak scans (each stream is in order in itself)
+        for (int b = 0; b < 2; ++b)
+            if (!h->pcm_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcm_free[b], hipEventDisableTiming));
+        if (!h->tail_end) HIPCHK(h, hipEventCreateWithFlags(&h->tail_end, hipEventDisableTiming));
+        if (h->pass_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->pcm_free[par], 0));
+        HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->copy_stream));
+    }
     // ---- PCIe pieces, in unit order, on the copy stream
     if (from_host) {
         for (const Unit& u : units) {
@@ -1277,11 +1316,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // page-locked output: the overlap-add of the synthesis writes the samples straight into the caller's buffer over
     // PCIe (no device-side copy of the waveforms, no copy call: the runtime's device-to-host copies made the host wait
     // for the events they depend on); pageable output: into the device buffer, then a copy
-    float* wav_mapped = nullptr;
-    if (io.wav_host && h->tune[CSS_TUNE_OUT_MAPPED]) {
-        if (h->mapped_key != io.wav_host) { h->mapped_key = io.wav_host; h->mapped_val = mapped_host(io.wav_host); }
-        wav_mapped = (float*)h->mapped_val;
-    }
+    if (!piped && !h->tune[CSS_TUNE_OUT_MAPPED]) wav_mapped = nullptr;
     // (one tail per BATCH, not per unit: these kernels are latency-bound chains of small launches -- a third of the
     // frames takes the same ~120 us -- and the lanes of a batch finish together, so per-unit tails only queue up)
     auto tail_of = [&](size_t k0, size_t k1) -> int {   // units [k0, k1)
@@ -1315,7 +1350,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
                 const int64_t q_hi = (g_hi == TL) ? TL + 1 : g_hi;   // the last range also writes the tail half-frame
                 const int64_t f_lo = std::max<int64_t>(g_done - 1, 0);
                 istft_gemm_on(h, f_lo, g_hi, ts);
-                if (wav_mapped) {   // the PCIe-bound overlap-add goes to the copy stream: the next piece's kernels run beside it
+                if (wav_mapped && piped) {   // (the copy stream belongs to the NEXT pass's samples by now)
+                    wave_ola_on(h, f_lo, g_hi, g_done, q_hi, wav_mapped, io.cap, 0, ts);
+                    hipEventRecord(h->ev[6], ts);
+                } else if (wav_mapped) {   // the PCIe-bound overlap-add goes to the copy stream: the next piece's kernels run beside it
                     hipEvent_t done = pool_event(h);
                     HIPCHK(h, hipEventRecord(done, ts));
                     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, done, 0));
@@ -1382,10 +1420,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         HIPCHK(h, hipEventRecord(u->m, st));
         return CSS_OK;
     };
-    if (io.after) HIPCHK(h, hipStreamWaitEvent(h->stream, io.after, 0));   // (the uploads above do not wait for it)
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         first = ui;
-        if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post)) != CSS_OK) return rc;
+        if ((rc = masknet_batch(h, mio, s0, (int)std::min<int64_t>(cap, nseg - s0), prep, post,
+                                (piped && h->tail_pending && s0 == 0) ? h->tail_end : nullptr)) != CSS_OK) return rc;
         if (h->tune[CSS_TUNE_TAIL_PER_UNIT]) {
             for (size_t k = first; k < ui; ++k)
                 if ((rc = tail_of(k, k + 1)) != CSS_OK) return rc;
@@ -1396,7 +1434,16 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     h->stft_done = h->perms_done = true;
     hipEventRecord(h->ev[3], h->stream);
     hipEventRecord(h->ev[4], h->stream);
-    if (h->lanes_done) HIPCHK(h, hipEventRecord(h->lanes_done, h->stream));
+    if (piped) {   // no join: the next queued pass's estimator runs beside this pass's tail; css_wait waits for all streams
+        HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
+        HIPCHK(h, hipEventRecord(h->tail_end, h->tail_stream));
+        hipEventRecord(h->ev[7], h->tail_stream);
+        h->tail_pending = true;
+        h->pass_no += 1;
+        h->queued += 1;
+        HIPCHK(h, hipGetLastError());
+        return CSS_OK;
+    }
     // ---- join: the main stream continues after the tail (and the last download)
     hipEvent_t tail_done = pool_event(h);
     HIPCHK(h, hipEventRecord(tail_done, h->tail_stream));
@@ -1455,14 +1502,9 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
 }
 
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
-                    float* wav_host, int64_t cap, css_handle_t after) {
+                    float* wav_host, int64_t cap) {
     if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
-    if (after == h) return fail(h, CSS_ERR_INVALID_ARG, "a handle's own passes are ordered anyway: pass another handle or NULL");
-    if (after && after->device != h->device) return fail(h, CSS_ERR_INVALID_ARG, "`after` lives on another device");
-    HIPCHK(h, hipSetDevice(h->device));
-    if (!h->lanes_done) HIPCHK(h, hipEventCreateWithFlags(&h->lanes_done, hipEventDisableTiming));
     RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
-    io.after = (after && after->queued > 0) ? after->lanes_done : nullptr;
     return run_once(h, n_samples, n_ch, cfg, io);
 }
 
@@ -1472,9 +1514,15 @@ int css_wait(css_handle_t h) {
     HIPCHK(h, hipSetDevice(h->device));
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->tail_stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    HIPCHK(h, hipMemcpy(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost));
     HIPCHK(h, hipGetLastError());
     const auto t1 = std::chrono::steady_clock::now();
     h->queued = 0;
+    h->tail_pending = false;
+    h->pass_no = 0;
+    h->peak_dev = (unsigned int*)h->level.p;
     finish_timings(h, t0, t0, t1, false);
     h->range_last = 0;
     if (*h->range_flag_host && h->split) {   // the inputs are the caller's: nothing to repeat here

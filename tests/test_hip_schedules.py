@@ -81,3 +81,39 @@ def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes):
             be.close()
     finally:
         sep.close()
+
+
+@pytest.mark.parametrize("lanes,max_batch,pinned", [(3, 64, True), (2, 7, True), (1, 64, True), (3, 16, False)])
+def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinned):
+    """css_run_enqueue / css_wait: sessions of different lengths and contents queued back to back (page-locked buffers:
+    neighbouring passes overlap -- uploads under the previous estimator, stitching / synthesis / download beside the next
+    one; pageable output: the passes just queue up) give, each, the bits of its own synchronous css_run."""
+    L, CSS = pkg("_lib"), pkg("css")
+    st, desc = model
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch)
+    try:
+        h = sep.handle
+        h.set_lanes(lanes)
+        sessions = []
+        for k, seconds in enumerate([19.0, 33.3, 7.7, 33.3, 61.7, 3.6, 47.9, 19.0]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=100 + k)
+            pcm = np.ascontiguousarray(mix[0, :mix.shape[1] - 37 * k])
+            ref = h.run(pcm, run_cfg).copy()
+            sessions.append((pcm, ref))
+        for rounds in range(2):   # twice: the second queue starts on buffers the first one left behind
+            queued = []
+            for pcm, ref in sessions:
+                src = L.pinned_copy(pcm) if pinned else pcm
+                out = L.pinned_empty(ref.shape, np.float32) if pinned else np.empty(ref.shape, np.float32)
+                out[:] = np.nan
+                queued.append((h.run_enqueue(src, run_cfg, out), ref, src))
+            h.wait()
+            for k, (got, ref, _) in enumerate(queued):
+                assert np.array_equal(got, ref), (rounds, k)
+        # a synchronous call with passes still queued waits for them first
+        got0 = h.run_enqueue(L.pinned_copy(sessions[0][0]), run_cfg, L.pinned_empty(sessions[0][1].shape, np.float32))
+        assert np.array_equal(h.run(sessions[1][0], run_cfg), sessions[1][1])
+        assert np.array_equal(got0, sessions[0][1])
+    finally:
+        sep.close()

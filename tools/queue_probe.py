@@ -15,6 +15,8 @@ mix = SYN.synth_meeting(seconds, 7, seed=1); n = mix.shape[1]
 run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
 seps = [SEP.HipSeparator(state, None, device=0, max_batch_segments=128) for _ in range(2)]
 hs = [s.handle for s in seps]
+if os.environ.get('LANES'):
+    for h in hs: h.set_lanes(int(os.environ['LANES']))
 plan = L.plan(desc, run_cfg, n)
 pcm = L.pinned_copy(np.ascontiguousarray(mix[0]))
 outs = [L.pinned_empty((3, int(plan.n_out)), np.float32) for _ in range(2)]
@@ -46,5 +48,6 @@ print(f"  css_run_device (resident), one handle   : {timed(dev_run):.3f}")
 print(f"  css_run_enqueue, one handle             : {timed(lambda: queued(False)):.3f}")
 print(f"  css_run_enqueue, two handles, unchained : {timed(lambda: queued(True, False)):.3f}")
 print(f"  css_run_enqueue, two handles in turn    : {timed(lambda: queued(True, True)):.3f}")
+queued(False)
 print("  results equal the synchronous pass:", all(np.array_equal(o[:, :plan.n_out], ref) for o in outs))
 for s in seps: s.close()
