@@ -8,7 +8,9 @@
 One "step" = one pass of the CSS hot path (css/css.py::separate_and_stitch equivalent: STFT -> Conformer mask
 estimator -> WTA/SCM/MVDR -> PIT stitch -> activity gate -> iSTFT) over one synthetic 7-channel 16 kHz meeting,
 timed from the PCM in (page-locked) HOST memory to the separated waveforms in host memory: both PCIe legs are
-inside the timed region (SURVEY.md 8(d) "Metric").  `value` = audio seconds separated per wall second.
+inside the timed region (SURVEY.md 8(d) "Metric").  `value` = audio seconds separated per wall second.  At N = 1 the K
+steps are K sessions in a queue (css_run_enqueue ... css_wait: a session's PCIe legs run under its neighbours' kernels);
+the same K sessions as K synchronous css_run calls are the `synchronous_call` key of the line.
 
   N = 1   BASELINE.json configs[1]: the 60 s meeting (40 segments).  The same line also carries the 30-min meeting of
           configs[3] on this one GPU (`meeting_1800s`), the device-resident figure, the exact-float32 arithmetic mode,
@@ -277,7 +279,34 @@ def main():
     out_pin = L.pinned_empty((S, int(plan.n_out)), np.float32)
     torch.cuda.synchronize()
 
-    # ---- headline: host -> host, exactly K steps after W warm-up steps, synchronised on both sides
+    # ---- headline: a queue of K sessions, each host -> host (css_run_enqueue ... css_wait): exactly K steps after W warm-up
+    # steps, synchronised on both sides.  Every session is uploaded, separated and downloaded inside the timed region; what
+    # the queue adds over K synchronous calls is that a session's PCIe legs run under its neighbours' kernels.
+    out_pin2 = L.pinned_empty((S, int(plan.n_out)), np.float32)
+    outs = (out_pin, out_pin2)
+
+    def queued(k_steps):
+        for k in range(k_steps):
+            h.run_enqueue(pcm_pin, run_cfg, outs[k % 2])
+        h.wait()
+
+    queued(args.warmup)
+    h.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    queued(args.steps)
+    h.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert np.isfinite(out_pin).all() and (args.steps < 2 or np.array_equal(out_pin, out_pin2))
+    result.update({
+        "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "scaling": "strong", "dtype": dtype_of[h.linear_mode()],
+        "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({plan.num_segments} segments of 3 s / 1.5 s "
+                               f"hop), Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR; a queue of sessions, each host PCM -> "
+                               f"host waveforms (css_run_enqueue / css_wait, page-locked buffers, every session's two PCIe "
+                               f"legs inside the timed region, overlapped with its neighbours' kernels)",
+                   "segments": int(plan.num_segments), "sharding": "single GPU"},
+    })
+    # ---- the same K sessions as K synchronous calls (css_run returns when the waveforms are in host memory)
     for _ in range(args.warmup):
         h.run(pcm_pin, run_cfg, out=out_pin)
     h.sync(); torch.cuda.synchronize()
@@ -285,16 +314,9 @@ def main():
     for _ in range(args.steps):
         h.run(pcm_pin, run_cfg, out=out_pin)
     h.sync(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert np.isfinite(out_pin).all()
-    result.update({
-        "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "scaling": "strong", "dtype": dtype_of[h.linear_mode()],
-        "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({plan.num_segments} segments of 3 s / 1.5 s "
-                               f"hop), Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR, host PCM -> host waveforms "
-                               f"(css_run, page-locked buffers, both PCIe legs timed)",
-                   "segments": int(plan.num_segments), "sharding": "single GPU"},
-    })
+    ms_sync = 1e3 * (time.perf_counter() - t0) / args.steps
+    result["synchronous_call"] = {"ms_per_step": round(ms_sync, 3), "value": round(seconds / (ms_sync * 1e-3), 2),
+                                  "note": "css_run: one session per call, host -> host, the call's own latency (nothing to overlap with)"}
     stage = h.timings()
     result["stage_ms"] = {k: round(v, 3) for k, v in stage.items()
                           if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total", "host_enqueue", "host_total")}
@@ -319,6 +341,7 @@ def main():
     ms_dev = timed(lambda: h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out))
     result["device_resident"] = rec(ms_dev, "css_run_device: PCM and waveforms in HBM (no PCIe leg)")
     result["host_vs_device_resident"] = round((1e3 * elapsed / args.steps) / ms_dev, 4)
+    result["synchronous_vs_device_resident"] = round(ms_sync / ms_dev, 4)
     pageable = np.ascontiguousarray(mix[0])
     result["pageable_host"] = rec(timed(lambda: h.run(pageable, run_cfg), steps=5, warmup=1),
                                   "css_run from/to ordinary (pageable) host memory: the driver's staged copies")
@@ -395,10 +418,20 @@ def main():
         out_long = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
         ms_long = fused_host_to_host(h, pcm_long, out_long, 3, 1)
         assert np.isfinite(out_long[:, ::4096]).all()
-        result["meeting_1800s"] = {**rec(ms_long, "the strong-scaling workload of the N > 1 lines on ONE GPU, host -> host"),
+        result["meeting_1800s"] = {**rec(ms_long, "the strong-scaling workload of the N > 1 lines on ONE GPU, host -> host, one synchronous css_run per meeting"),
                                    "value": round(args.long_seconds / (ms_long * 1e-3), 2),
                                    "segments": int(plan_long.num_segments), "seconds": args.long_seconds}
-        del pcm_long, out_long
+        out_long2 = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
+        h.run_enqueue(pcm_long, run_cfg, out_long2); h.wait()
+        h.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(4):
+            h.run_enqueue(pcm_long, run_cfg, (out_long, out_long2)[k % 2])
+        h.wait(); torch.cuda.synchronize()
+        ms_q = 1e3 * (time.perf_counter() - t0) / 4
+        result["meeting_1800s"]["queued"] = {"ms_per_step": round(ms_q, 3), "value": round(args.long_seconds / (ms_q * 1e-3), 2),
+                                             "note": "four such meetings queued (css_run_enqueue / css_wait)"}
+        del pcm_long, out_long, out_long2
 
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, seconds), {"activity_th": 0.3})

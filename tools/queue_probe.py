@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A queue of sessions: K meetings host -> host, synchronous css_run on one handle against css_run_enqueue on two handles
-used in turn (each pass starts behind the other handle's lanes; css_wait at the end).   python tools/queue_probe.py [seconds]"""
+"""A queue of sessions: K meetings host -> host, synchronous css_run against css_run_enqueue ... css_wait on one handle
+(consecutive passes overlap) and on two handles used in turn (they only contend).   python tools/queue_probe.py [seconds]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -26,14 +26,14 @@ def sync_run():
     for k in range(K): hs[0].run(pcm, run_cfg, out=outs[0])
 def dev_run():
     for k in range(K): hs[0].run_device(pd.data_ptr(), n, 7, run_cfg, wd.data_ptr(), int(plan.n_out))
-def queued(two=True, chain=True):
+def queued(two=False):
     for k in range(K):
         h = hs[k % 2] if two else hs[0]
-        h.run_enqueue(pcm, run_cfg, outs[k % 2], after=(hs[(k + 1) % 2] if (two and chain) else None))
+        h.run_enqueue(pcm, run_cfg, outs[k % 2])
     for h in hs: h.wait()
 ref = hs[0].run(pcm, run_cfg).copy()
 if len(sys.argv) > 2 and sys.argv[2] == "trace":
-    queued(True, True); queued(True, True); torch.cuda.synchronize()
+    queued(); queued(); torch.cuda.synchronize()
     for s in seps: s.close()
     sys.exit(0)
 def timed(fn):
@@ -46,8 +46,7 @@ print(f"{seconds:g} s meeting, {K} meetings back to back, ms per meeting:")
 print(f"  css_run, synchronous, one handle        : {timed(sync_run):.3f}")
 print(f"  css_run_device (resident), one handle   : {timed(dev_run):.3f}")
 print(f"  css_run_enqueue, one handle             : {timed(lambda: queued(False)):.3f}")
-print(f"  css_run_enqueue, two handles, unchained : {timed(lambda: queued(True, False)):.3f}")
-print(f"  css_run_enqueue, two handles in turn    : {timed(lambda: queued(True, True)):.3f}")
+print(f"  css_run_enqueue, two handles in turn    : {timed(lambda: queued(True)):.3f}")
 queued(False)
 print("  results equal the synchronous pass:", all(np.array_equal(o[:, :plan.n_out], ref) for o in outs))
 for s in seps: s.close()
