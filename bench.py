@@ -231,10 +231,18 @@ def main():
         assert torch.isfinite(out_host).all()
         if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
             ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
-            same = bool(np.array_equal(ref[:, o_lo:o_hi], out_host[:, :o_hi - o_lo].numpy()))
+            same_own = bool(np.array_equal(ref[:, o_lo:o_hi], out_host[:, :o_hi - o_lo].numpy()))
             be.begin(pcm_slice, n, 7, run_cfg, sample_range=(s_lo, s_hi), slice_only=True)
             full = PAR.sharded_separate_and_stitch(be, S, T, hop, desc.frame_hop, rank, world, dist)   # gather="all"
-            same = same and bool(np.array_equal(ref, full.cpu().numpy()))
+            with be.on_stream():   # (the copy must be ordered behind the join kernel on the handle's stream)
+                full = full.cpu().numpy()
+            same_all = bool(np.array_equal(ref, full))
+            if not (same_own and same_all):
+                bad_o = np.flatnonzero((ref[:, o_lo:o_hi] != out_host[:, :o_hi - o_lo].numpy()).any(axis=0))
+                bad_a = np.flatnonzero((ref != full).any(axis=0))
+                log(f"[rank {rank}] own range equal: {same_own} ({bad_o.size} samples differ, first {bad_o[:1] + o_lo}, last {bad_o[-1:] + o_lo}); "
+                    f"all-gathered equal: {same_all} ({bad_a.size} samples differ, first {bad_a[:1]}, last {bad_a[-1:]})")
+            same = same_own and same_all
             del full
             log(f"[rank {rank}] sharded == fused single-GPU result, bit for bit (own range [{o_lo}, {o_hi}) and the "
                 f"all-gathered whole): {same}")
