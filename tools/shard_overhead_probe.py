@@ -39,8 +39,8 @@ for f in (fused, staged, fused, staged):
     res.setdefault(f.__name__, []).append(1e3 * (time.perf_counter() - t0) / steps)
 for k, v in res.items():
     print(f"- {k:7s}: {min(v):.3f} ms per meeting  (runs: {', '.join(f'{x:.3f}' for x in v)})")
-print(f"- staged / fused = {min(res['staged']) / min(res['fused']):.3f}  (the staged driver runs the segments' stages one after the "
-      f"other on one stream; the fused pass puts the beamformer on the lanes and the tail on its own stream)")
+print(f"- staged / fused = {min(res['staged']) / min(res['fused']):.3f}  (the staged driver is parallel.py's phases at world = 1; the fused pass is css_run_device, which takes the same plain "
+      f"stage sequence for resident samples)")
 # ---- the exchanges' own device work for an 8-rank plan: pack, unpack (index_select / slice adds) -- no collective
 world = 8
 be.begin(pcm, n, 7, run_cfg)
