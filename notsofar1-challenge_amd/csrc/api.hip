@@ -406,6 +406,15 @@ int check_session(css_ctx* h) {
 
 }  // namespace
 
+// queued passes (css_run_enqueue) finish before anything else touches the handle's state or buffers
+#define CSS_DRAIN(h)                                                  \
+    do {                                                              \
+        if ((h) && (h)->queued) {                                     \
+            const int rc_drain_ = css_wait(h);                        \
+            if (rc_drain_ != CSS_OK) return rc_drain_;                \
+        }                                                             \
+    } while (0)
+
 // =================================================================================================
 extern "C" {
 
@@ -643,6 +652,7 @@ static int upload_pcm(css_handle_t h, const float* pcm_host, int64_t s_lo, int64
 }
 
 int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device) {
+    CSS_DRAIN(h);
     if (!h || !pcm) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (!pcm_is_device) return css_begin_range(h, pcm, n_samples, n_ch, cfg, 0, n_samples);
     const int rc = begin_impl(h, n_samples, n_ch, cfg);
@@ -655,6 +665,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
 
 int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     int64_t s_lo, int64_t s_hi) {
+    CSS_DRAIN(h);
     if (!h || !pcm_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (s_lo < 0 || s_hi > n_samples || s_lo > s_hi) return fail(h, CSS_ERR_INVALID_ARG, "sample range out of bounds");
     int rc = begin_impl(h, n_samples, n_ch, cfg);
@@ -1106,6 +1117,7 @@ int css_stage_join_shards(css_handle_t h, const float* gathered_dev, int32_t wor
 }
 
 int css_sync(css_handle_t h) {
+    CSS_DRAIN(h);
     if (!h) return CSS_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1554,6 +1566,7 @@ int css_get_stream(css_handle_t h, void** stream_out) {
 }
 
 int css_set_lanes(css_handle_t h, int lanes) {
+    CSS_DRAIN(h);
     if (!h || lanes < 1 || lanes > css_ctx::MAX_LANES) return fail(h, CSS_ERR_INVALID_ARG, "lanes must be in [1, 4]");
     h->lanes = lanes;   // the lanes' activation buffers are sized by the next css_begin / css_run* / css_*_host call
     return CSS_OK;
@@ -1594,6 +1607,7 @@ int css_check_range(css_handle_t h) {
 // torch.nn.Linear on caller data through one of the path's three GEMM kernels (unit tests of the arithmetic).
 int css_linear_host(css_handle_t h, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
                     int32_t kernel, int32_t layout, float* y) {
+    CSS_DRAIN(h);
     if (!h || !x || !w || !y || M < 1 || N < 1 || K < 32 || K % 32) return fail(h, CSS_ERR_INVALID_ARG, "bad argument (K must be a multiple of 32)");
     if (kernel < 0 || kernel > 2) return fail(h, CSS_ERR_INVALID_ARG, "kernel must be 0 (split, weights direct), 1 (split, LDS staged) or 2 (exact float32)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1636,6 +1650,7 @@ int css_host_alloc(size_t bytes, void** out) {
 int css_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? CSS_OK : CSS_ERR_HIP; }
 
 int css_set_linear_mode(css_handle_t h, int mode) {
+    CSS_DRAIN(h);
     if (!h || (mode != CSS_LINEAR_SPLIT_F16 && mode != CSS_LINEAR_EXACT_F32)) return fail(h, CSS_ERR_INVALID_ARG, "unknown linear mode");
     const bool split = mode == CSS_LINEAR_SPLIT_F16;
     if (split == h->split) return CSS_OK;
@@ -1659,6 +1674,7 @@ int css_get_linear_mode(css_handle_t h) {
 }
 
 int css_set_profile(css_handle_t h, int enable) {
+    CSS_DRAIN(h);
     if (!h) return CSS_ERR_INVALID_ARG;
     h->profile_gemm = enable != 0;
     return CSS_OK;
@@ -1697,6 +1713,7 @@ int css_get_plan(css_handle_t h, CssPlan* out) {
 // -------------------------------------------------------------------------------------------------
 // separator-protocol helpers on caller data
 int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, float* x_planes, int64_t t_frames) {
+    CSS_DRAIN(h);
     if (!h || !pcm || !x_planes) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (n_ch < 1) return fail(h, CSS_ERR_SHAPE, "n_ch must be >= 1");
     const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop;
@@ -1722,6 +1739,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
 }
 
 int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks) {
+    CSS_DRAIN(h);
     if (!h || !x_planes || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     if (t_frames < 2 || t_frames > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 256] frames");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1787,6 +1805,7 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
 }
 
 int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks) {
+    CSS_DRAIN(h);
     if (!h || !masks) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     float *X, *M;
     int T;
@@ -1805,6 +1824,7 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
 int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_spk, const float* gt_noise, int32_t batch,
                              int64_t n_samples, int32_t n_ch, int32_t loss_name, int32_t base_loss, int32_t clip_gt,
                              float noise_weight, float* spk_loss, float* noise_loss, int32_t* perms, float* loss) {
+    CSS_DRAIN(h);
     if (!h || !gt_spk || !gt_noise || !loss) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (loss_name < 0 || loss_name > 1 || base_loss < 0 || base_loss > 1) return fail(h, CSS_ERR_INVALID_ARG, "unknown loss_name / base_loss");
     const int F = h->d.num_bins, S = h->d.num_spks;
@@ -1867,6 +1887,7 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
 int css_handoff_logmel(css_handle_t h, const float* wav_dev, int64_t wav_ld, int32_t stream, int32_t n_mels, int32_t pad_frames,
                        int32_t drop_silence, float* mel_host, int64_t mel_capacity_frames, int64_t* n_mel_frames,
                        int64_t* regions_host, int32_t max_regions, int32_t* n_regions) {
+    CSS_DRAIN(h);
     int rc = check_session(h);
     if (rc) return rc;
     if (!wav_dev || !mel_host || !n_mel_frames || !regions_host || !n_regions || max_regions < 1)
@@ -1944,6 +1965,7 @@ int css_handoff_logmel(css_handle_t h, const float* wav_dev, int64_t wav_ld, int
 }
 
 int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t t_frames, float* wav) {
+    CSS_DRAIN(h);
     if (!h || !y_planes || !wav || batch < 1 || t_frames < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
     const int F = h->d.num_bins, N = h->d.frame_len, hop = h->d.frame_hop, KI = h->KIp;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2009,6 +2031,7 @@ int css_buffer_dims(css_handle_t h, int which, int64_t dims[4], int32_t* elem_by
 }
 
 int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
+    CSS_DRAIN(h);
     int rc = check_session(h);
     if (rc) return rc;
     DevBuf* b;
@@ -2048,6 +2071,7 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
 }
 
 int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes) {
+    CSS_DRAIN(h);
     int rc = check_session(h);
     if (rc) return rc;
     DevBuf* b;

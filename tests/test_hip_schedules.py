@@ -115,5 +115,9 @@ def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinne
         got0 = h.run_enqueue(L.pinned_copy(sessions[0][0]), run_cfg, L.pinned_empty(sessions[0][1].shape, np.float32))
         assert np.array_equal(h.run(sessions[1][0], run_cfg), sessions[1][1])
         assert np.array_equal(got0, sessions[0][1])
+        # ... and so does anything else that touches the handle's state (here: reading a buffer back)
+        got2 = h.run_enqueue(L.pinned_copy(sessions[2][0]), run_cfg, L.pinned_empty(sessions[2][1].shape, np.float32))
+        perms = h.read(L.BUF_PERMS)
+        assert np.array_equal(got2, sessions[2][1]) and perms.shape[0] == L.plan(desc, run_cfg, sessions[2][0].shape[0]).num_segments
     finally:
         sep.close()
