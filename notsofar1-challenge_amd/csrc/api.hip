@@ -721,8 +721,7 @@ static int stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* pl
         else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
     }
     CSS_PROF(CSS_PROF_STFT, st);
-    if (!launch_stft_fft((const float*)h->pcm_cm.p + t_lo * hop, h->n_pad, h->n_ch, (int)(f_hi - t_lo), h->stft_tab,
-                         (float*)h->X.p + t_lo, h->T_ld, st))
+    if (!launch_stft_fft((const float*)h->pcm_cm.p, h->n_pad, h->n_ch, t_lo, f_hi, h->stft_tab, (float*)h->X.p, h->T_ld, st))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     (void)F;
     return CSS_OK;
@@ -1731,7 +1730,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
     launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, h->stream);
-    if (!launch_stft_fft(cm, n_pad, n_ch, (int)T, h->stft_tab, out, T, h->stream))
+    if (!launch_stft_fft(cm, n_pad, n_ch, 0, T, h->stft_tab, out, T, h->stream))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     HIPCHK(h, hipMemcpyAsync(x_planes, out, out_b, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1791,7 +1790,7 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     for (int b = 0; b < batch; ++b) {
         // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
         launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
-        if (!launch_stft_fft(cm + (size_t)b * C * n_pad, n_pad, C, T, h->stft_tab, X + (int64_t)b * T, TT, h->stream))
+        if (!launch_stft_fft(cm + (size_t)b * C * n_pad, n_pad, C, 0, T, h->stft_tab, X + (int64_t)b * T, TT, h->stream))
             return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     }
     const int64_t cap = std::min<int64_t>(h->max_batch, batch);
@@ -1847,7 +1846,7 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
         HIPCHK(h, hipMemcpyAsync(sig + ((size_t)b * (S + 1) + S) * n_pad, gt_noise + (size_t)b * n_samples,
                                  (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, h->stream));
     }
-    if (!launch_stft_fft(sig, n_pad, nsig, T, h->stft_tab, G, T, h->stream))
+    if (!launch_stft_fft(sig, n_pad, nsig, 0, T, h->stft_tab, G, T, h->stream))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     launch_val_loss(X, M, G, batch, T, F, S, loss_name, base_loss, clip_gt ? 1 : 0, partial, h->stream);
     std::vector<double> part((size_t)batch * chunks * 16);

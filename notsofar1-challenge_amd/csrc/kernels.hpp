@@ -102,8 +102,8 @@ size_t stft_table_floats();
 void stft_build_tables(float* host);   // window | radix-4 twiddles | real-spectrum twiddles
 // frames 0 .. nf-1 of C channels (channel c's first sample at x + c * x_stride, frame t at sample 256 t) -> planes
 // out[(c * 514 + r) * row_ld + t], r = f (Re) / 257 + f (Im).  false: the kernel's LDS could not be reserved.
-bool launch_stft_fft(const float* x, int64_t x_stride, int C, int nf, const float* tables, float* out, int64_t row_ld,
-                     hipStream_t s);
+bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
+                     int64_t row_ld, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add

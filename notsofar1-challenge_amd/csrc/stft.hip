@@ -5,7 +5,7 @@
 // memory-sized work -- 27 MB of samples in, 54 MB of planes out per minute -- so it is done here the cheap way:
 // a block owns 16 consecutive frames of one channel, reads their samples as contiguous runs (window applied on the
 // way in), packs each real frame into 256 complex points, runs four radix-4 Stockham stages over all 16 frames in LDS,
-// separates the real spectrum (bins 0 .. 256) and writes it transposed -- time fastest, 64-byte runs -- into the
+// separates the real spectrum (bins 0 .. 256) and writes it transposed -- time fastest, 16-byte pieces of 64-byte runs -- into the
 // planes X[c][Re f | Im f][t] every later stage reads.  The rounding is that of an FFT (~log2 N ulps against ~sqrt N for
 // the direct sum; both ~1e-7 relative to the frame's largest bin, tests/test_hip_parity.py holds the planes to 1e-6
 // against the oracle and 2e-6 against the reference).  The imaginary parts of the DC and Nyquist bins are exact zeros
@@ -43,26 +43,32 @@ void stft_build_tables(float* t) {
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// x: channel c's samples start at x + c * x_stride; frame t (0 .. nf-1) begins at sample t * 256.
-// out: plane row r of channel c, frame t at out + (c * 2F + r) * row_ld + t   (r = f: Re, F + f: Im; F = 257)
-__global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int nf,
+// x: channel c's samples start at x + c * x_stride; frame t begins at sample t * 256.  Frames [t_lo, t_hi) are transformed.
+// out: plane row r of channel c, frame t at out + (c * 2F + r) * row_ld + t   (r = f: Re, F + f: Im; F = 257).
+// A block owns the 16-frame tile [16 B, 16 B + 16) of ABSOLUTE frame indices (frames of the tile outside the range are
+// computed from a clamped frame and not stored), so that a group of four consecutive frames of one plane row is a
+// 16-byte-aligned piece whatever range a launch covers (row_ld % 4 == 0, out 16-byte aligned): the spectrum leaves as
+// float4 stores, 8 per thread instead of 32 scalar ones -- the store phase was bound by store issue.
+__global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int t_lo, int t_hi,
                                                                const float* __restrict__ tab, float* __restrict__ out,
-                                                               int64_t row_ld) {
+                                                               int64_t row_ld, int wide) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
     float2* bufA = fft_lds;
     float2* bufB = fft_lds + FFT_TB * FFT_FS;
+    float2* twl = fft_lds + 2 * FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
-    const int t0 = blockIdx.x * FFT_TB;
+    const int t0 = (t_lo / FFT_TB + blockIdx.x) * FFT_TB;
     const float* xc = x + (int64_t)c * x_stride;
     const float* win = tab;
     const float2* tw256 = reinterpret_cast<const float2*>(tab + FFT_N);
     const float2* tw512 = reinterpret_cast<const float2*>(tab + FFT_N + 2 * FFT_H);
     // ---- windowed, packed load: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1]
+    twl[tid] = tw256[tid];
 #pragma unroll 4
     for (int e = tid; e < FFT_TB * FFT_H; e += FFT_THREADS) {
         const int fr = e >> 8, n = e & 255;
-        const int t = min(t0 + fr, nf - 1);   // frames past the launch's range repeat the last one (never stored)
+        const int t = max(min(t0 + fr, t_hi - 1), t_lo);   // frames outside the range repeat its nearest frame (never stored)
         const float2 s = *reinterpret_cast<const float2*>(xc + (int64_t)t * FFT_H + 2 * n);
         const float2 w = *reinterpret_cast<const float2*>(win + 2 * n);
         bufA[fr * FFT_FS + n] = make_float2(s.x * w.x, s.y * w.y);
@@ -83,9 +89,9 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
             float2 u0 = in[j], u1 = in[j + 64], u2 = in[j + 128], u3 = in[j + 192];
             if (p > 0) {
                 const int m = k * (64 / Ns);        // exp(-2 pi i k / (4 Ns)) = tw256[k * 64 / Ns]
-                u1 = cmulf(u1, tw256[m]);
-                u2 = cmulf(u2, tw256[2 * m]);
-                u3 = cmulf(u3, tw256[3 * m]);
+                u1 = cmulf(u1, twl[m]);
+                u2 = cmulf(u2, twl[2 * m]);
+                u3 = cmulf(u3, twl[3 * m]);
             }
             // radix-4 butterfly (forward: multiply by -i is (x, y) -> (y, -x))
             const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
@@ -103,39 +109,69 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
     // ---- real spectrum from the packed transform Z (in src), written time-fastest
     //   E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / (2i),  X[k] = E + e^{-2 pi i k / 512} O
     const int F = FFT_H + 1;
-    const int tl = tid & (FFT_TB - 1);
-    static_assert(FFT_TB == 16 || FFT_TB == 32, "store phase indexing");
-    const bool store = t0 + tl < nf;
-    float* oc = out + (int64_t)c * 2 * F * row_ld + t0 + tl;
-    for (int f = tid / FFT_TB; f < F; f += FFT_THREADS / FFT_TB) {
-        const float2 z0 = src[tl * FFT_FS + (f & 255)];
-        const float2 z1 = src[tl * FFT_FS + ((256 - f) & 255)];
-        float re, im;
+    static_assert(FFT_TB == 16, "store phase indexing");
+    auto bin = [&](int fr, int f, float2 w5, float& re, float& im) {
+        const float2 z0 = src[fr * FFT_FS + (f & 255)];
+        const float2 z1 = src[fr * FFT_FS + ((256 - f) & 255)];
         if (f == 0) { re = z0.x + z0.y; im = 0.f; }
         else if (f == FFT_H) { re = z0.x - z0.y; im = 0.f; }
         else {
             const float2 e = make_float2(0.5f * (z0.x + z1.x), 0.5f * (z0.y - z1.y));
             const float2 o = make_float2(0.5f * (z0.y + z1.y), 0.5f * (z1.x - z0.x));
-            const float2 wo = cmulf(tw512[f], o);
+            const float2 wo = cmulf(w5, o);
             re = e.x + wo.x;
             im = e.y + wo.y;
         }
-        if (store) {
-            oc[(int64_t)f * row_ld] = re;
-            oc[(int64_t)(F + f) * row_ld] = im;
+    };
+    float* oc = out + (int64_t)c * 2 * F * row_ld + t0;
+    if (wide) {
+        // a thread owns one bin row of a four-frame group: lanes 0..3 cover the tile's 64 bytes of that row
+        const int g4 = (tid & 3) * 4;
+        const int ta = t0 + g4;
+        const bool all_in = ta >= t_lo && ta + 4 <= t_hi;
+        for (int f = tid >> 2; f < F; f += FFT_THREADS / 4) {
+            const float2 w5 = tw512[f];
+            float re[4], im[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bin(g4 + q, f, w5, re[q], im[q]);
+            float* pr = oc + (int64_t)f * row_ld + g4;
+            float* pi = oc + (int64_t)(F + f) * row_ld + g4;
+            if (all_in) {
+                *reinterpret_cast<float4*>(pr) = make_float4(re[0], re[1], re[2], re[3]);
+                *reinterpret_cast<float4*>(pi) = make_float4(im[0], im[1], im[2], im[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ta + q >= t_lo && ta + q < t_hi) { pr[q] = re[q]; pi[q] = im[q]; }
+            }
+        }
+    } else {
+        const int tl = tid & (FFT_TB - 1);
+        const bool store = t0 + tl >= t_lo && t0 + tl < t_hi;
+        for (int f = tid / FFT_TB; f < F; f += FFT_THREADS / FFT_TB) {
+            float re, im;
+            bin(tl, f, tw512[f], re, im);
+            if (store) {
+                oc[(int64_t)f * row_ld + tl] = re;
+                oc[(int64_t)(F + f) * row_ld + tl] = im;
+            }
         }
     }
 }
 
-bool launch_stft_fft(const float* x, int64_t x_stride, int C, int nf, const float* tables, float* out, int64_t row_ld,
-                     hipStream_t s) {
-    if (nf <= 0 || C <= 0) return true;
-    const size_t lds = (size_t)2 * FFT_TB * FFT_FS * sizeof(float2);   // 65.8 KB
+// frames [t_lo, t_hi) of C channels; x and out are the bases of frame 0
+bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
+                     int64_t row_ld, hipStream_t s) {
+    if (t_hi <= t_lo || C <= 0) return true;
+    const size_t lds = ((size_t)2 * FFT_TB * FFT_FS + FFT_H) * sizeof(float2);   // 67.8 KB
     // (the attribute is per device: set it on every launch -- a host-side table lookup -- rather than behind a
     // process-wide flag that a second device, or a second thread's first launch, would miss)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    hipLaunchKernelGGL(stft_fft_kernel, dim3((nf + FFT_TB - 1) / FFT_TB, C), dim3(FFT_THREADS), lds, s, x, x_stride, nf, tables, out, row_ld);
+    const int tiles = (int)((t_hi + FFT_TB - 1) / FFT_TB - t_lo / FFT_TB);
+    const int wide = (row_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(stft_fft_kernel, dim3(tiles, C), dim3(FFT_THREADS), lds, s, x, x_stride, (int)t_lo, (int)t_hi, tables, out,
+                       row_ld, wide);
     return true;
 }
 
