@@ -19,8 +19,7 @@ namespace css {
 
 constexpr int FFT_N = 512;            // frame length
 constexpr int FFT_H = 256;            // packed complex length = hop
-constexpr int FFT_TB = 16;            // frames per block: 66 KB of LDS, two blocks per CU cover each other's load / store phases
-                                      // (32 frames: 128-byte store runs, but one block per CU -- 67 us against 58 us per minute of audio)
+constexpr int FFT_TB = 16;            // frames per block: 35 KB of LDS, four blocks per CU cover each other's load / store phases
 constexpr int FFT_FS = FFT_H + 1;     // frame stride in LDS (complex elements): odd, so the frames of a store pass hit distinct bank pairs
 constexpr int FFT_THREADS = 256;
 
@@ -54,8 +53,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
                                                                int64_t row_ld, int wide) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
     float2* bufA = fft_lds;
-    float2* bufB = fft_lds + FFT_TB * FFT_FS;
-    float2* twl = fft_lds + 2 * FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
+    float2* twl = fft_lds + FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int t0 = (t_lo / FFT_TB + blockIdx.x) * FFT_TB;
@@ -74,14 +72,17 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
         bufA[fr * FFT_FS + n] = make_float2(s.x * w.x, s.y * w.y);
     }
     __syncthreads();
-    // ---- four radix-4 Stockham stages (decimation in time), ping-pong A -> B -> A -> B -> A
+    // ---- four radix-4 Stockham stages (decimation in time) IN PLACE: every thread holds its four butterflies' inputs in
+    //      registers, the block meets, the outputs go back into the same buffer (half the LDS of a ping-pong pair: four
+    //      blocks per CU instead of two cover each other's load, barrier and store phases)
     float2* src = bufA;
-    float2* dst = bufB;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int Ns = 1 << (2 * p);              // 1, 4, 16, 64
+        constexpr int NB = FFT_TB * 64 / FFT_THREADS;
+        float2 r0[NB], r1[NB], r2[NB], r3[NB];
 #pragma unroll
-        for (int i = 0; i < FFT_TB * 64 / FFT_THREADS; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int b = i * FFT_THREADS + tid;
             const int fr = b >> 6, j = b & 63;
             const int k = j & (Ns - 1);
@@ -96,15 +97,25 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
             // radix-4 butterfly (forward: multiply by -i is (x, y) -> (y, -x))
             const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
             const float2 a2 = make_float2(u1.x + u3.x, u1.y + u3.y), a3 = make_float2(u1.y - u3.y, u3.x - u1.x);   // -i (u1 - u3)
-            const int j0 = ((j - k) << 2) + k;
-            float2* o = dst + fr * FFT_FS + j0;
-            o[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-            o[Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
-            o[2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-            o[3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+            r0[i] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            r1[i] = make_float2(a1.x + a3.x, a1.y + a3.y);
+            r2[i] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            r3[i] = make_float2(a1.x - a3.x, a1.y - a3.y);
         }
         __syncthreads();
-        float2* tmp = src; src = dst; dst = tmp;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int b = i * FFT_THREADS + tid;
+            const int fr = b >> 6, j = b & 63;
+            const int k = j & (Ns - 1);
+            const int j0 = ((j - k) << 2) + k;
+            float2* o = src + fr * FFT_FS + j0;
+            o[0] = r0[i];
+            o[Ns] = r1[i];
+            o[2 * Ns] = r2[i];
+            o[3 * Ns] = r3[i];
+        }
+        __syncthreads();
     }
     // ---- real spectrum from the packed transform Z (in src), written time-fastest
     //   E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / (2i),  X[k] = E + e^{-2 pi i k / 512} O
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
 bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
                      int64_t row_ld, hipStream_t s) {
     if (t_hi <= t_lo || C <= 0) return true;
-    const size_t lds = ((size_t)2 * FFT_TB * FFT_FS + FFT_H) * sizeof(float2);   // 67.8 KB
+    const size_t lds = ((size_t)FFT_TB * FFT_FS + FFT_H) * sizeof(float2);   // 34.9 KB
     // (the attribute is per device: set it on every launch -- a host-side table lookup -- rather than behind a
     // process-wide flag that a second device, or a second thread's first launch, would miss)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
