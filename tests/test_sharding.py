@@ -133,3 +133,28 @@ def test_sharded_driver_over_gloo_matches_single_rank(tmp_path, world):
         assert own.shape == (3, hi - lo) and np.array_equal(own, single[:, lo:hi]), f"rank {r}: own range differs"
         edge = hi
     assert edge == single.shape[1]
+
+
+def test_upload_schedule_covers_the_ranks_segments_and_samples():
+    """parallel.upload_schedule: the groups tile [seg_lo, seg_hi) in order, every group's last sample is inside the piece
+    that ends at its cut, the cuts ascend inside the rank's sample range, no crumbs at the end."""
+    par = pkg("parallel")
+    T, hop, fhop, flen = 186, 93, 256, 512
+    for nseg, world in ((1209, 8), (1209, 2), (40, 3), (7, 2), (300, 5)):
+        mix_frames = (nseg - 1) * hop + T - 11
+        n = (mix_frames - 1) * fhop + flen
+        for r in range(world):
+            me = par.make_shard_plan(nseg, mix_frames, mix_frames, T, hop, fhop, r, world)
+            for first, growth in ((32, 8), (3, 2), (1, 1)):
+                groups, cuts = par.upload_schedule(me, T, hop, flen, n, first=first, growth=growth)
+                if me.seg_hi == me.seg_lo:
+                    assert groups == [] and cuts == []
+                    continue
+                assert groups[0][0] == me.seg_lo and groups[-1][1] == me.seg_hi
+                assert all(a[1] == b[0] and a[1] > a[0] for a, b in zip(groups, groups[1:])) and groups[-1][1] > groups[-1][0]
+                assert len(cuts) == len(groups) - 1 and cuts == sorted(cuts)
+                lo, hi = me.pcm_range(flen, n)
+                for (a, b), c in zip(groups, cuts):
+                    assert lo < c <= hi
+                    assert min(((b - 1) * hop + T - 1) * fhop + flen, n) <= c      # the group's frames read samples below the cut
+                assert groups[-1][1] - groups[-1][0] >= min(first // 2, me.seg_hi - me.seg_lo)
