@@ -237,8 +237,8 @@ int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_
  *   CSS_LINEAR_SPLIT_F16 (default)  operands carried as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product,
  *                                   float32 accumulation: float32-grade accuracy at 5.3x the float32 matrix rate;
  *   CSS_LINEAR_EXACT_F32            the exact float32 MFMA chain (bit-identical to an fmaf loop over k).
- * The default of a new handle is CSS_LINEAR_SPLIT_F16 unless the environment holds CSS_EXACT_F32=1 at css_create.
- * May be switched between runs. */
+ * The default of a new handle is CSS_LINEAR_SPLIT_F16 (css_create falls to CSS_LINEAR_EXACT_F32 by itself when a weight of
+ * the blob is outside the float16 range).  May be switched between runs; no environment variable is read. */
 enum css_linear_mode { CSS_LINEAR_SPLIT_F16 = 0, CSS_LINEAR_EXACT_F32 = 1 };
 int css_set_linear_mode(css_handle_t h, int mode);
 int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css_status */
