@@ -126,6 +126,7 @@ struct css_ctx {
     // the last transform of the pass that used sample buffer b; `tail_end` = the end of the last queued pass's tail
     int64_t pass_no = 0;
     hipEvent_t pcm_free[2] = {nullptr, nullptr};
+    hipEvent_t level_free[2] = {nullptr, nullptr};   // end of the tail of the pass that used level word b (its last reader)
     hipEvent_t tail_end = nullptr;
     bool tail_pending = false;
     bool piped_now = false;   // run_once -> begin_impl: the level word is cleared on the copy stream, not here
@@ -167,6 +168,7 @@ int fail(css_ctx* h, int code, const std::string& msg) {
 
 int ensure(css_ctx* h, DevBuf& b, size_t bytes, bool zero = false) {
     if (bytes <= b.cap) return CSS_OK;
+    if (b.p && h->queued) HIPCHK(h, hipDeviceSynchronize());   // queued passes may still use the old allocation
     if (b.p) HIPCHK(h, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -536,6 +538,7 @@ int css_destroy(css_handle_t h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->tail_end) hipEventDestroy(h->tail_end);
     for (auto& e : h->pcm_free) if (e) hipEventDestroy(e);
+    for (auto& e : h->level_free) if (e) hipEventDestroy(e);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); hipStreamDestroy(h->tail_stream); }
     if (h->range_flag_dev) hipFree(h->range_flag_dev);
@@ -1287,10 +1290,16 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     } else {
         // the samples go into the buffer the pass before last used: free once that pass has transformed its frames; the
         // level word of this parity is cleared here, in front of the pieces' peak scans (each stream is in order in itself)
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
             if (!h->pcm_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcm_free[b], hipEventDisableTiming));
+            if (!h->level_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->level_free[b], hipEventDisableTiming));
+        }
         if (!h->tail_end) HIPCHK(h, hipEventCreateWithFlags(&h->tail_end, hipEventDisableTiming));
-        if (h->pass_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->pcm_free[par], 0));
+        if (h->pass_no >= 2) {
+            HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->pcm_free[par], 0));
+            // ... and the level word when that pass's TAIL has read it (the host may be several passes ahead of the device)
+            HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->level_free[par], 0));
+        }
         HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->copy_stream));
     }
     // ---- PCIe pieces, in unit order, on the copy stream
@@ -1448,6 +1457,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     if (piped) {   // no join: the next queued pass's estimator runs beside this pass's tail; css_wait waits for all streams
         HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
         HIPCHK(h, hipEventRecord(h->tail_end, h->tail_stream));
+        HIPCHK(h, hipEventRecord(h->level_free[par], h->tail_stream));
         hipEventRecord(h->ev[7], h->tail_stream);
         h->tail_pending = true;
         h->pass_no += 1;

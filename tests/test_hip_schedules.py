@@ -121,3 +121,30 @@ def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinne
         assert np.array_equal(got2, sessions[2][1]) and perms.shape[0] == L.plan(desc, run_cfg, sessions[2][0].shape[0]).num_segments
     finally:
         sep.close()
+
+
+def test_queued_sessions_with_the_host_passes_ahead(mc_state):
+    """The full 18-block estimator keeps the device busy for several milliseconds per session while the host enqueues a
+    session in two: the host runs passes ahead, so everything a queued pass re-uses (sample buffer half, level word,
+    events) must be protected against the passes still in flight.  Different sessions of different lengths, buffers sized
+    beforehand (no re-allocation stalls) and not (growing sessions)."""
+    L, CSS = pkg("_lib"), pkg("css")
+    st, desc = mc_state
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([20.0, 27.0, 34.0, 41.0, 20.0, 27.0, 34.0, 41.0, 23.0]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=300 + k)
+            pcm = L.pinned_copy(np.ascontiguousarray(mix[0] * (0.02 if k % 3 == 1 else 1.0)))   # levels differ too
+            sessions.append((pcm, h.run(pcm, run_cfg).copy()))
+        for presized in (False, True):
+            if presized:
+                h.run(sessions[3][0], run_cfg)
+            outs = [h.run_enqueue(pcm, run_cfg, L.pinned_empty(ref.shape, np.float32)) for pcm, ref in sessions]
+            h.wait()
+            for k, (got, (_, ref)) in enumerate(zip(outs, sessions)):
+                assert np.array_equal(got, ref), (presized, k, float(np.abs(got - ref).max()))
+    finally:
+        sep.close()
