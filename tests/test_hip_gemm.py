@@ -156,5 +156,16 @@ def test_out_of_range_pass_is_repeated_in_float32(mc_state, mix60):
         with pytest.raises(L.CssError) as e:
             h.run(mix, run_cfg)
         assert e.value.code == L.CSS_ERR_RANGE
+        # queued passes have no automatic repeat (the inputs are the caller's): css_wait reports the range error, and the
+        # handle is usable afterwards -- the synchronous call repeats in float32 as before
+        h.set_range_fallback(True)
+        pin = L.pinned_copy(mix)
+        out = L.pinned_empty(ref.shape, np.float32)
+        h.run_enqueue(pin, run_cfg, out)
+        h.run_enqueue(pin, run_cfg, out)
+        with pytest.raises(L.CssError) as e:
+            h.wait()
+        assert e.value.code == L.CSS_ERR_RANGE
+        assert np.array_equal(h.run(mix, run_cfg), ref)
     finally:
         sep.close()
