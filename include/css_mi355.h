@@ -208,7 +208,8 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
  * pass before last used) while pass P - 1's estimator runs, and P - 1's stitching, synthesis and download (zero-copy
  * into wav_host) run beside P's estimator -- both PCIe legs of a session hide under its neighbours' kernels, results bit
  * for bit those of css_run (tests/test_hip_session.py, bench.py).  With pageable output the passes simply queue up.
- * No automatic float32 repeat here: css_wait returns CSS_ERR_RANGE if a queued pass left the split-f16 range. */
+ * The call blocks while three queued passes are still unfinished (back-pressure: the host never runs more than three
+ * passes ahead of the device).  No automatic float32 repeat here: css_wait returns CSS_ERR_RANGE if a queued pass left the split-f16 range. */
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     float* wav_host, int64_t cap);
 /* Blocks until every pass queued on h has finished (results in their wav_host buffers); CssTimings describe the last. */
