@@ -16,10 +16,11 @@ the same K sessions as K synchronous css_run calls are the `synchronous_call` ke
           configs[3] on this one GPU (`meeting_1800s`), the device-resident figure, the exact-float32 arithmetic mode,
           the roofline of the dominant kernel, the memory-bound kernels' GB/s, and the CPU baseline.
   N > 1   BASELINE.json configs[3]: ONE fixed 1800 s meeting (1209 segments), strong-scaled: sharded by sliding-window
-          segment across the N ranks with the RCCL all-gather stitch of notsofar1-challenge_amd/parallel.py.  Every rank
-          uploads only the samples of its own segments and downloads only its own range of the result (the stitched
-          streams are complete in every rank's HBM after the all-gather).  Rank 0 also times the same meeting alone on
-          its GPU after the timed region (`single_gpu_same_workload`), so that every line compares like with like.
+          segment across the N ranks with the three small RCCL all-gathers of notsofar1-challenge_amd/parallel.py (PIT
+          costs, activity bits, one 256-sample seam block per stream).  Every rank uploads only the samples of its own
+          segments, piece by piece under the stages, and finishes and downloads only its own range of the result.
+          Rank 0 also times the same meeting alone on its GPU after the timed region (`single_gpu_same_workload`), so
+          that every line compares like with like.
 
 Weights: v1.0-MC architecture (D=512, H=8, 18 blocks, 1799 inputs), seeded portable random init with the
 conditioning recipe of the golden tests (no pretrained checkpoint exists offline) -- arithmetic and
