@@ -312,6 +312,7 @@ def main():
             h.run_enqueue(pcm_pin, run_cfg, outs[k % 2])
         h.wait()
 
+    h.run(pcm_pin, run_cfg, out=out_pin)   # initialisation, not a step: the handle allocates its device buffers on first use
     queued(args.warmup)
     h.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
