@@ -214,6 +214,11 @@ class HipShardBackend:
         self.h.stage_join_shards(all_shards.data_ptr(), len(plans), all_shards.shape[2], [p.t_lo for p in plans],
                                  [p.t_hi for p in plans], out.data_ptr(), out.stride(0))
 
+    def check_range(self):
+        """Host-synchronising test of the split-f16 range flag after a staged session (css_check_range): raises
+        CssError(CSS_ERR_RANGE) when a Linear-layer operand overflowed, i.e. the session's waveforms are not valid."""
+        self.h.check_range()
+
     def scratch(self, name, shape, dtype):
         """persistent work tensors (send / receive pieces, index maps): allocated once per shape"""
         key = (name, tuple(shape), dtype)
@@ -388,37 +393,69 @@ def _all_gather(dist, send, world, comm_dev):
 
 
 def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int,
-                                rank: int, world: int, dist=None, out=None, gather: str = "all", segment_groups=None):
-    """Runs one rank's share of a session that `backend.begin(...)` has opened.  Asynchronous on the backend's stream.
+                                rank: int, world: int, dist=None, out=None, gather: str = "all", segment_groups=None,
+                                trace=None, check_range: bool = True):
+    """Runs one rank's share of a session that `backend.begin(...)` has opened.
 
     gather="all" (default): returns the full separated waveforms [S, n_out] (a tensor on the backend's device),
     identical on every rank and identical to the single-rank result -- what css.py:110 returns.
     gather="range": returns (wav, (lo, hi)): the finished samples [lo, hi) of this rank's own range, [S, hi - lo]; the
     ranges of the ranks tile [0, n_out) and their concatenation is the single-rank result, bit for bit.  Only one
     256-sample block per stream crosses between neighbours.
-    segment_groups: upload_schedule's groups when the session's samples arrive piece by piece (HipShardBackend.begin(cuts=))."""
+    segment_groups: upload_schedule's groups when the session's samples arrive piece by piece (HipShardBackend.begin(cuts=)).
+
+    LIFETIME of the result: with `out=None`, gather="range" (and world == 1) return a VIEW of a work tensor the backend
+    keeps between sessions -- valid until the next begin() on the same backend; pass `out` (gather="all": [S, n_out];
+    gather="range": [S, >= hi - lo]) or copy it on the backend's stream to keep it.  gather="all" with world > 1
+    allocates a fresh tensor when `out` is None.
+
+    check_range=True (default) ends with backend.check_range(): one host synchronisation, after which a Linear-layer
+    operand that left the split-f16 range (split_f16.hpp) raises CssError(CSS_ERR_RANGE) instead of returning NaN
+    waveforms (repeat the session after handle.set_linear_mode("exact_f32")).  check_range=False keeps the call
+    asynchronous on the backend's stream: the CALLER then checks once it has synchronised (bench.py does, at its barrier).
+    trace: optional callable(label), called on the host between the phases (bench.py records an event on the stream)."""
     assert gather in ("all", "range"), gather
     ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world, segment_groups)
     comm_dev = getattr(backend, "comm_dev", None)
-    ctx = ss._ctx()
-    with ctx:
+    mark = trace if trace is not None else (lambda label: None)
+
+    def finish(result):
+        if check_range and hasattr(backend, "check_range"):
+            backend.check_range()
+        return result
+
+    with ss._ctx():
         costs = ss.segments_and_costs()
+        mark("segments")
         if world > 1:
             costs = _all_gather(dist, costs, world, comm_dev if comm_dev is not None else costs.device)
+        mark("exchange_costs")
         act = ss.masks_and_activity(costs)
+        mark("scan_stitch_masks")
         if world > 1:
             act = _all_gather(dist, act, world, comm_dev if comm_dev is not None else act.device)
+        mark("exchange_activity")
         shard = ss.gate_and_istft(act)
+        mark("gate_istft")
         if gather == "range":
             seams = None
             if world > 1:
                 seam = ss.seam_piece(shard)
                 seams = _all_gather(dist, seam, world, comm_dev if comm_dev is not None else seam.device)
-            return ss.finish_range(shard, seams), ss.own_range()
+            own, rng = ss.finish_range(shard, seams), ss.own_range()
+            if out is not None:
+                out[:, :rng[1] - rng[0]].copy_(own)
+                own = out[:, :rng[1] - rng[0]]
+            mark("exchange_waveforms")
+            return finish((own, rng))
         if world == 1:
-            if out is None:
-                return shard[:, :ss.n_out]
-            out.copy_(shard[:, :ss.n_out])
-            return out
+            res = shard[:, :ss.n_out]
+            if out is not None:
+                out.copy_(res)
+                res = out
+            mark("exchange_waveforms")
+            return finish(res)
         shards = _all_gather(dist, shard, world, comm_dev if comm_dev is not None else shard.device)
-        return ss.join_shards(shards, out)
+        res = ss.join_shards(shards, out)
+        mark("exchange_waveforms")
+        return finish(res)
