@@ -209,7 +209,11 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
  * into wav_host) run beside P's estimator -- both PCIe legs of a session hide under its neighbours' kernels, results bit
  * for bit those of css_run (tests/test_hip_session.py, bench.py).  With pageable output the passes simply queue up.
  * The call blocks while three queued passes are still unfinished (back-pressure: the host never runs more than three
- * passes ahead of the device).  No automatic float32 repeat here: css_wait returns CSS_ERR_RANGE if a queued pass left the split-f16 range. */
+ * passes ahead of the device).  A queue never mixes the two modes un-drained: when a pageable output follows a page-locked
+ * one (or the reverse) the call first waits for the queued passes on the device.  Range rule as css_run: if a queued pass
+ * left the split-f16 range, css_wait repeats every pass queued since the last css_wait on the exact float32 kernels (from
+ * the caller's buffers, which it still holds) and css_range_status reports it; with css_set_range_fallback(h, 0) css_wait
+ * returns CSS_ERR_RANGE instead. */
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     float* wav_host, int64_t cap);
 /* Blocks until every pass queued on h has finished (results in their wav_host buffers); CssTimings describe the last. */

@@ -131,6 +131,11 @@ struct css_ctx {
     hipEvent_t tail_end = nullptr;
     bool tail_pending = false;
     bool piped_now = false;   // run_once -> begin_impl: the level word is cleared on the copy stream, not here
+    int last_piped = -1;      // overlap mode of the last queued pass (-1: nothing queued): a queue never mixes modes un-drained
+    // css_run_enqueue's arguments since the last css_wait: a queued pass that left the split-f16 range is repeated from
+    // them on the exact float32 kernels (the caller keeps pcm_host valid and wav_host untouched until css_wait anyway)
+    struct QueuedPass { const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; float* wav; int64_t cap; };
+    std::vector<QueuedPass> queue_log;
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
     std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -656,6 +661,18 @@ static int upload_pcm(css_handle_t h, const float* pcm_host, int64_t s_lo, int64
     return CSS_OK;
 }
 
+// The level (power-of-two gain of the split synthesis operand) is the peak of the samples some FRAME reads,
+// [0, (stft_frames - 1) * hop + frame_len): the up to hop - 1 trailing samples no frame covers are left out, so that
+// the fused pass, the staged pass and every sharding of it (parallel.py uploads exactly the covered ranges) scan the
+// same samples and agree bit for bit whatever the tail holds.
+static inline int64_t covered_end(const css_ctx* h) {
+    const int64_t fr = h->plan.stft_frames;
+    return fr > 0 ? std::min<int64_t>((fr - 1) * h->d.frame_hop + h->d.frame_len, h->plan.n_samples) : 0;
+}
+static inline int64_t peak_len(const css_ctx* h, int64_t s_lo, int64_t s_hi) {   // samples of [s_lo, s_hi) to scan
+    return std::max<int64_t>(std::min<int64_t>(s_hi, covered_end(h)) - s_lo, 0);
+}
+
 int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, int pcm_is_device) {
     CSS_DRAIN(h);
     if (!h || !pcm) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
@@ -663,7 +680,7 @@ int css_begin(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch,
     const int rc = begin_impl(h, n_samples, n_ch, cfg);
     if (rc != CSS_OK) return rc;
     h->pcm_src = pcm;
-    launch_pcm_peak_f32(pcm, n_samples * n_ch, h->peak_dev, h->stream);
+    launch_pcm_peak_f32(pcm, peak_len(h, 0, n_samples) * n_ch, h->peak_dev, h->stream);
     hipEventRecord(h->ev[1], h->stream);
     return CSS_OK;
 }
@@ -678,7 +695,7 @@ int css_begin_range(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     if ((rc = ensure(h, h->pcm_in, (size_t)n_samples * n_ch * sizeof(float))) != CSS_OK) return rc;
     h->pcm_src = (const float*)h->pcm_in.p;
     if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->stream)) != CSS_OK) return rc;
-    launch_pcm_peak_f32(h->pcm_src + s_lo * n_ch, (s_hi - s_lo) * n_ch, h->peak_dev, h->stream);
+    launch_pcm_peak_f32(h->pcm_src + s_lo * n_ch, peak_len(h, s_lo, s_hi) * n_ch, h->peak_dev, h->stream);
     hipEventRecord(h->ev[1], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -702,7 +719,7 @@ int css_upload_range(css_handle_t h, const float* pcm_host, int64_t s_lo, int64_
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, opened, 0));
     }
     if ((rc = upload_pcm(h, pcm_host, s_lo, s_hi, h->copy_stream)) != CSS_OK) return rc;
-    launch_pcm_peak_f32(h->pcm_src + s_lo * h->n_ch, (s_hi - s_lo) * h->n_ch, h->peak_dev, h->copy_stream);
+    launch_pcm_peak_f32(h->pcm_src + s_lo * h->n_ch, peak_len(h, s_lo, s_hi) * h->n_ch, h->peak_dev, h->copy_stream);
     HIPCHK(h, hipEventRecord(landed, h->copy_stream));
     h->uploads.push_back({s_lo, s_hi, landed});
     HIPCHK(h, hipGetLastError());
@@ -1205,7 +1222,20 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         wav_mapped = (float*)h->mapped_val;
     }
     // queued passes OVERLAP when the output is page-locked (see css_ctx::pass_no); otherwise they just queue up
-    const bool piped = io.enqueue_only && io.pcm_host && wav_mapped;
+    // (with the beamformer on the tail stream -- CSS_TUNE_MVDR_ON_LANES = 0 -- a tail also reads the spectra X, which the
+    // next pass's transform overwrites: such passes queue up without overlapping)
+    const bool piped = io.enqueue_only && io.pcm_host && wav_mapped && h->tune[CSS_TUNE_MVDR_ON_LANES];
+    if (io.enqueue_only && h->queued && h->last_piped != (int)piped) {
+        // the overlap mode changes inside a queue (a page-locked output follows a pageable one or the reverse): the two
+        // modes order the level word, the mask buffers and the tail differently, so the queue is drained on the device
+        // first (its bookkeeping -- css_wait, the range verdict -- stays with the caller)
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->tail_stream));
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        h->tail_pending = false;
+    }
+    if (io.enqueue_only) h->last_piped = (int)piped;
     const int par = piped ? (int)(h->pass_no & 1) : 0;
     h->peak_dev = (unsigned int*)h->level.p + 8 * par;
     h->piped_now = piped;
@@ -1240,7 +1270,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // its lanes, beamformer, costs, scan, overlap-add, gate, synthesis on one stream) measures 2 % ahead of the unit
     // pipeline below (profiles/r02_shard_overhead.md: 5.35 vs 5.43 ms per 60 s meeting, 143.0 vs 146.2 ms per 30 min)
     if (io.pcm_dev && io.wav_dev && !h->tune[CSS_TUNE_PIPELINE_DEVICE]) {
-        launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->stream);
+        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->stream);
         if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
         if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
         if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
@@ -1323,16 +1353,16 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             }
             HIPCHK(h, hipEventRecord(u.up, h->copy_stream));
             // the recording's level (power-of-two gain of the split synthesis operand) piece by piece, beside the next upload
-            if (io.pcm_host) launch_pcm_peak_f32(h->pcm_src + u.s_lo * n_ch, (u.s_hi - u.s_lo) * n_ch, h->peak_dev, h->copy_stream);
+            if (io.pcm_host) launch_pcm_peak_f32(h->pcm_src + u.s_lo * n_ch, peak_len(h, u.s_lo, u.s_hi) * n_ch, h->peak_dev, h->copy_stream);
             else
                 for (int c = 0; c < n_ch; ++c)
-                    launch_pcm_peak_i16(planes_dev + (size_t)c * n + u.s_lo, u.s_hi - u.s_lo, h->peak_dev, h->copy_stream);
+                    launch_pcm_peak_i16(planes_dev + (size_t)c * n + u.s_lo, peak_len(h, u.s_lo, u.s_hi), h->peak_dev, h->copy_stream);
         }
         hipEvent_t level = pool_event(h);
         HIPCHK(h, hipEventRecord(level, h->copy_stream));
         HIPCHK(h, hipStreamWaitEvent(h->tail_stream, level, 0));
     } else {
-        launch_pcm_peak_f32(h->pcm_src, n * n_ch, h->peak_dev, h->tail_stream);
+        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->tail_stream);
     }
     if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
         HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
@@ -1366,8 +1396,8 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         const int64_t g_end = last ? TL : std::max<int64_t>(t_done - halo, g_done);
         if (g_end > g_done || last) {
             { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, g_done, g_end, ts); }
-            // the last range leaves in two pieces, so that the first piece's download runs beside the second's synthesis
-            // (more pieces do not pay: these launches are latency-bound, a fifth of the frames costs what all of them cost)
+            // the last range may leave in CSS_TUNE_TAIL_PIECES pieces (default 1), the first piece's download beside the
+            // second's synthesis: measured no gain -- these launches are latency-bound, a fifth of the frames costs what all cost
             const int pieces = (last && io.wav_host && g_end - g_done >= 512) ? std::max(h->tune[CSS_TUNE_TAIL_PIECES], 1) : 1;
             const int64_t g_first = g_done;
             for (int pc = 0; pc < pieces; ++pc) {
@@ -1536,7 +1566,9 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
                     float* wav_host, int64_t cap) {
     if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
-    return run_once(h, n_samples, n_ch, cfg, io);
+    const int rc = run_once(h, n_samples, n_ch, cfg, io);
+    if (rc == CSS_OK) h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
+    return rc;
 }
 
 int css_wait(css_handle_t h) {
@@ -1552,14 +1584,28 @@ int css_wait(css_handle_t h) {
     const auto t1 = std::chrono::steady_clock::now();
     h->queued = 0;
     h->tail_pending = false;
+    h->last_piped = -1;
     h->pass_no = 0;
     h->peak_dev = (unsigned int*)h->level.p;
     finish_timings(h, t0, t0, t1, false);
     h->range_last = 0;
-    if (*h->range_flag_host && h->split) {   // the inputs are the caller's: nothing to repeat here
+    std::vector<css_ctx::QueuedPass> log;
+    log.swap(h->queue_log);
+    if (*h->range_flag_host && h->split) {
+        // the same rule as css_run: the queued passes accumulate into one range word, so every pass queued since the last
+        // css_wait is repeated, one by one, on the exact float32 kernels (their inputs are still the caller's to keep)
         h->range_last = 1;
-        return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range in one of the queued passes: "
-                                      "repeat them with css_run (automatic float32 repeat) or in CSS_LINEAR_EXACT_F32");
+        if (!h->range_fallback)
+            return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range in one of the queued passes "
+                                          "(|x| > 65504): use CSS_LINEAR_EXACT_F32");
+        int rc = css_set_linear_mode(h, CSS_LINEAR_EXACT_F32);
+        for (size_t i = 0; i < log.size() && rc == CSS_OK; ++i) {
+            RunIo io; io.pcm_host = log[i].pcm; io.wav_host = log[i].wav; io.cap = log[i].cap;
+            rc = run_once(h, log[i].n, log[i].n_ch, &log[i].cfg, io);
+        }
+        const int rc2 = css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16);
+        h->range_fallbacks += (int64_t)log.size();
+        return rc != CSS_OK ? rc : rc2;
     }
     return CSS_OK;
 }

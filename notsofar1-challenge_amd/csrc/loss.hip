@@ -9,8 +9,9 @@ constexpr int LOSS_FB = 8;   // bins per block
 
 // X: mixture planes [C][2F][B*T] (clip b in columns [bT, (b+1)T)); masks [(S+1)F][B*T]; G: ground-truth planes
 // [B*(S+1)][2F][T] (speaker s of clip b at b*(S+1) + s, the noise at b*(S+1) + S).
-// partial[(b * chunks + chunk) * 16 + a*S + s] = sum over the chunk's bins and all frames of base(pred_a, target_s),
-// [.. + 15] = the noise term; summed by the host in chunk order and divided by F*T.
+// partial[(b * chunks + chunk) * 16 + a*3 + s] = sum over the chunk's bins and all frames of base(pred_a, target_s)
+// (a, s < S <= 3; row stride 3 whatever S), [.. + 9] = the noise term, [.. + 10 .. 15] unused; summed by the host in
+// chunk order and divided by F*T.
 __global__ __launch_bounds__(256) void val_loss_kernel(const float* __restrict__ X, const float* __restrict__ masks,
                                                        const float* __restrict__ G, int B, int T, int F, int S,
                                                        int loss_name, int base, int clip, double* __restrict__ partial) {

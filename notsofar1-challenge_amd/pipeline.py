@@ -23,7 +23,7 @@ from pathlib import Path
 from typing import Dict, Optional
 
 from .css import CssCfg, css_inference
-from .separator import load_css_model
+from .separator import _device_index, load_css_model
 
 _LOG = logging.getLogger('css')
 
@@ -46,7 +46,13 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
     rank, world = _rank_world(rank, world)
     if device is None:
         device = f"cuda:{int(os.environ.get('LOCAL_RANK', cfg.device_id))}"
-    dev_index = int(str(device).split(":")[1]) if ":" in str(device) else int(cfg.device_id)
+    # one index for the resident model AND for css_inference's `separator.to(cuda:<device_id>)`: an int, "cuda:1" or a
+    # torch.device all name the same GPU (a mismatch would rebuild the resident handle on another device per session)
+    if isinstance(device, int) or ":" in str(device):
+        dev_index = _device_index(device)
+    else:   # "cuda" / torch.device("cuda") without an index: the configured device
+        dev_index = int(cfg.device_id)
+    device = f"cuda:{dev_index}"
     cfg = dataclasses.replace(cfg, device_id=dev_index)
     resident: Dict[bool, object] = {}
     rows = []

@@ -156,16 +156,23 @@ def test_out_of_range_pass_is_repeated_in_float32(mc_state, mix60):
         with pytest.raises(L.CssError) as e:
             h.run(mix, run_cfg)
         assert e.value.code == L.CSS_ERR_RANGE
-        # queued passes have no automatic repeat (the inputs are the caller's): css_wait reports the range error, and the
-        # handle is usable afterwards -- the synchronous call repeats in float32 as before
+        # queued passes follow the same rule: css_wait repeats every pass queued since the last css_wait on the exact float32
+        # kernels (from the caller's buffers) and reports it; with the fallback off it returns CSS_ERR_RANGE
         h.set_range_fallback(True)
+        before = h.range_status()[0]
         pin = L.pinned_copy(mix)
-        out = L.pinned_empty(ref.shape, np.float32)
+        out, out2 = L.pinned_empty(ref.shape, np.float32), np.empty(ref.shape, np.float32)
         h.run_enqueue(pin, run_cfg, out)
+        h.run_enqueue(pin, run_cfg, out2)        # (pageable output: the queue changes mode in between)
+        h.wait()
+        assert h.range_status() == (before + 2, True) and h.linear_mode() == "split_f16"
+        assert np.array_equal(out, ref) and np.array_equal(out2, ref)
+        h.set_range_fallback(False)
         h.run_enqueue(pin, run_cfg, out)
         with pytest.raises(L.CssError) as e:
             h.wait()
         assert e.value.code == L.CSS_ERR_RANGE
+        h.set_range_fallback(True)
         assert np.array_equal(h.run(mix, run_cfg), ref)
     finally:
         sep.close()

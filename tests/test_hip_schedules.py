@@ -123,6 +123,43 @@ def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinne
         sep.close()
 
 
+def test_queue_that_mixes_page_locked_and_pageable_outputs(mc_state):
+    """One queue, outputs alternately page-locked (passes overlap: level word / sample buffer by parity, tail beside the
+    next estimator) and pageable (passes queue up on the main stream): the two modes order the shared buffers differently,
+    so the library drains the device whenever the mode changes inside a queue.  Full estimator (the host runs ahead),
+    sessions of different lengths and LEVELS (a wrong level word shows as a power-of-two gain error), both orders; also
+    with the beamformer moved to the tail stream (CSS_TUNE_MVDR_ON_LANES = 0: such passes must not overlap at all)."""
+    L, CSS = pkg("_lib"), pkg("css")
+    st, desc = mc_state
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([20.0, 27.0, 34.0, 20.0, 41.0, 23.0]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=500 + k)
+            pcm = L.pinned_copy(np.ascontiguousarray(mix[0] * (0.003 if k % 2 else 1.0)))
+            sessions.append((pcm, h.run(pcm, run_cfg).copy()))
+        for first_pinned in (True, False):
+            outs = []
+            for k, (pcm, ref) in enumerate(sessions):
+                pinned = (k % 2 == 0) == first_pinned
+                out = L.pinned_empty(ref.shape, np.float32) if pinned else np.empty(ref.shape, np.float32)
+                out[:] = np.nan
+                outs.append(h.run_enqueue(pcm, run_cfg, out))
+            h.wait()
+            for k, (got, (_, ref)) in enumerate(zip(outs, sessions)):
+                assert np.array_equal(got, ref), (first_pinned, k, float(np.abs(got - ref).max()))
+        h.set_tuning("mvdr_on_lanes", 0)
+        outs = [h.run_enqueue(pcm, run_cfg, L.pinned_empty(ref.shape, np.float32)) for pcm, ref in sessions]
+        h.wait()
+        h.set_tuning("mvdr_on_lanes", 1)
+        for k, (got, (_, ref)) in enumerate(zip(outs, sessions)):
+            assert np.array_equal(got, ref), ("mvdr on the tail stream", k)
+    finally:
+        sep.close()
+
+
 def test_queued_sessions_with_the_host_passes_ahead(mc_state):
     """The full 18-block estimator keeps the device busy for several milliseconds per session while the host enqueues a
     session in two: the host runs passes ahead, so everything a queued pass re-uses (sample buffer half, level word,
