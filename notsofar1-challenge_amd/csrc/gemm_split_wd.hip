@@ -37,7 +37,9 @@ constexpr int WD_BM = 128;
 // kt+1, the LDS stores of slab kt+2 and the global loads of slab kt+3 / weights kt+1 are spread between the MFMAs
 // of slab kt (sched_group_barrier pattern): an MFMA leaves ~5 issue slots free while it runs, and with one or two
 // waves per SIMD nothing else would hide those instructions.
-template <int BM, int WMV>
+// BUF: operand loads as buffer loads (resource descriptor in SGPRs + 32-bit lane offset + scalar slab offset) instead of
+// 64-bit-per-lane global loads: half the address registers through the issue path, no 64-bit pointer arithmetic per slab
+template <int BM, int WMV, bool BUF = false>
 __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 ? 2 : 3) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WMV * 256;
     constexpr int TM = BM / 32 / WMV;           // 32-row tiles per wave
@@ -89,13 +91,28 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     f32x16 cor0 = {0}, cor1 = {0}, cor2 = {0}, cor3 = {0};   // the 2^-11-scaled cross terms
 #define CSS_KOFF(kt_) (((kt_) * BK) < klast ? ((kt_) * BK) : klast)
 #define CSS_KT(kt_) ((kt_) < nk ? (kt_) : nk - 1)
-#define CSS_G1(i, st, k0) if constexpr (i < NLA) stg##st##_##i = *reinterpret_cast<const float4*>(pa##i + (k0));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)((int64_t)M * g.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)((int64_t)(jt_max + 1) * 32 * g.K * 4), 0x00020000);
+#define CSS_VOFFA(i) (unsigned)(((int64_t)((m0 + lr + (i) * LROWS) < M ? (m0 + lr + (i) * LROWS) : M - 1) * g.lda + lc) * 4)
+    const unsigned va0 = CSS_VOFFA(0), va1 = CSS_VOFFA(1), va2 = CSS_VOFFA(NLA > 2 ? 2 : 0), va3 = CSS_VOFFA(NLA > 2 ? 3 : 0);
+#undef CSS_VOFFA
+    const unsigned vw = (unsigned)(((int64_t)jt * (g.K / 16) * 2 * 64 + lane) * 16);
+#define CSS_G1(i, st, k0)                                                                                                  \
+    if constexpr (i < NLA) {                                                                                               \
+        if constexpr (BUF) stg##st##_##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, va##i, (k0) * 4, 0)); \
+        else stg##st##_##i = *reinterpret_cast<const float4*>(pa##i + (k0));                                               \
+    }
 #define CSS_GLOAD(st, k0) CSS_I4(CSS_G1, st, k0)
 #define CSS_L1(i, st, buf) \
     if constexpr (i < NLA) *reinterpret_cast<float4*>(lds + (buf) * STAGE + (lr + i * LROWS) * LDS_LD + lc) = stg##st##_##i;
 #define CSS_LSTORE(st, buf) CSS_I4(CSS_L1, st, buf)
 #define CSS_W1(i, st, q_) wr##st##_##i = (q_)[i * 64];
-#define CSS_WLOAD(st, kt_) { const float4* q_ = pw + (int64_t)(kt_) * 4 * 64; CSS_I4(CSS_W1, st, q_) }
+#define CSS_W1B(i, st, so_) wr##st##_##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsW, vw + i * 1024, so_, 0));
+#define CSS_WLOAD(st, kt_)                                                                       \
+    {                                                                                            \
+        if constexpr (BUF) { const int so_ = (kt_) * 4096; CSS_I4(CSS_W1B, st, so_) }            \
+        else { const float4* q_ = pw + (int64_t)(kt_) * 4 * 64; CSS_I4(CSS_W1, st, q_) }         \
+    }
     const float* as0 = lds + (wm * (BM / WMV) + c) * LDS_LD + 4 * h;
     // operand o = row tile (o & 3) + 4 * kk (o >> 2)
 #define CSS_A1(o, st, buf)                                                                                    \
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
 #undef CSS_L1
 #undef CSS_WLOAD
 #undef CSS_W1
+#undef CSS_W1B
 #undef CSS_I4
 #undef CSS_I8
 }
@@ -269,19 +287,31 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     const GemmArgs& g = g_in;
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
     const int pick = g.tile_rows;
+    // 128 x 128 tiles through LDS DMA with specialised waves (gemm_split_dma.hip): same bits; tile_rows = 3 asks for it,
+    // the automatic choice follows gemm_split_ws_pays() (which is "never" today: see that function)
+    if ((pick == 3 || (!pick && gemm_split_ws_pays(g))) && gemm_split_ws_eligible(g)) {
+        GemmArgs q = g;
+        q.tile_rows = 3;
+        return launch_gemm_split_dma(q, s);
+    }
+    // (buffer loads -- BUF = true -- measured 1-6 % ahead of 64-bit global loads on every shape of the path, same bits;
+    // tile_rows = 65 keeps the global-load form of the 64-row kernel for A/B timing: tools/gemm_dma_bench.hip)
     if (pick == 32) {
         const int tm32 = (g.M + 31) / 32;
-        hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);
+        hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1, true>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);
     } else if (pick == 96) {
         const int tm96 = (g.M + 95) / 96;
-        hipLaunchKernelGGL((gemm_split_wd_kernel<96, 1>), dim3(tm96 * tiles_n), dim3(256), 0, s, g, tm96, tiles_n);
+        hipLaunchKernelGGL((gemm_split_wd_kernel<96, 1, true>), dim3(tm96 * tiles_n), dim3(256), 0, s, g, tm96, tiles_n);
     } else if (pick == 4) {
-        hipLaunchKernelGGL((gemm_split_wd_kernel<128, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g, tiles_m, tiles_n);
-    } else if (pick == 64 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
+        hipLaunchKernelGGL((gemm_split_wd_kernel<128, 1, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g, tiles_m, tiles_n);
+    } else if (pick == 65) {
         const int tm64 = (g.M + 63) / 64;
-        hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
+        hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, false>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
+    } else if (pick == 64 || pick == 3 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
+        const int tm64 = (g.M + 63) / 64;
+        hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
     } else {
-        hipLaunchKernelGGL((gemm_split_wd_kernel<128, 2>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_split_wd_kernel<128, 2, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g, tiles_m, tiles_n);
     }
 }
 

@@ -10,7 +10,7 @@ from conftest import pkg
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128)),
+KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128, 3)),   # 3: 128 x 128 tiles, both operands by LDS DMA
            1: ("split-f16, LDS staged", (0, 8, 4, 64)),
            2: ("exact float32", (0, 8, 4, 64))}
 
@@ -72,7 +72,8 @@ def test_small_magnitude_regime_is_bounded(handle):
 
 
 @pytest.mark.parametrize("shape", [(100, 512, 512), (7440, 1536, 512), (23808, 512, 1024), (1028, 22506, 512),
-                                   (28125, 512, 544), (777, 1028, 1824)])
+                                   (28125, 512, 544), (777, 1028, 1824), (7440, 512, 512), (7440, 512, 32), (7440, 512, 64),
+                                   (7441, 512, 96), (129, 128, 1024)])
 def test_tile_layouts_give_the_same_bits(handle, shape):
     """Every tile layout of a kernel, and the launcher's own choice at this shape, writes the same bits -- including
     the large launches (long meetings, 128-segment batches) where the launcher switches layouts."""

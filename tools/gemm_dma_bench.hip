@@ -1,0 +1,94 @@
+// gemm_split_dma.hip against gemm_split_wd.hip on the shapes of the CSS path: bit-for-bit comparison of every output
+// (row-major C and the attention's fragment buffer) and launch times (tools only, not shipped).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_dma_bench.hip notsofar1-challenge_amd/csrc/gemm.hip \
+//     notsofar1-challenge_amd/csrc/gemm_split.hip notsofar1-challenge_amd/csrc/gemm_split_wd.hip \
+//     notsofar1-challenge_amd/csrc/gemm_split_dma.hip -Inotsofar1-challenge_amd/csrc -o /tmp/gemm_dma_bench
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+using namespace css;
+
+int main(int argc, char** argv) {
+    struct Shape { int N, K; const char* name; int kind; };   // kind 0: relu + split out, 1: residual, 2: qkv (frag), 3: bias only f32
+    Shape shapes[] = {{512, 512, "attn-out", 1}, {1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 2},
+                      {512, 1824, "embed", 3}};
+    std::vector<int> Ms = {7440, 2480, 23808};
+    if (argc > 1) { Ms.clear(); for (int i = 1; i < argc; ++i) Ms.push_back(atoi(argv[i])); }
+    std::vector<int> variants = {65, 3};
+    if (getenv("ABLATE")) variants = {24, 3, 2001, 2002, 2004, 2006};
+    const int T = 186, H = 8, D = 512;
+    const size_t maxe = 24000ull * 1824;
+    float *A, *B, *Bt, *As, *C[2], *R, *bias, *frag[2];
+    unsigned int* flag;
+    hipMalloc(&A, maxe * 4); hipMalloc(&As, maxe * 4); hipMalloc(&B, 1536 * 1824 * 4); hipMalloc(&Bt, 1536 * 1824 * 4);
+    hipMalloc(&C[0], maxe * 4); hipMalloc(&C[1], maxe * 4); hipMalloc(&R, maxe * 4); hipMalloc(&bias, 4096 * 4);
+    const size_t fragf = (size_t)qk_fragment_floats(24000 / T + 1, T, H);
+    hipMalloc(&frag[0], fragf * 4); hipMalloc(&frag[1], fragf * 4);
+    hipMalloc(&flag, 64); hipMemset(flag, 0, 64);
+    std::vector<float> h(maxe);
+    unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    hipMemcpy(A, h.data(), maxe * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data() + 12345, 1536 * 1824 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(R, h.data() + 777, (maxe - 777) * 4, hipMemcpyHostToDevice); hipMemcpy(bias, h.data() + 99, 4096 * 4, hipMemcpyHostToDevice);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> c0, c1;
+    int bad_total = 0;
+    for (int M : Ms) for (auto& sh : shapes) {
+        launch_split_convert(A, sh.K, As, M, sh.K, sh.K, st);
+        launch_split_convert_tiled(B, sh.K, Bt, sh.N, sh.K, st);
+        hipStreamSynchronize(st);
+        auto args = [&](int which) {
+            GemmArgs g{};
+            g.A = As; g.lda = sh.K; g.B = Bt; g.ldb = sh.K; g.C = C[which]; g.ldc = sh.N; g.M = M; g.N = sh.N; g.K = sh.K; g.batch = 1;
+            g.alpha = 1.f; g.split_in = 1; g.b_tiled = 1; g.bias = bias; g.range_flag = flag;
+            if (sh.kind == 0) { g.act = ACT_RELU; g.split_out = sh.N; }
+            if (sh.kind == 1) { g.residual = R; g.ldr = sh.N; g.alpha = 0.5f; }
+            if (sh.kind == 2) { g.split_out = sh.N; g.frag_out = frag[which]; g.frag_D = D; g.frag_T = T; g.frag_heads = H; g.frag_invT = 1.0f / T; }
+            return g;
+        };
+        auto timeit = [&](auto&& launch) {
+            for (int i = 0; i < 3; ++i) launch();
+            hipStreamSynchronize(st);
+            const int it = 20;
+            hipEventRecord(e0, st);
+            for (int i = 0; i < it; ++i) launch();
+            hipEventRecord(e1, st); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            return 1e3 * ms / it;
+        };
+        const double fl = 2.0 * M * sh.N * sh.K;
+        hipMemsetAsync(C[0], 0xFF, (size_t)M * sh.N * 4, st); hipMemsetAsync(frag[0], 0, fragf * 4, st);
+        GemmArgs g0 = args(0); g0.tile_rows = 64;
+        const double t0 = timeit([&] { launch_gemm_split_wd(g0, st); });
+        printf("M=%5d %-9s N=%4d K=%4d : wd64 %6.2f us %4.0f TF |", M, sh.name, sh.N, sh.K, t0, fl / t0 / 1e6);
+        c0.resize((size_t)M * sh.N); hipMemcpy(c0.data(), C[0], c0.size() * 4, hipMemcpyDeviceToHost);
+        std::vector<float> f0(sh.kind == 2 ? fragf : 0), f1(f0.size());
+        if (sh.kind == 2) hipMemcpy(f0.data(), frag[0], fragf * 4, hipMemcpyDeviceToHost);
+        for (int v : variants) {
+            hipMemsetAsync(C[1], 0xFF, (size_t)M * sh.N * 4, st); hipMemsetAsync(frag[1], 0, fragf * 4, st);
+            GemmArgs g1 = args(1); g1.tile_rows = v;
+            const double t1 = timeit([&] { if (v == 65) launch_gemm_split_wd(g1, st); else launch_gemm_split_dma(g1, st); });
+            c1.resize(c0.size()); hipMemcpy(c1.data(), C[1], c1.size() * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0, first = 0;
+            // q / k columns of the qkv launch are not written to C (they leave in fragment order): compare only what is written
+            for (size_t i = 0; i < c0.size(); ++i)
+                if (memcmp(&c0[i], &c1[i], 4)) { if (!bad) first = i; ++bad; }
+            if (sh.kind == 2) {
+                hipMemcpy(f1.data(), frag[1], fragf * 4, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < f0.size(); ++i) if (memcmp(&f0[i], &f1[i], 4)) { if (!bad) first = i; ++bad; }
+            }
+            printf(" dma%-4d %6.2f us %4.0f TF %s", v, t1, fl / t1 / 1e6, v > 1000 ? "-" : bad ? "MISMATCH" : "same");
+            if (v > 1000) bad = 0;
+            if (bad) printf("(%zu, first %zu: %g vs %g)", bad, first, first < c0.size() ? c0[first] : 0.f, first < c1.size() ? c1[first] : 0.f);
+            bad_total += bad != 0;
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    unsigned int fl_ = 0; hipMemcpy(&fl_, flag, 4, hipMemcpyDeviceToHost);
+    printf("range flag %u, mismatching cases %d\n", fl_, bad_total);
+    return bad_total != 0;
+}

@@ -16,12 +16,12 @@ print("| kernel | launches | total ms | avg us | min us | max us | share |")
 print("|---|---:|---:|---:|---:|---:|---:|")
 for name, r in g.iterrows():
     print(f"| `{name}` | {int(r['count'])} | {r['sum'] / 1e3:.2f} | {r['mean']:.2f} | {r['min']:.2f} | {r['max']:.2f} | {100 * r['sum'] / tot:.1f}% |")
-gm = df[df["Kernel_Name"].str.contains("gemm_kernel|gemm_split")].copy()
+gm = df[df["Kernel_Name"].str.contains("gemm_kernel|gemm_split|gemm_split_ws")].copy()
 if len(gm):
     gm["blocks"] = gm["Grid_Size_X"] // gm["Workgroup_Size_X"]
     print("\n## GEMM kernels (css::gemm_kernel, gemm_split_kernel, gemm_split_wd_kernel) by launch shape\n")
     print("| workgroups | threads/wg | launches | avg us |")
     print("|---:|---:|---:|---:|")
-    for (b, w), r in gm.groupby(["blocks", "Workgroup_Size_X"])["dur_us"].agg(["count", "mean"]).iterrows():
-        print(f"| {b} | {w} | {int(r['count'])} | {r['mean']:.2f} |")
+    for (kn, b, w), r in gm.groupby(["Kernel_Name", "blocks", "Workgroup_Size_X"])["dur_us"].agg(["count", "mean"]).iterrows():
+        print(f"| {kn[:34]} {b} | {w} | {int(r['count'])} | {r['mean']:.2f} |")
     print(f"\nGEMM launches: {len(gm)}, average duration {gm['dur_us'].mean():.2f} us")
