@@ -145,8 +145,9 @@ def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg:
     assert speech_mix.ndim == 3, f'expecting 3 dimensions, got {speech_mix.shape}'
     assert speech_mix.shape[0] == 1, 'assuming 1 example in batch. easy to support more.'
     if not isinstance(separator, HipSeparator):
-        raise TypeError("separate_and_stitch runs the fused HIP path and needs a HipSeparator; build one with "
-                        "HipSeparator(state_dict, cfg) or load_css_model(model_dir)")
+        # the reference's customisation point (README: "implement stft / separate / istft"): any object with the
+        # separator protocol supplies the masks, everything around it runs on the HIP stages
+        return _separate_and_stitch_protocol(speech_mix, separator, fs, device, cfg, return_side_info)
     assert not separator.training
     separator.to(device)
     desc = separator.desc
@@ -169,6 +170,106 @@ def separate_and_stitch(speech_mix: np.ndarray, separator, fs: int, device, cfg:
         'segment_frames': int(run_cfg.c.segment_frames),
     }
     return separated_wavs, side_info
+
+
+_STAGE_SEPARATORS: Dict[tuple, HipSeparator] = {}
+
+
+def _stage_separator(num_mics: int, num_spks: int, device) -> HipSeparator:
+    """A handle for the HIP stages around a foreign mask estimator: the library wants a model at css_create, so this is a
+    one-block stand-in (2 MB of seeded weights) whose estimator is never launched.  One per (microphones, speakers, GPU)."""
+    from .separator import _device_index
+    from .weights import ModelDesc, portable_state_dict
+    key = (num_mics, num_spks, _device_index(device))
+    sep = _STAGE_SEPARATORS.get(key)
+    if sep is None:
+        bins = 257
+        desc = ModelDesc(num_mics=num_mics, num_bins=bins, in_features=bins * (1 + (num_mics - 1 if num_mics > 1 else 0)),
+                         attention_dim=256, attention_heads=4, linear_units=256, num_blocks=1, num_spks=num_spks)
+        sep = _STAGE_SEPARATORS[key] = HipSeparator(portable_state_dict(desc, 0), None, device=device)
+        assert (sep.desc.num_mics, sep.desc.num_spks) == (num_mics, num_spks)
+    return sep
+
+
+def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, device, cfg: CssCfg, return_side_info: bool):
+    """css/css.py:110-338 for ANY object that honours the separator protocol (css.py:131: `stft`, `separate`, `istft`;
+    conformer_wrapper.py:79-146).  As in the reference, `separator.separate(stft_seg)` is called once per segment with a
+    complex tensor [1, F, T, C] on `device` (css.py:183-199; zero-padded last segment) and returns
+    {'spk_masks': [1, F, T, S], 'noise_masks': [1, F, T, 1]}.  Everything else -- analysis transform of the whole
+    recording, winner-take-all masks / covariances / MVDR, mask floor, stitching, gate, synthesis -- runs on the HIP
+    stages of the C ABI (css_begin, css_stage_stft, css_stage_mvdr, ..., css_stage_istft); the masks go straight into the
+    library's device buffer through a zero-copy torch view.  Nothing is computed on the host.
+
+    The stages implement the transform of the reference's ConformerCssWrapper (512-point Hann analysis, hop 256, sqrt-Hann
+    synthesis, feature.py:88-167); a separator whose own `stft` is a different transform is rejected: its masks would not
+    belong to these spectra."""
+    import torch
+    from .parallel import HipShardBackend
+    assert not getattr(separator, "training", False)
+    n, c = speech_mix.shape[1], speech_mix.shape[2]
+    S = cfg.num_spks
+    stage = _stage_separator(c, S, device)
+    desc = stage.desc
+    run_cfg = make_run_cfg(cfg, fs, c, desc.frame_len, desc.frame_hop)
+    h = stage.handle
+    dev = torch.device("cuda", stage._device)
+    if hasattr(separator, "to"):
+        separator.to(dev)
+    be = HipShardBackend(h, dev)
+    F, T, hop = desc.num_bins, int(run_cfg.c.segment_frames), int(run_cfg.c.hop_frames)
+    try:
+        h.begin(np.ascontiguousarray(speech_mix[0], dtype=np.float32), n, c, run_cfg)
+        h.stage_stft()
+        plan = h.get_plan()
+        nseg, TL, frames = int(plan.num_segments), int(plan.mix_frames), int(plan.stft_frames)
+        with be.on_stream(), torch.no_grad():
+            X = be._view(_lib.BUF_X, "<f4")                      # [C, 2F, T_ld]: rows 0..F-1 real, F..2F-1 imaginary
+            masks = be._view(_lib.BUF_MASKS, "<f4")              # [(S + 1) F, nseg * T]
+            assert tuple(masks.shape) == ((S + 1) * F, nseg * T), (masks.shape, S, F, nseg, T)
+            # the separator's own transform must be the stages' transform (checked on the first frames of the recording)
+            if hasattr(separator, "stft"):
+                probe = torch.from_numpy(np.ascontiguousarray(speech_mix[:, :desc.frame_len + 3 * desc.frame_hop])).to(dev)
+                theirs = separator.stft(probe if c > 1 else probe[..., 0])
+                theirs = theirs.reshape(1, F, -1, c) if theirs.ndim == 3 else theirs
+                k = min(theirs.shape[2], frames)
+                ours = torch.complex(X[:, :F, :k], X[:, F:2 * F, :k]).permute(1, 2, 0)[None]
+                scale = float(ours.abs().max()) + 1e-30
+                if tuple(theirs.shape[:2]) != (1, F) or float((theirs[:, :, :k].to(dev) - ours).abs().max()) > 1e-3 * scale:
+                    raise ValueError("the separator's stft() is not the transform of the HIP stages (512-point Hann, hop 256, "
+                                     "conformer_wrapper.py:106-129): its masks cannot be applied to these spectra")
+            for i in range(nseg):                                # css.py:182-250, one call per segment as in the reference
+                t = max(min(T, frames - i * hop), 0)
+                seg = torch.zeros((1, F, T, c), dtype=torch.complex64, device=dev)
+                if t > 0:
+                    blk = X[:, :, i * hop:i * hop + t]
+                    seg[0, :, :t, :] = torch.complex(blk[:, :F], blk[:, F:2 * F]).permute(1, 2, 0)
+                out = separator.separate(seg if c > 1 else seg[..., 0])
+                spk, noi = out['spk_masks'], out['noise_masks']
+                assert tuple(spk.shape) == (1, F, T, S), f'spk_masks {tuple(spk.shape)}, expected {(1, F, T, S)}'   # css.py:202
+                assert tuple(noi.shape) == (1, F, T, 1), f'noise_masks {tuple(noi.shape)}, expected {(1, F, T, 1)}'  # css.py:203
+                both = torch.cat([spk, noi], dim=3)[0].to(device=dev, dtype=torch.float32)      # [F, T, S + 1]
+                masks[:, i * T:(i + 1) * T] = both.permute(2, 0, 1).reshape((S + 1) * F, T)
+        h.stage_mvdr(0, nseg)
+        h.stage_pit_costs(0, nseg - 1)
+        h.stage_pit_scan()
+        h.stage_stitch(0, TL)
+        h.stage_istft(0, TL)
+        h.check_range()
+        wav = h.read(_lib.BUF_WAV)
+        separated_wavs = [wav[k] for k in range(S)]
+        if not return_side_info:
+            return separated_wavs, {}
+        mask_st = h.read(_lib.BUF_MASK_ST)
+        act_b = h.read(_lib.BUF_ACT_B).astype(bool)
+        act_final = h.read(_lib.BUF_ACT_FINAL).astype(bool)
+        return separated_wavs, {
+            'mask_stitched': _maybe_torch(np.ascontiguousarray(np.transpose(mask_st, (1, 2, 0)))[None]),
+            'activity_b': _maybe_torch(np.ascontiguousarray(act_b.T)),
+            'activity_final': _maybe_torch(np.ascontiguousarray(act_final.T)[None]),
+            'segment_frames': T,
+        }
+    finally:
+        be.close()
 
 
 @dataclass
