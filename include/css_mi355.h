@@ -322,7 +322,7 @@ int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int3
 /* ConformerCssWrapper.forward (conformer_wrapper.py:58-77: stft -> separate) for a batch of equally long clips, fused
  * on the device -- the validation forward of the reference's training loop (train.py:529 eval_model).
  * pcm_host [batch][n_samples][n_ch] -> masks_host [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1
- * (2 <= T' <= 256), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
+ * (2 <= T' <= 512), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
 int css_forward_host(css_handle_t h, const float* pcm_host, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks_host);
 /* The validation loss of the reference's training loop for a batch of equally long clips (css/training/train.py:411-481
  * _calc_loss as train.py:529 eval_model calls it; no backward pass): forward as css_forward_host, |STFT| of microphone 0

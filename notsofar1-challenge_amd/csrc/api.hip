@@ -585,10 +585,10 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if (!cfg->w_first || !cfg->w_mid || !cfg->w_last) return fail(h, CSS_ERR_INVALID_ARG, "segment weights missing");
     if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
-    if (T < 2 || T > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 256] (at most 4 s segments)");
+    if (T < 2 || T > 512) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 512] (at most 8 s segments)");
     if (cfg->stitching_loss < 0 || cfg->stitching_loss > 1 || cfg->stitching_input < 0 || cfg->stitching_input > 1)
         return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
-    if (hop <= 0 || 4 * hop < T || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy T/4 <= hop < T (at most four segments overlap; at least one frame of overlap for the stitching cost)");
+    if (hop <= 0 || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy 1 <= hop < T (at least one frame of overlap for the stitching cost, css.py:276)");
     HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};
     if (plan_impl(h->d, *cfg, n_samples, &p) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "bad segment configuration");
@@ -1456,8 +1456,10 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         if (u.seg_lo != seg_lo || u.n != cnt) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
         if (u.up) HIPCHK(h, hipStreamWaitEvent(st, u.up, 0));
         // this unit's segments also read frames (and its transform samples) that the units just before it produced on
-        // other streams: a frame is read by at most four segments, a batch has at most MAX_LANES lanes
-        for (size_t k = ui >= (size_t)css_ctx::MAX_LANES ? ui - css_ctx::MAX_LANES : 0; k < ui; ++k)
+        // other streams: a frame is read by at most ceil(T / hop) segments (each in its own unit at worst), a batch has
+        // at most MAX_LANES lanes
+        const size_t back = (size_t)std::max<int>(css_ctx::MAX_LANES, (T + hop - 1) / hop);
+        for (size_t k = ui >= back ? ui - back : 0; k < ui; ++k)
             HIPCHK(h, hipStreamWaitEvent(st, units[k].x, 0));
         if (int e = stft_frames(h, u.f_lo, u.f_hi, planes_dev, st)) return e;
         HIPCHK(h, hipEventRecord(u.x, st));
@@ -1806,7 +1808,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
 int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks) {
     CSS_DRAIN(h);
     if (!h || !x_planes || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
-    if (t_frames < 2 || t_frames > 256) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 256] frames");
+    if (t_frames < 2 || t_frames > 512) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 512] frames");
     HIPCHK(h, hipSetDevice(h->device));
     const int F = h->d.num_bins, C = h->d.num_mics, T = t_frames, nm = h->d.num_spks + h->d.num_nois;
     const int64_t TT = (int64_t)batch * T;
@@ -1839,7 +1841,7 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     if (n_ch != C) return fail(h, CSS_ERR_SHAPE, "the model expects " + std::to_string(C) + " channels");
     if (n_samples < N) return fail(h, CSS_ERR_INVALID_ARG, "clip shorter than one frame");
     const int64_t T64 = (n_samples - N) / hop + 1;
-    if (T64 < 2 || T64 > 256) return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2..256 frames");
+    if (T64 < 2 || T64 > 512) return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2..512 frames");
     const int T = (int)T64;
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t TT = (int64_t)batch * T;

@@ -795,7 +795,11 @@ void launch_relpos_attention(const float* qkv, const float* qk_frag, const float
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)
         CSS_ATT_CASE(5) CSS_ATT_CASE(6) CSS_ATT_CASE(7) CSS_ATT_CASE(8)
-        default: break;  // longer segments are rejected at css_begin (segment_frames <= 256)
+        // segments of 257 .. 512 frames (4 .. 8 s): the same schedule with one wave per SIMD; the score tiles of a
+        // query tile stay in registers up to NJT = 16 (256 VGPRs + up to 158 accumulation registers, no spills)
+        CSS_ATT_CASE(9) CSS_ATT_CASE(10) CSS_ATT_CASE(11) CSS_ATT_CASE(12)
+        CSS_ATT_CASE(13) CSS_ATT_CASE(14) CSS_ATT_CASE(15) CSS_ATT_CASE(16)
+        default: break;  // longer segments are rejected at css_begin (segment_frames <= 512)
     }
 #undef CSS_ATT_CASE
 }

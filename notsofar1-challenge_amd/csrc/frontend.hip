@@ -175,8 +175,7 @@ void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_
 // maps such a bin to the float32 value just inside -pi, and the side of the atan2 branch cut of the
 // IPD feature depends on that (DESIGN.md "Numerical hazards").  PHASE_NEG_REAL is that value.
 // ------------------------------------------------------------------------------------------------
-constexpr int FEAT_TMAX = 256;
-constexpr int FEAT_LD = FEAT_TMAX + 1;
+// FEAT_TMAX: segment lengths an instantiation covers (256: up to 4 s, the shipped 3 s; 512: up to 8 s)
 #define CSS_PHASE_NEG_REAL (-3.14159250259399414f) /* 0xC0490FDA */
 #define CSS_EPS32 1.1920928955078125e-07f
 
@@ -184,11 +183,13 @@ __device__ __forceinline__ float phase_of(float re, float im) {
     return (im == 0.f && re < 0.f) ? CSS_PHASE_NEG_REAL : atan2f(im, re);
 }
 
+template <int FEAT_TMAX>
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, int64_t T_ld, int64_t stft_frames,
                                                        int F, float* __restrict__ feat, int Kp,
                                                        const float* __restrict__ in_bias,
                                                        const float* __restrict__ in_scale, int64_t seg_lo, int T,
                                                        int hop, int split_out) {
+    constexpr int FEAT_LD = FEAT_TMAX + 1;
     __shared__ float tile[32 * FEAT_LD];
     const int f0 = blockIdx.x * 32, m = blockIdx.y, segl = blockIdx.z;
     const int64_t st = (seg_lo + segl) * (int64_t)hop;
@@ -292,8 +293,12 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
                      int split_out, hipStream_t s) {
     const dim3 grid((F + 31) / 32, C, nseg), block(256);
-    hipLaunchKernelGGL(features_kernel, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                       seg_lo, T, hop, split_out);
+    if (T <= 256)
+        hipLaunchKernelGGL(features_kernel<256>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
+                           seg_lo, T, hop, split_out);
+    else
+        hipLaunchKernelGGL(features_kernel<512>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
+                           seg_lo, T, hop, split_out);
 }
 
 // ------------------------------------------------------------------------------------------------

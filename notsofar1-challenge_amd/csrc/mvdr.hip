@@ -64,6 +64,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 constexpr int SCM_WAVES = 2;   // bins per block
 
+template <int NI>   // 64-frame pieces of a segment: 4 (T <= 256) or 8 (T <= 512)
 __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float scm_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -81,16 +82,16 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * T);    // [4][T]
     double* tot = reinterpret_cast<double*>(ms + 4 * T + 2 * T);              // [4][2 * NPACK] group totals (8-byte aligned)
     // ---- the bin's rows, contiguous along time: every load of the 18 rows is in flight before the first LDS store
-    // (row by row, a wave waited out 18 memory round trips; T <= 256 = 4 x 64 lanes)
+    // (row by row, a wave waited out 18 memory round trips; T <= NI x 64 lanes)
     {
-        float v[2 * NC + 4][4];
+        float v[2 * NC + 4][NI];
 #pragma unroll
         for (int r = 0; r < 2 * NC + 4; ++r) {
             const float* src = r < 2 * NC ? a.X + ((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st
                                           : a.masks + ((int64_t)(r - 2 * NC) * F + f) * a.mask_ld + seg * (int64_t)T;
             const bool row_ok = r < 2 * NC + nm;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int t = lane + 64 * i;
                 v[r][i] = (row_ok && t < tv) ? src[t] : 0.f;
             }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
 #pragma unroll
         for (int r = 0; r < 2 * NC + 4; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int t = lane + 64 * i;
                 if (t < tv) xs[r * T + t] = v[r][i];   // rows 14 .. 17 are the mask rows (ms = xs + 14 T)
             }
@@ -234,7 +235,17 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
 void launch_scm(const MvdrArgs& a, hipStream_t s) {
     // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 98 doubles
     const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * 2 * NPACK * 2) * sizeof(float);
-    hipLaunchKernelGGL(scm_kernel, dim3((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), dim3(64 * SCM_WAVES), per_wave * SCM_WAVES, s, a);
+    const dim3 grid((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), block(64 * SCM_WAVES);
+    if (a.T <= 256) {
+        hipLaunchKernelGGL(scm_kernel<4>, grid, block, per_wave * SCM_WAVES, s, a);
+    } else {   // up to 8 s segments: 82 KB of LDS per block
+        static bool raised = false;
+        if (!raised) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+        hipLaunchKernelGGL(scm_kernel<8>, grid, block, per_wave * SCM_WAVES, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -241,9 +241,20 @@ __device__ __forceinline__ float seg_weight(const StitchArgs& a, int64_t seg, in
     return w[tl];
 }
 
-// the segments covering frame t (at most MAXC: css_begin enforces hop >= T / MAXC; two with the shipped
-// 3 s / 1.5 s configuration), in ascending segment order
+// the segments covering frame t in ascending segment order.  Up to MAXC of them (hop >= T / MAXC; two with the shipped
+// 3 s / 1.5 s configuration) are listed once per frame by contributors(); denser segmentations (any hop >= 1 the reference
+// accepts, css.py:144-171) take the *_general loops below, which walk first_seg(t) .. last_seg(t) per value.
 constexpr int MAXC = 4;
+__device__ __forceinline__ bool few_contributors(const StitchArgs& a) { return (a.T + a.hop - 1) / a.hop <= MAXC; }
+__device__ __forceinline__ int64_t first_seg(const StitchArgs& a, int64_t t) {
+    const int64_t lo = t - a.T + 1;
+    const int64_t s0 = lo <= 0 ? 0 : (lo + a.hop - 1) / a.hop;
+    return s0;
+}
+__device__ __forceinline__ int64_t last_seg(const StitchArgs& a, int64_t t) {
+    const int64_t s1 = t / a.hop;
+    return s1 < a.num_segments ? s1 : a.num_segments - 1;
+}
 __device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Contrib c[MAXC]) {
     const int64_t i1 = t / a.hop;
     int n = 0;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
     int n = 0;
     float wsum = 0.f;
     const float* mp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
-    if (active) {
+    if (active && few_contributors(a)) {
         n = contributors(a, t, c);
 #pragma unroll
         for (int i = 0; i < MAXC; ++i)
@@ -290,7 +301,26 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
             }
     }
     double sum = 0.0;
-    if (active && n > 0) {
+    if (!few_contributors(a)) {   // (uniform over the launch)
+        if (active) {
+            const int64_t s0 = first_seg(a, t), s1 = last_seg(a, t);
+            float ws = 0.f;
+            for (int64_t seg = s0; seg <= s1; ++seg) ws = __fadd_rn(ws, seg_weight(a, seg, (int)(t - seg * a.hop)));
+            float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
+            for (int f = fg; f < a.F; f += OM_FG) {
+                float v = 0.f;
+                for (int64_t seg = s0; seg <= s1; ++seg) {
+                    const int tl = (int)(t - seg * a.hop);
+                    const float m = a.masks[((int64_t)a.perms[seg * a.S + s] * a.F + f) * a.mask_ld + seg * a.T + tl];
+                    const float wm = __fmul_rn(seg_weight(a, seg, tl), m);
+                    v = seg == s0 ? wm : __fadd_rn(v, wm);
+                }
+                v = __fdiv_rn(v, ws);
+                out[(int64_t)f * a.T_long] = v;
+                sum += (double)v;
+            }
+        }
+    } else if (active && n > 0) {
         float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
         for (int f = fg; f < a.F; f += OM_FG) {
             float v = __fmul_rn(c[0].w, mp[0][(int64_t)f * a.mask_ld]);
@@ -367,10 +397,17 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
     int n = 0;
     float wsum = 0.f, gate = 0.f;
     const float2* pp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
-    if (active) {
+    const bool few = few_contributors(a);
+    const float2* sep = reinterpret_cast<const float2*>(a.sep);
+    int64_t gs0 = 0, gs1 = -1;
+    if (active && !few) {
+        gs0 = first_seg(a, t); gs1 = last_seg(a, t);
+        gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
+        for (int64_t seg = gs0; seg <= gs1; ++seg) wsum = __fadd_rn(wsum, seg_weight(a, seg, (int)(t - seg * a.hop)));
+    }
+    if (active && few) {
         n = contributors(a, t, c);
         gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
-        const float2* sep = reinterpret_cast<const float2*>(a.sep);
 #pragma unroll
         for (int i = 0; i < MAXC; ++i)
             if (i < n) {
@@ -380,7 +417,20 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
     }
     for (int f = fy; f < a.F; f += 16) {
         float re = 0.f, im = 0.f;
-        if (active && n > 0) {
+        if (active && !few) {
+            for (int64_t seg = gs0; seg <= gs1; ++seg) {
+                const int tl = (int)(t - seg * a.hop);
+                const float w = seg_weight(a, seg, tl);
+                const float2 v = sep[((seg * a.S + a.perms[seg * a.S + s]) * (int64_t)a.F + f) * a.T + tl];
+                const float wr = __fmul_rn(w, v.x), wi = __fmul_rn(w, v.y);
+                re = seg == gs0 ? wr : __fadd_rn(re, wr);
+                im = seg == gs0 ? wi : __fadd_rn(im, wi);
+            }
+            if (gs1 >= gs0) {
+                re = __fmul_rn(__fdiv_rn(re, wsum), gate);
+                im = __fmul_rn(__fdiv_rn(im, wsum), gate);
+            }
+        } else if (active && n > 0) {
             const float2 v0 = pp[0][(int64_t)f * a.T];
             re = __fmul_rn(c[0].w, v0.x);
             im = __fmul_rn(c[0].w, v0.y);

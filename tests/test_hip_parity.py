@@ -376,11 +376,14 @@ def test_short_and_error_inputs(L, CSS, sep_mc):
     with pytest.raises(AssertionError):                                  # css.py:224 mask_floor_db <= 0
         CSS.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), sep_mc, 16000, "cuda:0",
                                 CSS.CssCfg(mc_mask_floor_db=3.0))
-    with pytest.raises(NotImplementedError, match="segment/4 <= hop < segment"):   # the reference takes any segment / hop
-        CSS.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), sep_mc, 16000, "cuda:0",
-                                CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=0.5))
+    # what is left outside: no overlap for the stitching cost (hop == segment) and segments beyond 512 frames (8 s)
+    with pytest.raises(NotImplementedError, match="1 <= hop < segment"):
+        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=3.0), 16000, 7)
     with pytest.raises(NotImplementedError):
-        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=5.0, hop_size_sec=2.5), 16000, 7)   # 311-frame segments
+        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=9.0, hop_size_sec=4.5), 16000, 7)   # 561-frame segments
+    # ... and what round 3 brought inside (fixtures from the reference: test_hip_golden_r2.py): hop < segment / 4, 311 frames
+    assert int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=0.5), 16000, 7).c.hop_frames) == 31
+    assert int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=5.0, hop_size_sec=2.5), 16000, 7).c.segment_frames) == 311
     # digital silence: zero-padded frames, eps clamps, 1e-15 diagonal loading -- finite output, all zeros
     w, side = CSS.separate_and_stitch(np.zeros((1, 50000, 7), np.float32), sep_mc, 16000, "cuda:0", cfg)
     assert all(np.isfinite(x).all() and np.abs(x).max() == 0 for x in w)

@@ -83,6 +83,41 @@ def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes):
         sep.close()
 
 
+@pytest.mark.parametrize("seg,hop,seconds,max_batch", [(3.0, 0.5, 14.3, 64), (3.0, 0.5, 9.1, 5), (5.0, 2.5, 23.7, 64),
+                                                       (8.0, 1.0, 21.2, 3), (1.0, 0.1, 6.4, 16)])
+def test_dense_and_long_segmentations_every_schedule(model, seg, hop, seconds, max_batch):
+    """Segmentations beyond the shipped 3 s / 1.5 s -- more than four segments over a frame (the general overlap-add
+    loops), segments of more than 256 frames (the long-segment attention / feature / covariance kernels), and both at
+    once: the fused host -> host pipeline, the device-resident stage sequence and the sharded driver for 2, 3 and 5
+    virtual ranks (halo = ceil(T / hop) - 1 segments) give the same bits."""
+    import torch
+    L, CSS, PAR = pkg("_lib"), pkg("css"), pkg("parallel")
+    st, desc = model
+    mix = pkg("synth").synth_meeting(seconds, 7, seed=int(seconds * 7))
+    pcm = np.ascontiguousarray(mix[0, :mix.shape[1] - 123])
+    n = pcm.shape[0]
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch)
+    try:
+        h = sep.handle
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False, segment_size_sec=seg, hop_size_sec=hop), 16000, 7)
+        plan = L.plan(desc, run_cfg, n)
+        ref = h.run(pcm, run_cfg).copy()
+        assert np.isfinite(ref).all() and ref.shape == (3, plan.n_out) and float(np.abs(ref).max()) > 0
+        pin, out = L.pinned_copy(pcm), L.pinned_empty((3, int(plan.n_out)), np.float32)
+        assert np.array_equal(h.run(pin, run_cfg, out=out), ref)
+        pd = torch.from_numpy(pcm).cuda()
+        wd = torch.empty((3, int(plan.n_out)), dtype=torch.float32, device="cuda")
+        h.run_device(pd.data_ptr(), n, 7, run_cfg, wd.data_ptr(), int(plan.n_out))
+        torch.cuda.synchronize()
+        assert np.array_equal(wd.cpu().numpy(), ref)
+        nseg = int(plan.num_segments)
+        for world in sorted({2, min(3, nseg), min(5, nseg)}):
+            if world >= 2:
+                assert np.array_equal(virtual_rank_run(PAR, L, h, pcm, run_cfg, world), ref), world
+    finally:
+        sep.close()
+
+
 @pytest.mark.parametrize("lanes,max_batch,pinned", [(3, 64, True), (2, 7, True), (1, 64, True), (3, 16, False)])
 def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinned):
     """css_run_enqueue / css_wait: sessions of different lengths and contents queued back to back (page-locked buffers:

@@ -76,9 +76,10 @@ def test_csscfg_branches_vs_reference(opt_run, name):
         assert rel_rms(ww[0][:3], g["opt_default_wav_windows"][0][:3]) > 1e-2   # leave these permutations as they are)
 
 
-@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0)])
+# (3 s, 0.5 s): six segments over every frame; (5 s, 2.5 s): 311-frame segments -- round-3 fixtures (gen_golden_r3.py)
+@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0), (3.0, 0.5), (5.0, 2.5)])
 def test_other_segmentations_vs_reference(mc_state, mix60, golden, seg_hop):
-    g = golden("variants_mc.npz")
+    g = golden("segs_r3.npz" if seg_hop in ((3.0, 0.5), (5.0, 2.5)) else "variants_mc.npz")
     name = f"seg{int(seg_hop[0])}{int(seg_hop[1])}"
     mix = mix60[:, int(g["seg_offset"]):int(g["seg_offset"]) + int(g["seg_samples"])]
     params = O.ConformerParams(mc_state[0])
@@ -130,7 +131,7 @@ def test_config2_60s_mc_vs_reference(mc_state, mix60, golden):
     per_seg = [int((np.argmax(np.concatenate(store[i], -1), -1) != wta[i]).sum()) for i in range(40)]
     def ipd_on_cut(i):   # an inter-channel phase within an ulp of +-pi (DC / Nyquist are exactly real: not counted)
         f = O.features(X[:, i * 93:i * 93 + 186])[257:].reshape(6, 257, -1)[:, 1:256]
-        return bool(np.abs(np.abs(f) - np.pi).min() < 5e-7)
+        return bool(np.abs(np.abs(f) - np.pi).min() < 1e-6)
 
     on_cut = [i for i in range(39) if ipd_on_cut(i)]
     assert sum(n for i, n in enumerate(per_seg) if i not in on_cut) <= 1e-5 * wta.size + 3, per_seg
