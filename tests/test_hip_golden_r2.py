@@ -131,8 +131,12 @@ def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden):
     per_seg = [int((np.argmax(m[:, :, i], axis=0) != wta[i]).sum()) for i in range(40)]
     assert sum(n for i, n in enumerate(per_seg) if i not in cut) <= 1e-5 * wta.size + 3, per_seg
     assert all(per_seg[i] <= 0.005 * 257 * 186 for i in cut) and len(cut) <= 8, (cut, per_seg)
+    # out of the comparisons: on-cut segments whose decisions actually moved (an IPD feature landed on the other side of
+    # the cut: their mask VALUES differ too) and the ragged last segment (ill-conditioned, test_oracle_golden_r2.py); an
+    # on-cut segment without a flipped decision stays in (its masks are held to the stitched-mask bound below)
+    moved = [i for i in cut if per_seg[i] > 0]
     stable_t = np.ones(3749, bool)
-    for i in cut + [39]:
+    for i in moved + [39]:
         stable_t[i * 93:i * 93 + 186 + 2] = False
     ref_act = unpack_bits(g["activity_final"], tuple(g["activity_shape"]))
     assert np.array_equal(act_f[stable_t], ref_act[stable_t])
@@ -150,10 +154,25 @@ def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden):
     for i, n in enumerate(per_seg):
         if n:
             clean_t[max(i * 93 - 2, 0):i * 93 + 186 + 2] = False
-    assert clean_t.mean() > 0.6
     t = np.flatnonzero(clean_t)
+    free_err = [rel_rms(free[k, ::256][t], g["wav_dec"][k][t]) for k in range(S)]
+    forced_err = [rel_rms(forced[k, ::256][np.flatnonzero(stable_t)], g["wav_dec"][k][np.flatnonzero(stable_t)]) for k in range(S)]
+    # how much of the meeting each comparison covers ("the evidence should say how much was compared")
+    from test_hip_long import _report
+    _report("config2_60s_mc", {
+        "frames": 3749, "segments": 40,
+        "segments_on_the_ipd_branch_cut": cut, "of_which_with_moved_decisions": moved,
+        "segments_with_wta_flips": [i for i, n in enumerate(per_seg) if n],
+        "wta_flips_per_segment": per_seg, "wta_decisions": int(wta.size),
+        "frames_compared_on_the_reference_decisions": int(stable_t.sum()), "fraction_on_the_reference_decisions": round(float(stable_t.mean()), 4),
+        "frames_compared_free_running": int(clean_t.sum()), "fraction_free_running": round(float(clean_t.mean()), 4),
+        "waveform_rel_rms_on_the_reference_decisions": forced_err, "waveform_rel_rms_free_running": free_err})
+    # measured (round 3, MI355X): three on-cut segments with moved decisions + the ragged last one leave 0.842 of the frames
+    # for the comparison on the reference's decisions (6.7 ... 7.6e-6), one more segment with a single rounding-level flip
+    # takes the free-running comparison to 0.790 (6.6 ... 7.5e-6); asserted with a margin of one segment
+    assert stable_t.mean() >= 0.80 and clean_t.mean() >= 0.74, (stable_t.mean(), clean_t.mean())
     for k in range(S):
-        assert rel_rms(free[k, ::256][t], g["wav_dec"][k][t]) < 1e-4, k
+        assert free_err[k] < 1e-4, k
 
 
 def test_config3_60s_sc_vs_reference(L, sc_state, mix60, golden):

@@ -124,6 +124,45 @@ def test_decisions_and_window_vs_oracle(L, long_run, mc_state):
         assert rel_rms(got, ref) < 1e-4, (j, k, rel_rms(got, ref))
 
 
+def test_masks_deep_in_the_meeting_vs_oracle(L, long_run, mc_state):
+    """The estimator's masks of segments 0, 600 and 1208 (the ragged last one) of the 30-min meeting against the oracle's
+    own features + Conformer on the same frames: what tests/test_hip_parity.py holds for a 20 s input must hold at any
+    position of any batch (segment 600 is the 88th of the fifth 121-segment batch, 1208 closes the last)."""
+    h, run_cfg = long_run["h"], long_run["run_cfg"]
+    h.run(long_run["pcm"], run_cfg)
+    nseg = 1209
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
+    params = O.ConformerParams(mc_state[0])
+    pcm = long_run["pcm"]
+    worst = {}
+    for i in (0, 600, 1208):
+        a = i * HOP * 256
+        x = O.stft(pcm[a:a + (T - 1) * 256 + 512])          # [F, t, C], t < T for the last segment
+        seg = np.zeros((F, T, 7), np.complex64)
+        seg[:, :x.shape[1]] = x
+        om = O.conformer_forward(params, O.features(seg))   # [S + 1, F, T]
+        worst[i] = float(np.abs(m[:, :, i, :] - om).max())
+        assert worst[i] < 1.5e-5, (i, worst[i])
+    assert int(h.get_plan().last_valid) == 155               # segment 1208 is ragged: 155 of 186 frames
+    _report("masks_1800s_vs_oracle_max_abs", worst)
+
+
+def _report(key, value):
+    """parity bookkeeping: the measured margins of this run, next to the test output (profiles/r03_parity_margins.txt)"""
+    import json
+    print(f"[parity] {key}: {value}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        path = os.path.join(out, "parity_coverage.json")
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[key] = value
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+
+
 def _two_rank_worker(rank, world, port, seconds, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
