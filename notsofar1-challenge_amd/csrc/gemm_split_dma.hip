@@ -555,6 +555,7 @@ void launch_gemm_split_dma(const GemmArgs& g, hipStream_t s) {
         case 42: hipLaunchKernelGGL((gemm_split_dma_kernel<4, 2, 3>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
         case 242: hipLaunchKernelGGL((gemm_split_dma_kernel<2, 4, 2>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
         case 24: hipLaunchKernelGGL((gemm_split_dma_kernel<2, 4, 3>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
+        case 4: hipLaunchKernelGGL((gemm_split_ws_kernel<4>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
 #ifdef CSS_GEMM_DMA_ABLATE
 #define CSS_ABL(n) case 1000 + n: hipLaunchKernelGGL((gemm_split_dma_kernel<2, 4, 3, n>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
         CSS_ABL(1) CSS_ABL(2) CSS_ABL(4) CSS_ABL(3) CSS_ABL(5) CSS_ABL(6) CSS_ABL(7) CSS_ABL(16) CSS_ABL(18) CSS_ABL(32) CSS_ABL(34) CSS_ABL(22)

@@ -2,7 +2,7 @@
 # Collects everything profiles/ holds for one round (run on the GPU box through gpurun):
 #   bash tools/profile_round.sh r02
 # -> gpurun_out/<tag>_* ; copy the summaries into profiles/ afterwards.
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 o=gpurun_out
 python bench.py --steps 20 --warmup 3 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
@@ -15,12 +15,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/${tag}_pmc2 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/${tag}_pmc3 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-long > /dev/null 2>&1
 CSS_TRAFFIC_JSON=$o/${tag}_gemm_traffic.json python tools/summarize_pmc.py $o/${tag}_pmc1 $o/${tag}_pmc2 $o/${tag}_pmc3 > $o/${tag}_pmc.md
 python tools/parity_margins.py > $o/${tag}_parity_margins.txt 2>/dev/null
+# the -m gpu suite (writes gpurun_out/parity_coverage.json: how much of each comparison was covered)
+rm -f $o/parity_coverage.json
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $o/${tag}_pytest_gpu.txt
+[ -f $o/parity_coverage.json ] && cp $o/parity_coverage.json $o/${tag}_parity_coverage.json
 python tools/shard_overhead_probe.py 60 > $o/${tag}_shard_overhead.md 2>/dev/null
 python tools/shard_overhead_probe.py 1800 >> $o/${tag}_shard_overhead.md 2>/dev/null
 # the N > 1 code path as separate processes on this one GPU (RCCL refuses two ranks per device: gloo carries the pieces)
 for w in 2 8; do
-  CSS_BENCH_ONE_DEVICE=1 CSS_BENCH_BACKEND=gloo CSS_BENCH_CHECK=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $w \
-    --master-addr 127.0.0.1 --master-port $((29600 + w)) bench.py --gpus $w --steps 2 --warmup 1 > $o/${tag}_multiprocess_w$w.log 2>&1
+  # (started PLAINLY, as the driver starts benches: bench.py spawns its own ranks)
+  CSS_BENCH_ONE_DEVICE=1 CSS_BENCH_BACKEND=gloo CSS_BENCH_CHECK=1 timeout 1200 python bench.py --gpus $w --steps 2 --warmup 1 > $o/${tag}_multiprocess_w$w.log 2>&1
 done
 rm -rf $o/${tag}_prof $o/${tag}_pmc1/*/*.db 2>/dev/null
 head -c 1200 $o/${tag}_bench.json; echo; head -20 $o/${tag}_pmc.md; cat $o/${tag}_shard_overhead.md; tail -3 $o/${tag}_multiprocess_w2.log; tail -3 $o/${tag}_multiprocess_w8.log
