@@ -131,8 +131,11 @@ def test_create_without_gpu_fails_loudly(L):
     s = sep.HipSeparator(w.portable_state_dict(desc, 0))
     with pytest.raises(L.CssError):
         css.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), s, 16000, "cuda:0", css.CssCfg())
-    with pytest.raises(TypeError):
+    # a foreign separator-protocol object gets the HIP stages around its masks (tests/test_hip_protocol.py) -- and no
+    # CPU path either: without a GPU the stages' handle cannot be created
+    with pytest.raises(L.CssError) as e:
         css.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), object(), 16000, "cuda:0", css.CssCfg())
+    assert e.value.code == L.CSS_ERR_NO_DEVICE
 
 
 def test_wav_roundtrip_and_css_inference_plumbing(tmp_path):
