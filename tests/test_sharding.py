@@ -63,6 +63,32 @@ def test_shard_plan_halo_grows_with_overlap():
                             assert p.seg_lo <= seg < p.seg_hi
 
 
+@pytest.mark.parametrize("T,hop", [(186, 31), (186, 7), (311, 155), (499, 62), (61, 6)])
+def test_shard_plan_dense_and_long_segmentations(T, hop):
+    """Round 3: any hop with an overlap and segments up to 512 frames (3 s / 0.5 s -> hop = T / 6, 8 s / 1 s, ...): every
+    frame a rank owns is covered only by segments the rank computes, every owned boundary has both its segments, and the
+    ranks' frame ranges and boundaries tile the meeting."""
+    par = pkg("parallel")
+    for mix_frames in (T + 1, 3 * T + 5, 2000):
+        nseg = int(np.ceil((mix_frames - (T - hop)) / hop))
+        for world in (2, 3, 8):
+            plans = par.all_plans(nseg, mix_frames, mix_frames, T, hop, 256, world)
+            assert plans[0].t_lo == 0 and plans[-1].t_hi == mix_frames and plans[0].b_lo == 0 and plans[-1].b_hi == nseg - 1
+            for a, b in zip(plans, plans[1:]):
+                assert a.own_seg_hi == b.own_seg_lo and a.t_hi == b.t_lo and a.b_hi == b.b_lo
+            halo = -(-T // hop) - 1
+            for p in plans:
+                if p.own_seg_hi == p.own_seg_lo:
+                    continue
+                assert p.seg_lo == max(p.own_seg_lo - halo, 0) and p.seg_hi == p.own_seg_hi
+                for t in range(p.t_lo, p.t_hi, max((p.t_hi - p.t_lo) // 50, 1)):
+                    for seg in range(max(t // hop - halo - 1, 0), t // hop + 1):
+                        if seg < nseg and 0 <= t - seg * hop < T:
+                            assert p.seg_lo <= seg < p.seg_hi, (mix_frames, world, p, t, seg)
+                for b in range(p.b_lo, p.b_hi):
+                    assert p.seg_lo <= b and b + 1 < p.seg_hi
+
+
 def _small_model():
     w = pkg("weights")
     desc = w.ModelDesc(num_blocks=1)
