@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long", action="store_true", help="N = 1: skip the 30-min meeting")
     ap.add_argument("--lanes", type=int, default=0, help="kernel chains per mask-estimator batch (0 = the library's default)")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="css_set_tuning options of the handle (A/B runs), e.g. --tune gemm_ws=1")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -446,6 +448,10 @@ def main():
     h = sep.handle
     if args.lanes:
         h.set_lanes(args.lanes)
+    for kv in args.tune:
+        name, _, val = kv.partition("=")
+        h.set_tuning(name, int(val))
+        result.setdefault("tuning", {})[name] = int(val)
     pcm_pin = L.pinned_copy(np.ascontiguousarray(mix[0]))
     out_pin = L.pinned_empty((S, int(plan.n_out)), np.float32)
     torch.cuda.synchronize()
@@ -543,7 +549,7 @@ def main():
         h.set_profile(False)
         return t, ks
 
-    def gemm_roofline(t, mode):
+    def gemm_roofline(t, mode, ks_ref=None):
         # `achieved` counts ALGORITHMIC flops (2*M*N*K of the float32 products the network defines).
         achieved = t["gemm_flops"] / (t["gemm_ms"] * 1e-3) / 1e12 if t["gemm_ms"] > 0 else 0.0
         if mode == "split_f16":
@@ -558,14 +564,20 @@ def main():
             peak = PEAK_FP32_MATRIX_TFLOPS
             kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
             extra = {}
-        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                "launches_per_step": int(t["gemm_launches"]),
-                "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
-                "flops_per_step": t["gemm_flops"], **extra}
+        out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
+               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+               "launches_per_step": int(t["gemm_launches"]),
+               "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
+               "flops_per_step": t["gemm_flops"], **extra}
+        # `achieved` divides by the HIP-event brackets as they are: a bracket also holds the launch gap and the two event
+        # records (an EMPTY bracket behind a 4-byte fill measures `empty_event_bracket_us` on this box).  The kernel trace
+        # of the same command (profiles/r03_kernel_stats.md) gives the kernels' own durations: ~3 us less per launch.
+        if ks_ref and "event_pair_overhead" in ks_ref:
+            out["empty_event_bracket_us"] = round(1e3 * ks_ref["event_pair_overhead"][0] / max(ks_ref["event_pair_overhead"][1], 1), 2)
+        return out
 
     t, ks = profiled_pass()
-    roof = gemm_roofline(t, h.linear_mode())
+    roof = gemm_roofline(t, h.linear_mode(), ks)
     # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes from
     # the committed PMC passes of the same command (profiles/README.md), when present
     for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
@@ -584,14 +596,14 @@ def main():
                 for k in alg if k in ks and ks[k][0] > 0]
 
     result["roofline_hbm"] = hbm_table(hbm_kernel_bytes(plan, desc, T, hop, n), ks)
-    result["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks.items()}
+    result["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks.items() if k != "event_pair_overhead"}
 
     # ---- the strictly-float32 arithmetic mode, same workload, same timing rules
     h.set_linear_mode("exact_f32")
     ms_x = fused_host_to_host(h, pcm_pin, out_pin, max(args.steps // 2, 5), 2)
     tx, _ = profiled_pass()
     result["exact_f32"] = {**rec(ms_x, "css_set_linear_mode(CSS_LINEAR_EXACT_F32): every Linear layer on the exact float32 MFMA chain; host -> host"),
-                           "dtype": dtype_of["exact_f32"], "roofline": gemm_roofline(tx, "exact_f32")}
+                           "dtype": dtype_of["exact_f32"], "roofline": gemm_roofline(tx, "exact_f32", ks)}
     h.set_linear_mode("split_f16")
 
     # ---- BASELINE.json configs[3] on this one GPU: the fixed 30-min meeting every N > 1 line runs
@@ -613,7 +625,7 @@ def main():
         t_l, ks_l = h.timings(), h.kernel_stats()
         h.set_profile(False)
         result["roofline_hbm_1800s"] = hbm_table(hbm_kernel_bytes(plan_long, desc, T, hop, n_long), ks_l)
-        result["roofline_1800s"] = gemm_roofline(t_l, h.linear_mode())
+        result["roofline_1800s"] = gemm_roofline(t_l, h.linear_mode(), ks_l)
         del pcm_dev, wav_dev
         out_long = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
         ms_long = fused_host_to_host(h, pcm_long, out_long, 3, 1)

@@ -114,7 +114,7 @@ struct css_ctx {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -153,6 +153,10 @@ struct css_ctx {
     double gemm_flops = 0.0;
     float prof_ms[CSS_PROF_COUNT] = {};
     int32_t prof_launches[CSS_PROF_COUNT] = {};
+    // what an event pair measures with NOTHING between the two records (css_set_profile calibrates it): the part of every
+    // bracketed launch that is the bracket, not the kernel
+    float prof_pair_ms = 0.f;
+    int32_t prof_pairs = 0;
 
     std::string err;
 };
@@ -804,6 +808,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
                    int act, int split_out) {
         GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
         g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
+        g.allow_ws = h->tune[CSS_TUNE_GEMM_WS];
         g.range_flag = sp ? h->range_flag_dev : nullptr;
         return g;
     };
@@ -1744,6 +1749,25 @@ int css_set_profile(css_handle_t h, int enable) {
     CSS_DRAIN(h);
     if (!h) return CSS_ERR_INVALID_ARG;
     h->profile_gemm = enable != 0;
+    if (enable && !h->prof_pairs) {
+        // calibration: 64 empty brackets behind a kernel each (the bracket's cost depends on the stream being busy)
+        HIPCHK(h, hipSetDevice(h->device));
+        constexpr int NP = 64;
+        hipEvent_t ev[2 * NP];
+        for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+        unsigned int* scratch = h->range_flag_dev + 8;   // (a word of the 64-byte allocation nobody reads)
+        for (int i = 0; i < NP; ++i) {
+            HIPCHK(h, hipMemsetAsync(scratch, 0, 4, h->stream));
+            HIPCHK(h, hipEventRecord(ev[2 * i], h->stream));
+            HIPCHK(h, hipEventRecord(ev[2 * i + 1], h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float tot = 0.f;
+        for (int i = 0; i < NP; ++i) { float v = 0.f; hipEventElapsedTime(&v, ev[2 * i], ev[2 * i + 1]); tot += v; }
+        for (auto& e : ev) hipEventDestroy(e);
+        h->prof_pair_ms = tot;
+        h->prof_pairs = NP;
+    }
     return CSS_OK;
 }
 
@@ -1756,6 +1780,14 @@ int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_
             std::snprintf(out[n].name, sizeof(out[n].name), "%s", kProfNames[c]);
             out[n].ms = h->prof_ms[c];
             out[n].launches = h->prof_launches[c];
+        }
+        ++n;
+    }
+    if (h->prof_pairs) {   // not a kernel family: the empty-bracket calibration (ms over `launches` empty brackets)
+        if (n < cap) {
+            std::snprintf(out[n].name, sizeof(out[n].name), "%s", "event_pair_overhead");
+            out[n].ms = h->prof_pair_ms;
+            out[n].launches = h->prof_pairs;
         }
         ++n;
     }

@@ -539,10 +539,14 @@ bool gemm_split_ws_eligible(const GemmArgs& g) {
 // estimator, where every operand was just written by the previous kernel, the same launches take 27.5 us against 27.1
 // (kernel trace, 10 285 launches) and the pass is unchanged (A/B on one box: 3.99 against 3.96 ms of GEMM time) -- one
 // block per CU hides the cold first touches worse than two independent 64-row blocks do.  So the automatic choice is
-// "never" until the kernel is persistent over a launch's tiles; tile_rows = 3 selects it (tests, tools).
+// off by default (css_set_tuning(h, CSS_TUNE_GEMM_WS, 1) turns the shape rule below on, 2 takes every eligible launch);
+// tile_rows = 3 selects the kernel directly (tests, tools).
 bool gemm_split_ws_pays(const GemmArgs& g) {
-    (void)g;
-    return false;
+    if (!g.allow_ws || g.concurrent) return false;
+    if (g.allow_ws == 2) return true;
+    const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (g.allow_ws == 3) return g.N <= 512 && g.K >= 1024 && tiles >= 192;   // only the long-K launches (ffn-down, embed)
+    return g.N <= 512 && tiles >= 192 && (tiles <= 256 || g.K >= 1024);
 }
 
 // g.tile_rows selects the variant (tools / tests): 3 = specialised waves (gemm_split_ws_kernel, three slab buffers);

@@ -36,6 +36,7 @@ struct GemmArgs {
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
     int nt_store;   // epilogue stores bypass the caches (nontemporal)
+    int allow_ws;   // css_set_tuning(CSS_TUNE_GEMM_WS): the automatic choice may take gemm_split_dma.hip's specialised-wave kernel
     // weights-direct kernel only: columns n < 2 * frag_D (the q and k projections of the attention, D = heads * 64) leave
     // in the attention kernel's operand order instead of row-major C (encoder.hip qk fragment layout); rows are tokens
     // of segments of frag_T frames, frag_invT = 1.0f / frag_T
