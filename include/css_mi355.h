@@ -74,6 +74,22 @@ typedef struct CssModelDesc {
     int32_t maxlen;          /* relative-position table half size, 1000 (conformer.py:213); offsets past it are clamped (:24) */
 } CssModelDesc;
 
+/* Feature-extractor options beyond what the shipped v1.0 models use (ExtractorCfg, conformer_wrapper.py:11-24;
+ * implemented by FeatureExtractor / IPDFeature, css/css_with_conformer/executor/feature.py:198-249,478-508).  css_create
+ * starts from the shipped configuration: {0, 1, 1, 1, 0, C - 1 pairs (m, 0)}. */
+#define CSS_MAX_IPD_PAIRS 16
+typedef struct CssFeatureCfg {
+    int32_t log_spectrogram;            /* feature.py:500-501: log of the clamped magnitude before the normalisation          */
+    int32_t mvn_spectrogram;            /* feature.py:503-507: mean / (unbiased) std normalisation over the segment's frames  */
+    int32_t ipd_mean_normalize;         /* feature.py:214: remove the time-mean of the phase difference ...                   */
+    int32_t ipd_mean_normalize_version; /* ... 1: atan2(sin - mean sin, cos - mean cos) (:220-221); 2: minus atan2(mean sin,
+                                         * mean cos) (:222-224); 3: minus the mean angle (:225-227)                            */
+    int32_t ipd_cos;                    /* feature.py:234-236: cos of the (normalised) difference instead of the raw angle     */
+    int32_t num_pairs;                  /* microphone pairs of ipd_index, e.g. "1,4;2,5;3,6" -> 3; in_features = F (1 + pairs) */
+    int32_t pair_l[CSS_MAX_IPD_PAIRS];  /* phase difference = phase[pair_l] - phase[pair_r] (feature.py:212)                   */
+    int32_t pair_r[CSS_MAX_IPD_PAIRS];
+} CssFeatureCfg;
+
 /* Run-time knobs.  Mirrors the arithmetic-relevant fields of CssCfg (css/css.py:24-48) after the
  * seconds->frames conversion of css/css.py:144-152, which the host shim performs with the same
  * Python float expressions. */
@@ -314,6 +330,10 @@ int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* s
 int css_stage_join_shards(css_handle_t h, const float* gathered_dev, int32_t world, int64_t shard_ld, const int64_t* t_lo,
                           const int64_t* t_hi, float* out_dev, int64_t out_ld);
 int css_sync(css_handle_t h);
+
+/* Selects the feature-extractor options of the handle's model (see CssFeatureCfg); num_pairs must agree with the model's
+ * in_features, the pair indices with its microphones.  Single-channel models take the spectral options only. */
+int css_set_feature_options(css_handle_t h, const CssFeatureCfg* cfg);
 
 /* Separator-protocol helpers operating on caller data (host pointers):
  * stft: pcm [n][C] -> X planes [C][2F][T] (T = stft_frames, tightly packed). */

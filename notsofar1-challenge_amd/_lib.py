@@ -44,6 +44,12 @@ class CssModelDesc(C.Structure):
         "kernel_size", "num_spks", "num_nois", "frame_len", "frame_hop", "maxlen")]
 
 
+class CssFeatureCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("log_spectrogram", "mvn_spectrogram", "ipd_mean_normalize",
+                                         "ipd_mean_normalize_version", "ipd_cos", "num_pairs")] + \
+               [("pair_l", C.c_int32 * 16), ("pair_r", C.c_int32 * 16)]
+
+
 class CssRunCfg(C.Structure):
     _fields_ = [("segment_frames", C.c_int32), ("hop_frames", C.c_int32), ("dilation_frames", C.c_int32),
                 ("erosion_frames", C.c_int32), ("mc_mvdr", C.c_int32), ("stitching_loss", C.c_int32),
@@ -119,6 +125,7 @@ SIGNATURES = {
     "css_sync": (C.c_int, [_P]),
     "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "css_set_feature_options": (C.c_int, [_P, C.POINTER(CssFeatureCfg)]),
     "css_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     "css_handoff_logmel": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
@@ -387,6 +394,17 @@ class Handle:
     def set_linear_mode(self, mode):
         """"split_f16" (default: float32-grade accuracy on the f16 matrix cores) or "exact_f32"."""
         check(self.h, self.lib.css_set_linear_mode(self.h, {"split_f16": 0, "exact_f32": 1}[mode]))
+
+    def set_feature_options(self, log_spectrogram=False, mvn_spectrogram=True, ipd_mean_normalize=True,
+                            ipd_mean_normalize_version=1, ipd_cos=False, pairs=None):
+        """ExtractorCfg options beyond the shipped configuration (css_set_feature_options); pairs: [(l, r), ...]"""
+        c = CssFeatureCfg(int(log_spectrogram), int(mvn_spectrogram), int(ipd_mean_normalize), int(ipd_mean_normalize_version),
+                          int(ipd_cos), 0)
+        pairs = list(pairs) if pairs is not None else [(m, 0) for m in range(1, int(self.desc.num_mics))]
+        c.num_pairs = len(pairs)
+        for i, (l, r) in enumerate(pairs[:16]):
+            c.pair_l[i], c.pair_r[i] = int(l), int(r)
+        check(self.h, self.lib.css_set_feature_options(self.h, C.byref(c)))
 
     def set_range_fallback(self, enable: bool):
         check(self.h, self.lib.css_set_range_fallback(self.h, int(enable)))

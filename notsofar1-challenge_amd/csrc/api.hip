@@ -157,6 +157,7 @@ struct css_ctx {
     // bracketed launch that is the bracket, not the kernel
     float prof_pair_ms = 0.f;
     int32_t prof_pairs = 0;
+    FeatOpts feat_opts{};   // css_set_feature_options (css_create: the shipped configuration)
 
     std::string err;
 };
@@ -230,7 +231,10 @@ const char* validate_desc(const CssModelDesc& d) {
     if (d.num_mics != 1 && d.num_mics != 7) return "num_mics must be 1 or 7";
     if (d.frame_len != 2 * d.frame_hop || d.frame_len % 64) return "frame_len must equal 2*frame_hop and be a multiple of 64";
     if (d.num_bins != d.frame_len / 2 + 1) return "num_bins must be frame_len/2 + 1";
-    if (d.in_features != d.num_bins * d.num_mics) return "in_features must be num_bins * num_mics (magnitude + one IPD block per extra mic)";
+    // magnitude block + one block per IPD pair (ipd_index; the shipped models: one pair per extra microphone -> 1799 / 257)
+    if (d.num_bins <= 0 || d.in_features % d.num_bins || d.in_features / d.num_bins < 1 ||
+        d.in_features / d.num_bins > 1 + CSS_MAX_IPD_PAIRS || (d.num_mics == 1 && d.in_features != d.num_bins))
+        return "in_features must be num_bins * (1 + IPD pairs), at most 16 pairs (single-channel: num_bins)";
     if (d.attention_dim % 256 || d.attention_dim > 1024 || d.attention_dim <= 0) return "attention_dim must be a multiple of 256, at most 1024";
     if (d.attention_heads <= 0 || d.attention_dim / d.attention_heads != 64 || d.attention_dim % d.attention_heads) return "head size (attention_dim / attention_heads) must be 64";
     if (d.linear_units % 32 || d.linear_units <= 0) return "linear_units must be a multiple of 32";
@@ -457,6 +461,16 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     if (device < 0 || device >= ndev) return fail(nullptr, CSS_ERR_NO_DEVICE, "device index out of range");
     css_ctx* h = new css_ctx();
     h->d = *desc;
+    // feature extractor: the shipped configuration (ExtractorCfg defaults, conformer_wrapper.py:11-24): magnitude with mean /
+    // variance normalisation, IPD version 1 as raw angles, pairs (m, 0)
+    h->feat_opts = FeatOpts{};
+    h->feat_opts.mvn = 1; h->feat_opts.ipd_norm = 1; h->feat_opts.ipd_version = 1;
+    // (a model with another number of pairs gets its ipd_index through css_set_feature_options; until then pair p = (p + 1, 0))
+    h->feat_opts.num_pairs = desc->in_features / desc->num_bins - 1;
+    for (int p_ = 0; p_ < h->feat_opts.num_pairs && p_ < 16; ++p_) {
+        h->feat_opts.pair_l[p_] = (unsigned char)std::min(p_ + 1, desc->num_mics - 1);
+        h->feat_opts.pair_r[p_] = 0;
+    }
     h->device = device;
     h->max_batch = max_batch_segments > 0 ? max_batch_segments : 64;
     h->Kp = round_up(desc->in_features, 32);
@@ -816,7 +830,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         {
             CSS_PROF(CSS_PROF_FEATURES, st);
             launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
-                            io.hop, sp, st);
+                            io.hop, sp, h->feat_opts, st);
         }
         // embed: Linear -> LayerNorm -> ReLU (conformer.py:205-210)
         gemm(h, lin(feat, h->Kp, W.embed_w, W.embed_b, u, D, D, h->Kp, ACT_NONE, 0), st);
@@ -1737,6 +1751,30 @@ int css_set_linear_mode(css_handle_t h, int mode) {
     for (int l = 1; l < css_ctx::MAX_LANES; ++l)
         if (h->lfeat[l].p) HIPCHK(h, hipMemsetAsync(h->lfeat[l].p, 0, h->lfeat[l].cap, h->stream));
     h->split = split;
+    return CSS_OK;
+}
+
+int css_set_feature_options(css_handle_t h, const CssFeatureCfg* c) {
+    CSS_DRAIN(h);
+    if (!h || !c) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    const int C = h->d.num_mics, F = h->d.num_bins;
+    if (c->num_pairs < 0 || c->num_pairs > CSS_MAX_IPD_PAIRS) return fail(h, CSS_ERR_INVALID_ARG, "at most 16 IPD pairs");
+    if (C == 1 && c->num_pairs != 0) return fail(h, CSS_ERR_INVALID_ARG, "a single-channel model has no IPD pairs");
+    if (h->d.in_features != F * (1 + c->num_pairs))
+        return fail(h, CSS_ERR_SHAPE, "in_features = " + std::to_string(h->d.in_features) + " does not match num_bins * (1 + " +
+                                          std::to_string(c->num_pairs) + " IPD pairs)");
+    if (c->ipd_mean_normalize && (c->ipd_mean_normalize_version < 1 || c->ipd_mean_normalize_version > 3))
+        return fail(h, CSS_ERR_INVALID_ARG, "ipd_mean_normalize_version must be 1, 2 or 3 (feature.py:228-231)");
+    FeatOpts o{};
+    o.log_mag = c->log_spectrogram != 0; o.mvn = c->mvn_spectrogram != 0; o.ipd_norm = c->ipd_mean_normalize != 0;
+    o.ipd_version = c->ipd_mean_normalize_version; o.ipd_cos = c->ipd_cos != 0; o.num_pairs = c->num_pairs;
+    for (int p = 0; p < c->num_pairs; ++p) {
+        if (c->pair_l[p] < 0 || c->pair_l[p] >= C || c->pair_r[p] < 0 || c->pair_r[p] >= C)
+            return fail(h, CSS_ERR_INVALID_ARG, "IPD pair index outside the model's microphones");
+        o.pair_l[p] = (unsigned char)c->pair_l[p];
+        o.pair_r[p] = (unsigned char)c->pair_r[p];
+    }
+    h->feat_opts = o;
     return CSS_OK;
 }
 

@@ -188,10 +188,12 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                                                        int F, float* __restrict__ feat, int Kp,
                                                        const float* __restrict__ in_bias,
                                                        const float* __restrict__ in_scale, int64_t seg_lo, int T,
-                                                       int hop, int split_out) {
+                                                       int hop, int split_out, FeatOpts o) {
     constexpr int FEAT_LD = FEAT_TMAX + 1;
     __shared__ float tile[32 * FEAT_LD];
+    // blockIdx.y = 0: the spectral rows (microphone 0); y >= 1: IPD pair y - 1 = phase[ml] - phase[mr]
     const int f0 = blockIdx.x * 32, m = blockIdx.y, segl = blockIdx.z;
+    const int ml = m ? o.pair_l[m - 1] : 0, mr = m ? o.pair_r[m - 1] : 0;
     const int64_t st = (seg_lo + segl) * (int64_t)hop;
     const int64_t tv64 = stft_frames - st;
     const int tv = (int)(tv64 < 0 ? 0 : (tv64 > T ? T : tv64));
@@ -203,10 +205,10 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     float n_r0[NT], n_i0[NT], n_rm[NT], n_im[NT];
     auto fetch = [&](int b_) {
         const int f_ = min(f0 + wave * 8 + b_, F - 1);
-        const float* re0 = X + (int64_t)(f_)*T_ld + st;            // mic 0, Re row f
-        const float* im0 = X + (int64_t)(F + f_) * T_ld + st;      // mic 0, Im row f
-        const float* rem = re0 + (int64_t)m * 2 * F * T_ld;        // mic m
-        const float* imm = im0 + (int64_t)m * 2 * F * T_ld;
+        const float* re0 = X + ((int64_t)mr * 2 * F + f_) * T_ld + st;       // the pair's right microphone (0 for the spectral rows)
+        const float* im0 = X + ((int64_t)mr * 2 * F + F + f_) * T_ld + st;
+        const float* rem = X + ((int64_t)ml * 2 * F + f_) * T_ld + st;       // the pair's left microphone
+        const float* imm = X + ((int64_t)ml * 2 * F + F + f_) * T_ld + st;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int t = lane + 64 * i;
@@ -225,50 +227,75 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < NT; ++i) { c_r0[i] = n_r0[i]; c_i0[i] = n_i0[i]; c_rm[i] = n_rm[i]; c_im[i] = n_im[i]; }
         if (b + 1 < 8) fetch(b + 1);
-        float a[NT], bq[NT];
-        float s0 = 0.f, s1 = 0.f;
+        float a[NT], bq[NT], dd[NT];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int t = lane + 64 * i;
-            a[i] = 0.f; bq[i] = 0.f;
+            a[i] = 0.f; bq[i] = 0.f; dd[i] = 0.f;
             if (t < T) {
                 const float r0 = c_r0[i], i0 = c_i0[i];
                 if (m == 0) {
                     a[i] = fmaxf(sqrtf(r0 * r0 + i0 * i0), CSS_EPS32);
+                    if (o.log_mag) a[i] = logf(a[i]);                    // feature.py:500-501
                     s0 += a[i];
                 } else {
                     const float rm = c_rm[i], imv = c_im[i];
                     const float d = phase_of(rm, imv) - phase_of(r0, i0);
+                    dd[i] = d;
                     a[i] = cosf(d);
                     bq[i] = sinf(d);
                     s0 += a[i];
                     s1 += bq[i];
+                    s2 += d;
                 }
             }
         }
         s0 = wave_sum_f(s0);
         s1 = wave_sum_f(s1);
         if (m == 0) {
-            const float mean = s0 * invT;
-            float q = 0.f;
+            if (o.mvn) {                                                 // feature.py:503-507
+                const float mean = s0 * invT;
+                float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int t = lane + 64 * i;
-                if (t < T) { a[i] -= mean; q += a[i] * a[i]; }
-            }
-            const float sd = sqrtf(wave_sum_f(q) / (float)(T - 1));
-            const float den = sd + CSS_EPS32;
+                for (int i = 0; i < NT; ++i) {
+                    const int t = lane + 64 * i;
+                    if (t < T) { a[i] -= mean; q += a[i] * a[i]; }
+                }
+                const float sd = sqrtf(wave_sum_f(q) / (float)(T - 1));
+                const float den = sd + CSS_EPS32;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int t = lane + 64 * i;
-                if (t < T) tile[fl * FEAT_LD + t] = a[i] / den;
+                for (int i = 0; i < NT; ++i) {
+                    const int t = lane + 64 * i;
+                    if (t < T) tile[fl * FEAT_LD + t] = a[i] / den;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int t = lane + 64 * i;
+                    if (t < T) tile[fl * FEAT_LD + t] = a[i];
+                }
             }
-        } else {
+        } else if (o.ipd_norm && o.ipd_version == 1 && !o.ipd_cos) {     // the shipped configuration (feature.py:220-221,245)
             const float yrm = s0 * invT, yim = s1 * invT;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
                 if (t < T) tile[fl * FEAT_LD + t] = atan2f(bq[i] - yim, a[i] - yrm);
+            }
+        } else {                                                         // the other IPDFeature options (feature.py:214-236)
+            const float yrm = s0 * invT, yim = s1 * invT;
+            float shift = 0.f;
+            if (o.ipd_norm && o.ipd_version == 2) shift = atan2f(yim, yrm);
+            if (o.ipd_norm && o.ipd_version == 3) shift = wave_sum_f(s2) * invT;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = lane + 64 * i;
+                if (t < T) {
+                    float v = (o.ipd_norm && o.ipd_version == 1) ? atan2f(bq[i] - yim, a[i] - yrm) : dd[i] - shift;
+                    if (o.ipd_cos) v = cosf(v);
+                    tile[fl * FEAT_LD + t] = v;
+                }
             }
         }
     }
@@ -291,14 +318,15 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     int split_out, hipStream_t s) {
-    const dim3 grid((F + 31) / 32, C, nseg), block(256);
+                     int split_out, const FeatOpts& opts, hipStream_t s) {
+    (void)C;
+    const dim3 grid((F + 31) / 32, 1 + opts.num_pairs, nseg), block(256);
     if (T <= 256)
         hipLaunchKernelGGL(features_kernel<256>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out);
+                           seg_lo, T, hop, split_out, opts);
     else
         hipLaunchKernelGGL(features_kernel<512>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out);
+                           seg_lo, T, hop, split_out, opts);
 }
 
 // ------------------------------------------------------------------------------------------------

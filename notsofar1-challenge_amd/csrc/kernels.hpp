@@ -128,9 +128,13 @@ void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_
                          hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
 // or split-f16 rows (split_f16.hpp; the padding columns are never written and must be zero)
+struct FeatOpts {   // CssFeatureCfg in kernel-argument form
+    int log_mag, mvn, ipd_norm, ipd_version, ipd_cos, num_pairs;
+    unsigned char pair_l[16], pair_r[16];
+};
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     int split_out, hipStream_t s);
+                     int split_out, const FeatOpts& opts, hipStream_t s);
 // out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
 // only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
 // level (may be null): the samples are multiplied by 1 / level_gain(level) (undoes the scaling of the split spectra rows)

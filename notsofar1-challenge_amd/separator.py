@@ -65,20 +65,43 @@ class ConformerCssCfg:
 _SUPPORTED_EXTRACTOR = ExtractorCfg()
 
 
+def ipd_pairs(ipd_index: str):
+    """'1,0;2,0;...' -> [(l, r), ...] as IPDFeature parses it (feature.py:182-188)"""
+    return [tuple(int(x) for x in p.split(",")) for p in ipd_index.split(";")] if ipd_index else []
+
+
+def feature_options(e: ExtractorCfg) -> dict:
+    """ExtractorCfg -> keyword arguments of Handle.set_feature_options (css_set_feature_options)"""
+    return dict(log_spectrogram=e.log_spectrogram, mvn_spectrogram=e.mvn_spectrogram,
+                ipd_mean_normalize=e.ipd_mean_normalize, ipd_mean_normalize_version=e.ipd_mean_normalize_version,
+                ipd_cos=e.ipd_cos, pairs=ipd_pairs(e.ipd_index))
+
+
 def desc_from_cfg(cfg: ConformerCssCfg) -> ModelDesc:
-    """ConformerCssCfg -> the C ABI's model descriptor; rejects feature configurations the HIP feature
-    kernel does not implement (it implements exactly what the shipped v1.0 MC / SC models use)."""
+    """ConformerCssCfg -> the C ABI's model descriptor.  The spectral and IPD options of ExtractorCfg
+    (`log_spectrogram`, `mvn_spectrogram`, `ipd_index`, `ipd_mean_normalize`, `ipd_mean_normalize_version`, `ipd_cos`) are
+    all implemented (css_set_feature_options); rejected: another analysis window / frame size (the FFT kernel is the
+    512-point Hann transform) and `ang_index` -- the reference's own wrapper never passes the direction of arrival its
+    AngleFeature needs (conformer_wrapper.py:96-100 calls the executor without `doa`), so no model can use it there either."""
     e, n = cfg.extractor_conf, cfg.nnet_conf
-    for name in ("ang_index", "ipd_cos", "ipd_mean_normalize", "ipd_mean_normalize_version", "log_spectrogram",
-                 "mvn_spectrogram", "window", "round_pow_of_two"):
+    for name in ("ang_index", "window", "round_pow_of_two"):
         if getattr(e, name) != getattr(_SUPPORTED_EXTRACTOR, name):
             raise NotImplementedError(f"extractor_conf.{name}={getattr(e, name)!r} is not supported by the HIP "
-                                      f"feature kernel (supported: {getattr(_SUPPORTED_EXTRACTOR, name)!r})")
-    if e.ipd_index not in ('', _SUPPORTED_EXTRACTOR.ipd_index):
-        raise NotImplementedError(f"extractor_conf.ipd_index={e.ipd_index!r} not supported")
-    num_mics = 7 if e.ipd_index else 1
+                                      f"front end (supported: {getattr(_SUPPORTED_EXTRACTOR, name)!r})")
+    if (e.frame_len, e.frame_hop) != (512, 256):
+        raise NotImplementedError("the analysis transform is built for frame_len 512 / frame_hop 256")
+    pairs = ipd_pairs(e.ipd_index)
+    if len(pairs) > 16:
+        raise NotImplementedError("at most 16 IPD pairs")
+    if e.ipd_mean_normalize and e.ipd_mean_normalize_version not in (1, 2, 3):
+        raise RuntimeError(f"expect ipd_mean_normalization version 1, 2 or 3, got {e.ipd_mean_normalize_version}")  # feature.py:228-231
+    num_mics = (max(max(p) for p in pairs) + 1) if pairs else 1
+    num_mics = 7 if pairs and num_mics <= 7 else num_mics        # the NOTSOFAR array (mic_array_model.py:4)
+    bins = e.frame_len // 2 + 1
+    assert n.in_features == bins * (1 + len(pairs)), \
+        f"in_features={n.in_features} does not match {bins} bins x (1 + {len(pairs)} IPD pairs)"
     c = n.conformer_conf
-    return ModelDesc(num_mics=num_mics, num_bins=e.frame_len // 2 + 1, in_features=n.in_features,
+    return ModelDesc(num_mics=num_mics, num_bins=bins, in_features=n.in_features,
                      attention_dim=c.attention_dim, attention_heads=c.attention_heads,
                      linear_units=c.linear_units, num_blocks=c.num_blocks, kernel_size=c.kernel_size,
                      num_spks=n.num_spks, num_nois=n.num_nois, frame_len=e.frame_len, frame_hop=e.frame_hop)
@@ -152,6 +175,8 @@ class HipSeparator:
     def handle(self) -> _lib.Handle:
         if self._handle is None:
             self._handle = _lib.Handle(self.desc, self.blob, self._device, self._stream, self._max_batch)
+            if self.cfg is not None and self.cfg.extractor_conf != _SUPPORTED_EXTRACTOR:
+                self._handle.set_feature_options(**feature_options(self.cfg.extractor_conf))
         return self._handle
 
     def close(self):

@@ -201,11 +201,16 @@ def istft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int 
 # ----------------------------------------------------------------------------------------------
 # features (feature.py:478-508 compute_spectra, 198-249 IPDFeature, 543-569 forward)
 # ----------------------------------------------------------------------------------------------
-def features(stft_seg: np.ndarray, dtype=np.float32) -> np.ndarray:
-    """stft_seg complex [F, T, C] (MC) or [F, T] (SC) -> feature [D, T] (D = 1799 or 257).
+def features(stft_seg: np.ndarray, dtype=np.float32, log_spectrogram: bool = False, mvn_spectrogram: bool = True,
+             ipd_mean_normalize: bool = True, ipd_mean_normalize_version: int = 1, ipd_cos: bool = False,
+             pairs=None) -> np.ndarray:
+    """stft_seg complex [F, T, C] (MC) or [F, T] (SC) -> feature [D, T] (D = F (1 + pairs); 1799 or 257 as shipped).
 
-    Rows 0..F-1: mean/variance-normalised clamped magnitude of channel 0 (feature.py:496-507,
-    unbiased std).  Rows F + F*m + f: IPD v1 of pair (m+1, 0) as a raw angle (feature.py:214-221,245).
+    Rows 0..F-1: clamped magnitude of channel 0 (feature.py:496-499), optionally its log (:500-501), mean / variance
+    normalised over time with the unbiased std (:503-507).  Rows F + F*p + f: IPD of pair p (feature.py:212;
+    default pairs (m, 0), ipd_index '1,0;...;6,0'): phase difference, time-mean removed per version 1 (:220-221:
+    atan2 of the mean-removed unit phasor -- the shipped one), 2 (:222-224: minus atan2(mean sin, mean cos)) or
+    3 (:225-227: minus the mean angle), as a raw angle (:245) or its cosine (:234-236).
     """
     if stft_seg.ndim == 2:
         mag = np.abs(stft_seg).astype(dtype)[None]
@@ -216,18 +221,32 @@ def features(stft_seg: np.ndarray, dtype=np.float32) -> np.ndarray:
         pha = _angle(xs, dtype)
     eps = dtype(EPS32)
     f = np.maximum(mag[0], eps)
-    mean = f.mean(-1, keepdims=True, dtype=dtype)
-    std = f.std(-1, keepdims=True, ddof=1, dtype=dtype)
-    f = (f - mean) / (std + eps)
+    if log_spectrogram:
+        f = _ef(np.log, dtype, f)
+    if mvn_spectrogram:
+        mean = f.mean(-1, keepdims=True, dtype=dtype)
+        std = f.std(-1, keepdims=True, ddof=1, dtype=dtype)
+        f = (f - mean) / (std + eps)
     feats = [f]
     if pha is not None and pha.shape[0] > 1:
-        for m in range(1, pha.shape[0]):
-            d = pha[m] - pha[0]
-            yr = _cos(d, dtype)
-            yi = _sin(d, dtype)
-            yrm = yr.mean(-1, keepdims=True, dtype=dtype)
-            yim = yi.mean(-1, keepdims=True, dtype=dtype)
-            feats.append(_atan2(yi - yim, yr - yrm, dtype))
+        if pairs is None:
+            pairs = [(m, 0) for m in range(1, pha.shape[0])]
+        for l, r in pairs:
+            d = pha[l] - pha[r]
+            if ipd_mean_normalize:
+                yr = _cos(d, dtype)
+                yi = _sin(d, dtype)
+                yrm = yr.mean(-1, keepdims=True, dtype=dtype)
+                yim = yi.mean(-1, keepdims=True, dtype=dtype)
+                if ipd_mean_normalize_version == 1:
+                    d = _atan2(yi - yim, yr - yrm, dtype)
+                elif ipd_mean_normalize_version == 2:
+                    d = d - _atan2(yim, yrm, dtype)
+                elif ipd_mean_normalize_version == 3:
+                    d = d - d.mean(-1, keepdims=True, dtype=dtype)
+                else:
+                    raise RuntimeError("ipd_mean_normalize_version must be 1, 2 or 3")   # feature.py:228-231
+            feats.append(_cos(d, dtype) if ipd_cos else d)
     return np.concatenate(feats, axis=0)
 
 
