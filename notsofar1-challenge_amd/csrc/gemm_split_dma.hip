@@ -550,14 +550,12 @@ bool gemm_split_ws_pays(const GemmArgs& g) {
 }
 
 // g.tile_rows selects the variant (tools / tests): 3 = specialised waves (gemm_split_ws_kernel, three slab buffers);
-// 24 / 242 / 42 = gemm_split_dma_kernel as 2 x 4 waves with 3 / 2 buffers, 4 x 2 waves
+// 24 = gemm_split_dma_kernel (2 x 4 waves, 3 slab buffers; the 4 x 2 and two-buffer forms measured the same and are gone)
 void launch_gemm_split_dma(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     const int tiles_m = (g.M + dma::DBM - 1) / dma::DBM, tiles_n = (g.N + dma::DBN - 1) / dma::DBN;
     const dim3 grid(tiles_m * tiles_n);
     switch (g.tile_rows) {
-        case 42: hipLaunchKernelGGL((gemm_split_dma_kernel<4, 2, 3>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
-        case 242: hipLaunchKernelGGL((gemm_split_dma_kernel<2, 4, 2>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
         case 24: hipLaunchKernelGGL((gemm_split_dma_kernel<2, 4, 3>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
         case 4: hipLaunchKernelGGL((gemm_split_ws_kernel<4>), grid, dim3(512), 0, s, g, tiles_m, tiles_n); break;
 #ifdef CSS_GEMM_DMA_ABLATE
