@@ -289,7 +289,8 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     const int pick = g.tile_rows;
     // 128 x 128 tiles through LDS DMA with specialised waves (gemm_split_dma.hip): same bits; tile_rows = 3 asks for it,
     // the automatic choice follows gemm_split_ws_pays() (which is "never" today: see that function)
-    if ((pick == 3 || (!pick && gemm_split_ws_pays(g))) && gemm_split_ws_eligible(g)) {
+    if (pick == 33 && gemm_split_wsp_eligible(g)) return launch_gemm_split_dma(g, s);   // ... persistent over the tiles
+    if ((pick == 3 || pick == 33 || (!pick && gemm_split_ws_pays(g))) && gemm_split_ws_eligible(g)) {
         GemmArgs q = g;
         q.tile_rows = 3;
         return launch_gemm_split_dma(q, s);
@@ -307,7 +308,7 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     } else if (pick == 65) {
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, false>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
-    } else if (pick == 64 || pick == 3 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
+    } else if (pick == 64 || pick == 3 || pick == 33 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
     } else {

@@ -55,6 +55,7 @@ void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
 void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s);  // gemm_split_wd.hip (g.b_tiled)
 void launch_gemm_split_dma(const GemmArgs& g, hipStream_t s);  // gemm_split_dma.hip (g.b_tiled; both operands via LDS DMA)
 bool gemm_split_ws_eligible(const GemmArgs& g);                // ... whether its specialised-wave kernel can take the launch
+bool gemm_split_wsp_eligible(const GemmArgs& g);               // ... its persistent form (tile_rows = 33)
 bool gemm_split_ws_pays(const GemmArgs& g);                    // ... and whether it is the faster choice at this shape
 // float32 W [N][K] (row stride ld_src, K % 32 == 0) -> tile-major split-f16 weights, (N rounded up to 32) * K floats
 void launch_split_convert_tiled(const float* src, int64_t ld_src, float* dst, int N, int K, hipStream_t s);

@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
                       {512, 1824, "embed", 3}};
     std::vector<int> Ms = {7440, 2480, 23808};
     if (argc > 1) { Ms.clear(); for (int i = 1; i < argc; ++i) Ms.push_back(atoi(argv[i])); }
-    std::vector<int> variants = {65, 3, 24};
+    std::vector<int> variants = {3, 33};
     if (getenv("ABLATE")) variants = {24, 3, 2001, 2002, 2004, 2006};
     const int T = 186, H = 8, D = 512;
     const size_t maxe = 24000ull * 1824;
@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
         for (int v : variants) {
             hipMemsetAsync(C[1], 0xFF, (size_t)M * sh.N * 4, st); hipMemsetAsync(frag[1], 0, fragf * 4, st);
             GemmArgs g1 = args(1); g1.tile_rows = v;
-            const double t1 = timeit([&] { if (v == 65) launch_gemm_split_wd(g1, st); else launch_gemm_split_dma(g1, st); });
+            const double t1 = timeit([&] { if (v == 65 || v == 33) launch_gemm_split_wd(g1, st); else launch_gemm_split_dma(g1, st); });
             c1.resize(c0.size()); hipMemcpy(c1.data(), C[1], c1.size() * 4, hipMemcpyDeviceToHost);
             size_t bad = 0, first = 0;
             // q / k columns of the qkv launch are not written to C (they leave in fragment order): compare only what is written
