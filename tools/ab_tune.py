@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of css_set_tuning("gemm_ws", v) inside ONE process, passes interleaved (box-to-box and run-to-run spread is 3 %,
+"""A/B of css_set_tuning(NAME, v) inside ONE process, passes interleaved (box-to-box and run-to-run spread is 3 %,
 more than the effect): GEMM time per pass from the library's own HIP-event profile (one lane) and device-resident pass
-time on the production schedule (three lanes).   python tools/ab_gemm_ws.py [seconds] [rounds]"""
+time on the production schedule (three lanes).   python tools/ab_tune.py NAME v0,v1,... [seconds] [rounds]"""
 import importlib
 import os
 import sys
@@ -16,8 +16,10 @@ pkg = lambda n: importlib.import_module("notsofar1_challenge_amd." + n)  # noqa:
 
 def main():
     import torch
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    name = sys.argv[1]
+    modes = [int(v) for v in sys.argv[2].split(",")]
+    seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
+    rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     W, SYN, CSS, SEP, L = pkg("weights"), pkg("synth"), pkg("css"), pkg("separator"), pkg("_lib")
     desc = W.ModelDesc.mc_v1()
     cal = np.load(os.path.join(ROOT, "tests", "golden", "calib_mc.npz"))
@@ -33,13 +35,12 @@ def main():
     go = lambda: h.run_device(pcm.data_ptr(), n, 7, run_cfg, wav.data_ptr(), int(plan.n_out))  # noqa: E731
     for _ in range(3):
         go()
-    modes = [0, 1, 3, 2]
     gemm = {m: [] for m in modes}
     dev = {m: [] for m in modes}
     ref = None
     for r in range(rounds):
         for m in modes:
-            h.set_tuning("gemm_ws", m)
+            h.set_tuning(name, m)
             h.set_profile(True)
             go(); go()
             t = h.timings()
@@ -58,7 +59,7 @@ def main():
             assert np.array_equal(out, ref), m
     print(f"{seconds:g} s meeting, {rounds} interleaved rounds; results bit-identical in every mode")
     for m in modes:
-        print(f"gemm_ws={m}: GEMM ms per pass (one lane, HIP events) median {np.median(gemm[m]):.3f} min {min(gemm[m]):.3f} | "
+        print(f"{name}={m}: GEMM ms per pass (one lane, HIP events) median {np.median(gemm[m]):.3f} min {min(gemm[m]):.3f} | "
               f"device-resident pass ms median {np.median(dev[m]):.3f} min {min(dev[m]):.3f}")
     sep.close()
 
