@@ -209,8 +209,18 @@ def main():
     # CSS_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (RCCL refuses two ranks on one device, gloo does not: a 1-GPU box
     # can then exercise the N > 1 code path); CSS_BENCH_CHECK=1 compares the sharded result with the fused run;
     # CSS_BENCH_DRY=1 stops after the rendezvous and the rank / device census (no GPU needed: tests/test_bench_spawn.py)
+    # CSS_BENCH_FORCE_SHARDED=1 takes the N > 1 path with whatever world there is -- with one rank it is the RCCL smoke a
+    # 1-GPU box can run: communicator creation on the device, every collective of the path at world 1 (profiles/)
     backend = os.environ.get("CSS_BENCH_BACKEND", "nccl")
     dry = os.environ.get("CSS_BENCH_DRY") == "1"
+    sharded = world > 1 or os.environ.get("CSS_BENCH_FORCE_SHARDED") == "1"
+    if sharded and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(free_port)), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
     if dry:
         backend = "gloo"
     elif not torch.cuda.is_available():
@@ -222,7 +232,7 @@ def main():
         torch.cuda.set_device(local_rank)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     evidence = None
-    if world > 1:
+    if sharded:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -231,7 +241,7 @@ def main():
     if dry:
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "collective": evidence}), flush=True)
-        if world > 1:
+        if sharded:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -269,7 +279,7 @@ def main():
               "data": "synthetic"}
 
     # ================================================================================================ N > 1
-    if world > 1:
+    if sharded:
         seconds = args.long_seconds
         mix = meeting(seconds)
         n = mix.shape[1]

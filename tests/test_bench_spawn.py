@@ -35,10 +35,20 @@ def test_plain_launch_spawns_its_ranks():
     assert len({i["pid"] for i in col["ranks"]}) == 2      # two real processes
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_torch_distributed_run_entry_still_works():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+    for attempt in range(2):    # (a port can be taken between the probe and the rendezvous)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+        r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["collective"]["world"] == 2
@@ -54,3 +64,15 @@ def test_a_failing_rank_stops_the_launch():
                        text=True, timeout=300)
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr
+
+
+def test_one_rank_can_take_the_sharded_path():
+    """CSS_BENCH_FORCE_SHARDED=1: the N > 1 code path with one rank (on a 1-GPU box that is the RCCL smoke,
+    profiles/r03_rccl_world1.log); here: rendezvous + census at world 1."""
+    env = _env()
+    env["CSS_BENCH_FORCE_SHARDED"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["dry_run"] and line["collective"]["world"] == 1 and line["collective"]["ranks_seen_by_all_gather"] == [0]
