@@ -364,7 +364,8 @@ int css_validation_loss_host(css_handle_t h, const float* mix_host, const float*
  * ranges kept -- the time map back to the meeting -- and mel_host [n_mels][*n_mel_frames] receives Whisper's input
  * features of their concatenation (whisper/audio.py log_mel_spectrogram: reflect-padded 400-point Hann STFT, hop 160,
  * power, slaney mel bank with n_mels = 80 or 128, log10 floored at 1e-10, max - 8 clamp, (x + 4) / 4), computed on the
- * device.  drop_silence = 0: one region, the whole stream.  Whisper is not under the reference tree: parity unpinned. */
+ * device.  drop_silence = 0: one region, the whole stream.  Whisper is not under the reference tree: the algorithm is held to
+ * transformers.WhisperFeatureExtractor (tests/test_oracle_whisper_pin.py), not to openai-whisper itself. */
 int css_handoff_logmel(css_handle_t h, const float* wav_dev, int64_t wav_ld, int32_t stream, int32_t n_mels, int32_t pad_frames,
                        int32_t drop_silence, float* mel_host, int64_t mel_capacity_frames, int64_t* n_mel_frames,
                        int64_t* regions_host, int32_t max_regions, int32_t* n_regions);

@@ -6,7 +6,8 @@
 // back -- and turned into Whisper's input features on the device: reflect-padded 400-point Hann STFT at hop 160, power
 // spectrum, slaney mel filterbank (80 or 128 bands), log10 with the 1e-10 floor, the max - 8 clamp, (x + 4) / 4
 // (whisper/audio.py log_mel_spectrogram -- a dependency that is not under the reference tree and not installed here:
-// its published algorithm is restated, parity unpinned; tests compare with the oracle's numpy restatement).
+// its published algorithm is restated; tests compare with the oracle's numpy restatement, which is held to
+// transformers.WhisperFeatureExtractor in tests/test_oracle_whisper_pin.py).
 #include <cmath>
 #include <vector>
 

@@ -731,7 +731,9 @@ def validation_loss(params: ConformerParams, mix: np.ndarray, gt_spk0: np.ndarra
 # downstream hand-off: active regions + Whisper's log-mel front end.
 # whisper (openai-whisper, requirements.txt of the reference; asr/asr.py:58,73-74 calls it) is NOT under the reference
 # tree and not installed here: its published algorithm (whisper/audio.py log_mel_spectrogram; mel bank =
-# librosa.filters.mel(sr=16000, n_fft=400, n_mels), slaney scale / normalisation) is restated.  PARITY UNPINNED.
+# librosa.filters.mel(sr=16000, n_fft=400, n_mels), slaney scale / normalisation) is restated.  Pinned to a second
+# party's implementation of the same front end that the image holds (transformers.WhisperFeatureExtractor:
+# tests/test_oracle_whisper_pin.py), NOT to openai-whisper itself.
 # ----------------------------------------------------------------------------------------------
 def active_regions(act_final: np.ndarray, pad_frames: int, n_out: int, frame_hop: int = 256, frame_len: int = 512):
     """act_final [T_long] bool (css.py:303-312) -> [n, 2] sample ranges: maximal runs of active frames, widened by

@@ -206,8 +206,8 @@ def test_pcm16_wav_edges_on_device_are_bit_exact(tmp_path, tiny_models):
 def test_device_handoff_to_whisper_front_end(tiny_models):
     """SURVEY.md 8f N4 (css.py:313 "drop silent parts to save ASR compute"): after a device-resident pass, each
     stream's active regions -- the time map -- and Whisper's log-mel features of their concatenation, computed on the
-    GPU, against the oracle's restatement of whisper/audio.py on the same samples (parity unpinned: whisper is not
-    under the reference tree)."""
+    GPU, against the oracle's restatement of whisper/audio.py on the same samples (whisper is not under the reference
+    tree; the restatement is held to transformers.WhisperFeatureExtractor in tests/test_oracle_whisper_pin.py)."""
     import torch
     css, sep_mod, L = pkg("css"), pkg("separator"), pkg("_lib")
     _, models = tiny_models
