@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of css_set_tuning(NAME, v) inside ONE process, passes interleaved (box-to-box and run-to-run spread is 3 %,
 more than the effect): GEMM time per pass from the library's own HIP-event profile (one lane) and device-resident pass
-time on the production schedule (three lanes).   python tools/ab_tune.py NAME v0,v1,... [seconds] [rounds]"""
+time on the production schedule (three lanes).   python tools/ab_tune.py NAME|env:VAR v0,v1,... [seconds] [rounds]"""
 import importlib
 import os
 import sys
@@ -40,7 +40,10 @@ def main():
     ref = None
     for r in range(rounds):
         for m in modes:
-            h.set_tuning(name, m)
+            if name.startswith("env:"):      # a launcher-level switch read from the environment at every launch
+                os.environ[name[4:]] = str(m)
+            else:
+                h.set_tuning(name, m)
             h.set_profile(True)
             go(); go()
             t = h.timings()
