@@ -47,8 +47,56 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_REAL_STDOUT = None
+
+
+def keep_stdout_for_the_record():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL 2.26 prints a version banner through C
+    stdio, flushed at exit -- i.e. AFTER the record): from here on file descriptor 1 is stderr, and emit_record() writes
+    the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_record(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def pkg(name):
     return importlib.import_module("notsofar1_challenge_amd." + name)
+
+
+def gemm_roofline(t, mode, ks_ref=None):
+    # `achieved` counts ALGORITHMIC flops (2*M*N*K of the float32 products the network defines).
+    achieved = t["gemm_flops"] / (t["gemm_ms"] * 1e-3) / 1e12 if t["gemm_ms"] > 0 else 0.0
+    if mode == "split_f16":
+        # every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi, f32 accumulate): the ceiling for float32-grade
+        # products on the f16 pipes is the dense f16 peak / 3, and achieved / that ceiling equals
+        # executed-MFMA-flops / dense f16 peak (the matrix-core utilisation).
+        peak = PEAK_F16_MATRIX_TFLOPS / 3.0
+        kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, weights direct)"
+        extra = {"mfma_executed_tflops": round(3 * achieved, 2), "mfma_dense_peak_tflops": PEAK_F16_MATRIX_TFLOPS,
+                 "vs_f32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
+    else:
+        peak = PEAK_FP32_MATRIX_TFLOPS
+        kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
+        extra = {}
+    out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
+           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+           "launches_per_step": int(t["gemm_launches"]),
+           "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
+           "flops_per_step": t["gemm_flops"], **extra}
+    # `achieved` divides by the HIP-event brackets as they are: a bracket also holds the launch gap and the two event
+    # records (an EMPTY bracket behind a 4-byte fill measures `empty_event_bracket_us` on this box).  The kernel trace
+    # of the same command (profiles/r03_kernel_stats.md) gives the kernels' own durations: ~3 us less per launch.
+    if ks_ref and "event_pair_overhead" in ks_ref:
+        out["empty_event_bracket_us"] = round(1e3 * ks_ref["event_pair_overhead"][0] / max(ks_ref["event_pair_overhead"][1], 1), 2)
+    return out
 
 
 def cpu_baseline(mix, state, seconds, cfg_kwargs, threads=16):
@@ -197,6 +245,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N` (how the driver starts a bench): this process becomes the launcher of N ranks
         raise SystemExit(spawn_ranks(args.gpus))
+    keep_stdout_for_the_record()
 
     import torch
     import torch.distributed as dist
@@ -240,7 +289,7 @@ def main():
         evidence = rank_census(torch, dist, backend, rank, world, local_rank, comm_dev, dry)
     if dry:
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "collective": evidence}), flush=True)
+            emit_record({"dry_run": True, "n_gpus": world, "collective": evidence})
         if sharded:
             dist.barrier()
             dist.destroy_process_group()
@@ -399,6 +448,18 @@ def main():
 
         phase_ms = {"all": phases("all"), "range": phases("range")}
 
+        # ---- roofline of the dominant kernel on THIS workload: one more step with the library's per-launch HIP-event
+        # brackets on (every rank takes the step -- it holds collectives --, rank 0 reports its own shard's launches;
+        # one lane: the brackets need one ordered stream, as at N = 1)
+        barrier()
+        h.set_profile(True)
+        step("all")
+        barrier()
+        t_prof, ks_prof = h.timings(), h.kernel_stats()
+        h.set_profile(False)
+        roof = gemm_roofline(t_prof, h.linear_mode(), ks_prof)
+        roof["measured_on"] = f"rank 0's shard ({me.seg_hi - me.seg_lo} segments) during one sharded step"
+
         if os.environ.get("CSS_BENCH_CHECK") == "1":   # functional test: the sharded result equals the fused single-GPU run
             ref = h.run(np.ascontiguousarray(mix[0]), run_cfg)
             step("range"); barrier()
@@ -431,6 +492,7 @@ def main():
                                                                                "waveforms (S x n_out x 4 B over one PCIe link)"),
             "phase_ms": phase_ms,
             "collective": evidence,
+            "roofline": roof,
         })
         if rank == 0:
             # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)
@@ -443,7 +505,7 @@ def main():
             result["speedup_vs_1gpu_same_workload"] = round(ms1 / ms_all, 3)
         dist.barrier()
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            emit_record(result)
         be.close()
         sep.close()
         dist.destroy_process_group()
@@ -559,33 +621,6 @@ def main():
         h.set_profile(False)
         return t, ks
 
-    def gemm_roofline(t, mode, ks_ref=None):
-        # `achieved` counts ALGORITHMIC flops (2*M*N*K of the float32 products the network defines).
-        achieved = t["gemm_flops"] / (t["gemm_ms"] * 1e-3) / 1e12 if t["gemm_ms"] > 0 else 0.0
-        if mode == "split_f16":
-            # every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi, f32 accumulate): the ceiling for float32-grade
-            # products on the f16 pipes is the dense f16 peak / 3, and achieved / that ceiling equals
-            # executed-MFMA-flops / dense f16 peak (the matrix-core utilisation).
-            peak = PEAK_F16_MATRIX_TFLOPS / 3.0
-            kernel = "css::gemm_split_wd_kernel (3 x v_mfma_f32_32x32x16_f16 per product, weights direct)"
-            extra = {"mfma_executed_tflops": round(3 * achieved, 2), "mfma_dense_peak_tflops": PEAK_F16_MATRIX_TFLOPS,
-                     "vs_f32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
-        else:
-            peak = PEAK_FP32_MATRIX_TFLOPS
-            kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
-            extra = {}
-        out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
-               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-               "launches_per_step": int(t["gemm_launches"]),
-               "avg_launch_us": round(1e3 * t["gemm_ms"] / max(t["gemm_launches"], 1), 2),
-               "flops_per_step": t["gemm_flops"], **extra}
-        # `achieved` divides by the HIP-event brackets as they are: a bracket also holds the launch gap and the two event
-        # records (an EMPTY bracket behind a 4-byte fill measures `empty_event_bracket_us` on this box).  The kernel trace
-        # of the same command (profiles/r03_kernel_stats.md) gives the kernels' own durations: ~3 us less per launch.
-        if ks_ref and "event_pair_overhead" in ks_ref:
-            out["empty_event_bracket_us"] = round(1e3 * ks_ref["event_pair_overhead"][0] / max(ks_ref["event_pair_overhead"][1], 1), 2)
-        return out
-
     t, ks = profiled_pass()
     roof = gemm_roofline(t, h.linear_mode(), ks)
     # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes from
@@ -657,7 +692,7 @@ def main():
 
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, seconds), {"activity_th": 0.3})
-    print(json.dumps(result), flush=True)
+    emit_record(result)
     sep.close()
 
 

@@ -150,6 +150,7 @@ struct css_ctx {
     struct ProfEvent { hipEvent_t a, b; int cat; };
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;
+    size_t prof_reduced = 0;   // brackets already summed into prof_ms (a staged session has no closing call that does it)
     double gemm_flops = 0.0;
     float prof_ms[CSS_PROF_COUNT] = {};
     int32_t prof_launches[CSS_PROF_COUNT] = {};
@@ -629,6 +630,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     h->ev_pool_used = 0;
     h->tim = CssTimings{};
     h->prof_used = 0;
+    h->prof_reduced = 0;
     h->gemm_flops = 0.0;
     h->pcm_src = nullptr;
 
@@ -1194,17 +1196,10 @@ static hipEvent_t pool_event(css_ctx* h) {
     return h->ev_pool[h->ev_pool_used++];
 }
 
-// stage times of the pass just synchronised (HIP events on the handle's streams) and the per-family kernel profile
-using HostClock = std::chrono::steady_clock::time_point;
-static int finish_timings(css_ctx* h, HostClock t0, HostClock t1, HostClock t2, bool staged) {
-    auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
+// the per-launch event brackets recorded since the session began (css_set_profile) -> per-family sums; the streams
+// they were recorded on must have been synchronised
+static void reduce_profile(css_ctx* h) {
     CssTimings& t = h->tim;
-    t.host_enqueue = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    t.host_total = std::chrono::duration<float, std::milli>(t2 - t0).count();
-    // (pipelined pass: the stages overlap -- masknet = first chain's begin .. last chain's end, beamformer included;
-    //  stitch / istft = the LAST batch's tail)
-    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = staged ? ms(3, 4) : 0.f; t.stitch = ms(4, 5);
-    t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
     t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = h->gemm_flops;
     for (int c = 0; c < CSS_PROF_COUNT; ++c) { h->prof_ms[c] = 0.f; h->prof_launches[c] = 0; }
     if (h->profile_gemm) {
@@ -1217,6 +1212,21 @@ static int finish_timings(css_ctx* h, HostClock t0, HostClock t1, HostClock t2, 
         t.gemm_ms = h->prof_ms[CSS_PROF_LINEAR];
         t.gemm_launches = h->prof_launches[CSS_PROF_LINEAR];
     }
+    h->prof_reduced = h->prof_used;
+}
+
+// stage times of the pass just synchronised (HIP events on the handle's streams) and the per-family kernel profile
+using HostClock = std::chrono::steady_clock::time_point;
+static int finish_timings(css_ctx* h, HostClock t0, HostClock t1, HostClock t2, bool staged) {
+    auto ms = [&](int a, int b) { float v = 0.f; hipEventElapsedTime(&v, h->ev[a], h->ev[b]); return v; };
+    CssTimings& t = h->tim;
+    t.host_enqueue = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    t.host_total = std::chrono::duration<float, std::milli>(t2 - t0).count();
+    // (pipelined pass: the stages overlap -- masknet = first chain's begin .. last chain's end, beamformer included;
+    //  stitch / istft = the LAST batch's tail)
+    t.upload = ms(0, 1); t.stft = ms(1, 2); t.masknet = ms(2, 3); t.mvdr = staged ? ms(3, 4) : 0.f; t.stitch = ms(4, 5);
+    t.istft = ms(5, 6); t.download = ms(6, 7); t.total = ms(0, 7); t.features = 0.f;
+    reduce_profile(h);
     return CSS_OK;
 }
 
@@ -1809,8 +1819,17 @@ int css_set_profile(css_handle_t h, int enable) {
     return CSS_OK;
 }
 
+// staged sessions (css_begin + css_stage_*) have no closing call: their brackets are summed when the figures are asked for
+static void reduce_pending_profile(css_ctx* h) {
+    if (!h->profile_gemm || h->prof_reduced == h->prof_used) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);   // (the lanes' streams are joined into it behind every estimator batch)
+    reduce_profile(h);
+}
+
 int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_t* count) {
     if (!h || !count || (cap > 0 && !out)) return CSS_ERR_INVALID_ARG;
+    reduce_pending_profile(h);
     int n = 0;
     for (int c = 0; c < CSS_PROF_COUNT; ++c) {
         if (!h->prof_launches[c]) continue;
@@ -1835,6 +1854,7 @@ int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_
 
 int css_get_timings(css_handle_t h, CssTimings* out) {
     if (!h || !out) return CSS_ERR_INVALID_ARG;
+    reduce_pending_profile(h);
     *out = h->tim;
     return CSS_OK;
 }

@@ -17,8 +17,9 @@ def _env():
 
 
 def _one_json_line(stdout):
-    # (gloo itself chats on stdout: "[Gloo] Rank 0 is connected to ..."; RCCL does not)
-    lines = [ln for ln in stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    # the communication libraries chat on stdout themselves (gloo: "[Gloo] Rank 0 is connected to ...", RCCL 2.26: a
+    # version banner at exit); bench.py hands file descriptor 1 to stderr and writes its record to the real stdout
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, stdout          # rank 0 prints ONE line, the other ranks nothing
     return json.loads(lines[0])
 
