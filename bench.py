@@ -496,9 +496,14 @@ def main():
         })
         if rank == 0:
             # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)
+            # (its own handle with the N = 1 line's batch size: the sharded handle holds a rank's whole shard in one batch)
             pcm_all = L.pinned_copy(np.ascontiguousarray(mix[0]))
             out_all = L.pinned_empty((S, n_out), np.float32)
-            ms1 = fused_host_to_host(h, pcm_all, out_all, 3, 1)
+            sep1 = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=args.max_batch)
+            try:
+                ms1 = fused_host_to_host(sep1.handle, pcm_all, out_all, 3, 1)
+            finally:
+                sep1.close()
             result["single_gpu_same_workload"] = {"ms_per_step": round(ms1, 3), "value": round(seconds / (ms1 * 1e-3), 2),
                                                   "speedup": round(ms1 / ms_all, 3),
                                                   "speedup_gather_range": round(ms1 / (1e3 * el_range / args.steps), 3)}
