@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "lsap.hpp"
 
 using namespace css;
 
@@ -1977,7 +1978,7 @@ int css_forward_host(css_handle_t h, const float* pcm, int32_t batch, int64_t n_
 
 // css/training/train.py:411 _calc_loss for a validation batch (train.py:529 eval_model): forward, |STFT| of the mixture's
 // and the ground truths' reference channel, S x S base-loss matrix per clip -> PIT (losses.py:32-48: the assignment of
-// least mean loss; exhaustive over the <= 6 permutations, first minimum in lexicographic order), noise loss, weighted mean.
+// least mean loss, found as scipy's linear_sum_assignment finds it: lsap.hpp), noise loss, weighted mean.
 int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_spk, const float* gt_noise, int32_t batch,
                              int64_t n_samples, int32_t n_ch, int32_t loss_name, int32_t base_loss, int32_t clip_gt,
                              float noise_weight, float* spk_loss, float* noise_loss, int32_t* perms, float* loss) {
@@ -2020,15 +2021,14 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
             for (int i = 0; i < 9; ++i) mat[i] += q[i];
             noise += q[9];
         }
-        // the assignment of least mean loss: perm[a] = ground truth assigned to prediction a
-        int best_p[3] = {0, 1, 2}, p[3] = {0, 1, 2};
+        // the assignment of least mean loss (losses.py:43, linear_sum_assignment): perm[a] = ground truth assigned to prediction a
+        double cm[SMAX][SMAX] = {};
+        for (int a = 0; a < S; ++a)
+            for (int k = 0; k < S; ++k) cm[a][k] = mat[a * 3 + k];
+        int best_p[SMAX];
+        lsap_small(cm, S, best_p);
         double best = 0.0;
-        bool have = false;
-        do {
-            double tot = 0.0;
-            for (int a = 0; a < S; ++a) tot += mat[a * 3 + p[a]];
-            if (!have || tot < best) { best = tot; have = true; for (int a = 0; a < S; ++a) best_p[a] = p[a]; }
-        } while (std::next_permutation(p, p + S));
+        for (int a = 0; a < S; ++a) best += mat[a * 3 + best_p[a]];
         const double sl = best * inv / S, nl = noise * inv;
         if (spk_loss) spk_loss[b] = (float)sl;
         if (noise_loss) noise_loss[b] = (float)nl;

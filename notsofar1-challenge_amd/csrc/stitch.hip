@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include "lsap.hpp"
 #include "split_f16.hpp"
 
 namespace css {
@@ -27,7 +28,6 @@ __device__ __forceinline__ double wave_sum_dd(double v) {
 // sequential dependence of css.py:266-285 is confined to the tiny scan below.
 //   input 0: masks   input 1: |separated spectrum|     loss 0: L1   loss 1: squared error
 // ------------------------------------------------------------------------------------------------
-constexpr int SMAX = 4;
 constexpr int PIT_CH = 16;   // frequency chunks per boundary: 39 boundaries alone would occupy 39 of 256 CUs
 
 // One block per (boundary, frequency chunk) -> partial[b][chunk][16]; a second kernel adds the chunks in a fixed
@@ -105,9 +105,14 @@ void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, in
 
 // ------------------------------------------------------------------------------------------------
 // Sequential permutation scan (css.py:266-285 with losses.py:32-48): perm[0] = identity;
-// perm[i+1] = argmin over permutations sigma of sum_a cost_i[perm[i][a]][sigma[a]].
-// The reference minimises with scipy.optimize.linear_sum_assignment; for S <= 4 an exhaustive search
-// in lexicographic order (first minimum wins) is the same optimum.  Shared by host and device.
+// perm[i+1] = linear_sum_assignment(cost_i with its rows in the order perm[i]).
+// The reference minimises with scipy.optimize.linear_sum_assignment (losses.py:43; scipy 1.11.4): the shortest-
+// augmenting-path algorithm of scipy's rectangular_lsap (Crouse 2016).  Any exact method finds the same optimum; WHICH
+// optimum on exact ties is decided by that algorithm's scan order (columns in descending order, an unassigned column
+// wins among equally cheap ones, later ones otherwise) -- and exact ties are the normal case where two speakers are
+// silent through a whole overlap (every cost between them is 0: scipy swaps them, a lexicographic search would not).
+// So the algorithm is restated step by step, for S <= 4, shared by host and device; tests/test_cabi.py holds it to
+// scipy itself on tie-laden matrices.  c[a][b] = cost of assigning row a to column b; out: col4row.
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_boundaries, int S, int32_t* perms) {
     for (int a = 0; a < S; ++a) perms[a] = a;
@@ -115,27 +120,12 @@ __host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_bou
         const double* c = costs + b * S * S;
         const int32_t* lp = perms + b * S;
         int32_t* rp = perms + (b + 1) * S;
-        int sig[SMAX] = {0, 1, 2, 3}, best_sig[SMAX] = {0, 1, 2, 3};
-        double best = 0.0;
-        bool first = true;
-        while (true) {
-            double tot = 0.0;
-            for (int a = 0; a < S; ++a) tot += c[lp[a] * S + sig[a]];
-            if (first || tot < best) {
-                best = tot;
-                first = false;
-                for (int a = 0; a < S; ++a) best_sig[a] = sig[a];
-            }
-            // next lexicographic permutation of sig[0..S)
-            int i = S - 2;
-            while (i >= 0 && sig[i] > sig[i + 1]) --i;
-            if (i < 0) break;
-            int j = S - 1;
-            while (sig[j] < sig[i]) --j;
-            int tmp = sig[i]; sig[i] = sig[j]; sig[j] = tmp;
-            for (int l = i + 1, r = S - 1; l < r; ++l, --r) { tmp = sig[l]; sig[l] = sig[r]; sig[r] = tmp; }
-        }
-        for (int a = 0; a < S; ++a) rp[a] = best_sig[a];
+        double m[SMAX][SMAX];
+        for (int a = 0; a < S; ++a)
+            for (int k = 0; k < S; ++k) m[a][k] = c[lp[a] * S + k];   // the left segment's channels in their stitched order
+        int sig[SMAX];
+        lsap_small(m, S, sig);
+        for (int a = 0; a < S; ++a) rp[a] = sig[a];
     }
 }
 
@@ -191,15 +181,18 @@ __global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict_
         for (int e = threadIdx.x; e < nb * np; e += blockDim.x) {
             const int b = e / np, pin = e - b * np;
             const double* c = costs + (b0 + b) * S * S;
-            int lp[SMAX], sig[SMAX];
+            int lp[SMAX], sig[SMAX], q[SMAX];
             perm_from_index(pin, S, lp);
-            double best = 0.0;
+            double m[SMAX][SMAX];
+            for (int a = 0; a < S; ++a)
+                for (int k = 0; k < S; ++k) m[a][k] = c[lp[a] * S + k];
+            lsap_small(m, S, sig);
             int arg = 0;
-            for (int k = 0; k < np; ++k) {  // ascending lexicographic order, strict '<': first minimum wins
-                perm_from_index(k, S, sig);
-                double tot = 0.0;
-                for (int a = 0; a < S; ++a) tot += c[lp[a] * S + sig[a]];
-                if (k == 0 || tot < best) { best = tot; arg = k; }
+            for (int k = 0; k < np; ++k) {  // the state (lexicographic index) of the assignment found
+                perm_from_index(k, S, q);
+                bool same = true;
+                for (int a = 0; a < S; ++a) same &= q[a] == sig[a];
+                if (same) arg = k;
             }
             next[b * np + pin] = (uint8_t)arg;
         }

@@ -194,7 +194,7 @@ def _stage_separator(num_mics: int, num_spks: int, device) -> HipSeparator:
 def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, device, cfg: CssCfg, return_side_info: bool):
     """css/css.py:110-338 for ANY object that honours the separator protocol (css.py:131: `stft`, `separate`, `istft`;
     conformer_wrapper.py:79-146).  As in the reference, `separator.separate(stft_seg)` is called once per segment with a
-    complex tensor [1, F, T, C] on `device` (css.py:183-199; zero-padded last segment) and returns
+    complex tensor [1, F, T, C] on `device` (css.py:183-199; zero-padded last segment; C == 1 keeps its axis) and returns
     {'spk_masks': [1, F, T, S], 'noise_masks': [1, F, T, 1]}.  Everything else -- analysis transform of the whole
     recording, winner-take-all masks / covariances / MVDR, mask floor, stitching, gate, synthesis -- runs on the HIP
     stages of the C ABI (css_begin, css_stage_stft, css_stage_mvdr, ..., css_stage_istft); the masks go straight into the
@@ -228,8 +228,9 @@ def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, de
             assert tuple(masks.shape) == ((S + 1) * F, nseg * T), (masks.shape, S, F, nseg, T)
             # the separator's own transform must be the stages' transform (checked on the first frames of the recording)
             if hasattr(separator, "stft"):
+                # [B, N, C] in, [B, F, T, C] out, also for C == 1: what css.py:155 hands over
                 probe = torch.from_numpy(np.ascontiguousarray(speech_mix[:, :desc.frame_len + 3 * desc.frame_hop])).to(dev)
-                theirs = separator.stft(probe if c > 1 else probe[..., 0])
+                theirs = separator.stft(probe)
                 theirs = theirs.reshape(1, F, -1, c) if theirs.ndim == 3 else theirs
                 k = min(theirs.shape[2], frames)
                 ours = torch.complex(X[:, :F, :k], X[:, F:2 * F, :k]).permute(1, 2, 0)[None]
@@ -243,7 +244,7 @@ def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, de
                 if t > 0:
                     blk = X[:, :, i * hop:i * hop + t]
                     seg[0, :, :t, :] = torch.complex(blk[:, :F], blk[:, F:2 * F]).permute(1, 2, 0)
-                out = separator.separate(seg if c > 1 else seg[..., 0])
+                out = separator.separate(seg)                    # always [1, F, T, C], C == 1 included (css.py:199)
                 spk, noi = out['spk_masks'], out['noise_masks']
                 assert tuple(spk.shape) == (1, F, T, S), f'spk_masks {tuple(spk.shape)}, expected {(1, F, T, S)}'   # css.py:202
                 assert tuple(noi.shape) == (1, F, T, 1), f'noise_masks {tuple(noi.shape)}, expected {(1, F, T, 1)}'  # css.py:203
@@ -270,6 +271,15 @@ def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, de
         }
     finally:
         be.close()
+        if hasattr(separator, "cpu"):
+            separator.cpu()                                      # css.py:318: the separator goes back to the host
+
+
+def close_stage_separators() -> None:
+    """Releases the stand-in handles `_separate_and_stitch_protocol` keeps per (microphones, speakers, GPU)."""
+    while _STAGE_SEPARATORS:
+        _, sep = _STAGE_SEPARATORS.popitem()
+        sep.close()
 
 
 @dataclass

@@ -305,16 +305,19 @@ class ConformerParams:
                          maxlen=self.st["executor.nnet.conformer.pos_emb.pe_k.weight"].shape[0] // 2)
 
 
-def conformer_forward(p: ConformerParams, feat: np.ndarray, taps: Optional[dict] = None) -> np.ndarray:
+def conformer_forward(p: ConformerParams, feat: np.ndarray, taps: Optional[dict] = None,
+                      affine_applied: bool = False) -> np.ndarray:
     """feat [D, T] -> masks [num_spks+num_nois, F, T]   (ConformerCSS.forward, conformer.py:287-310).
 
-    Inference mode: every Dropout is the identity, BatchNorm uses running statistics.
+    Inference mode: every Dropout is the identity, BatchNorm uses running statistics.  ``affine_applied``: ``feat`` already
+    carries the input bias and scale of conformer.py:298-299 (the rows the HIP feature kernel hands to the embedding).
     """
     dt = p.dtype
     dims = p.dims()
     h_, dk = dims.attention_heads, dims.attention_dim // dims.attention_heads
     x = feat.T.astype(dt)  # [T, D]                                           conformer.py:295
-    x = (x + p("input_bias").reshape(-1)) * p("input_scale").reshape(-1)     # conformer.py:298-299
+    if not affine_applied:
+        x = (x + p("input_bias").reshape(-1)) * p("input_scale").reshape(-1)     # conformer.py:298-299
     # embed: Linear -> LayerNorm -> (Dropout) -> ReLU                           conformer.py:205-210
     x = _linear(x, p("conformer.embed.0.weight"), p("conformer.embed.0.bias"))
     x = _layer_norm(x, p("conformer.embed.1.weight"), p("conformer.embed.1.bias"))
@@ -500,24 +503,80 @@ def calc_segment_weight(seg_frames: int, m0: int, m1: int, is_first_seg=False, i
     return w
 
 
+def lsap(cost: np.ndarray) -> Tuple[int, ...]:
+    """``scipy.optimize.linear_sum_assignment`` for a square matrix, restated (the reference's permutation solver,
+    losses.py:43; scipy pinned 1.11.4, requirements.txt): the shortest-augmenting-path algorithm of scipy's
+    ``rectangular_lsap`` (Crouse 2016), INCLUDING its tie rules -- columns are scanned in descending order, among equally
+    cheap columns an unassigned one wins, later ones win otherwise.  The optimum is what a brute-force search finds; the
+    rules decide WHICH optimum on exact ties, and exact ties are the normal case where two speakers are silent through a
+    whole overlap (all four costs between them are 0).  Returns col4row: row a is assigned column col4row[a].
+    Pinned against scipy itself on tie-laden matrices in tests/test_oracle_lsap.py."""
+    c = np.asarray(cost, dtype=np.float64)
+    n = c.shape[0]
+    assert c.shape == (n, n)
+    inf = float("inf")
+    u, v = [0.0] * n, [0.0] * n
+    path = [-1] * n
+    col4row, row4col = [-1] * n, [-1] * n
+    for cur in range(n):
+        remaining = [n - it - 1 for it in range(n)]
+        num_remaining = n
+        sr, sc = [False] * n, [False] * n
+        spc = [inf] * n
+        min_val, i, sink = 0.0, cur, -1
+        while sink == -1:
+            index, lowest = -1, inf
+            sr[i] = True
+            for it in range(num_remaining):
+                j = remaining[it]
+                r = min_val + c[i, j] - u[i] - v[j]
+                if r < spc[j]:
+                    path[j] = i
+                    spc[j] = r
+                if spc[j] < lowest or (spc[j] == lowest and row4col[j] == -1):
+                    lowest = spc[j]
+                    index = it
+            min_val = lowest
+            assert min_val != inf, "infeasible cost matrix"
+            j = remaining[index]
+            if row4col[j] == -1:
+                sink = j
+            else:
+                i = row4col[j]
+            sc[j] = True
+            num_remaining -= 1
+            remaining[index] = remaining[num_remaining]
+        u[cur] += min_val
+        for i in range(n):
+            if sr[i] and i != cur:
+                u[i] += min_val - spc[col4row[i]]
+        for j in range(n):
+            if sc[j]:
+                v[j] -= min_val - spc[j]
+        j = sink
+        while True:
+            i = path[j]
+            row4col[j] = i
+            col4row[i], j = j, col4row[i]
+            if i == cur:
+                break
+    return tuple(col4row)
+
+
 def pit_perm(pred: np.ndarray, target: np.ndarray, loss: str = "l1") -> Tuple[float, Tuple[int, ...], np.ndarray]:
     """pred, target [..., S] -> (min loss, target_perm, cost[S, S]).
 
     cost[a, b] = mean |pred[..., a] - target[..., b]|  (losses.py:50-71); the reference minimises with
-    scipy's linear_sum_assignment (losses.py:43) -- for S = 3 that equals a brute-force search over
-    the 3! permutations (first minimum in lexicographic order on exact ties)."""
+    scipy's linear_sum_assignment (losses.py:43), restated in ``lsap`` with its tie rules."""
     s = pred.shape[-1]
     cost = np.zeros((s, s), dtype=np.float64)
     for a in range(s):
         for b in range(s):
             d = pred[..., a].astype(np.float64) - target[..., b].astype(np.float64)
             cost[a, b] = np.mean(np.abs(d)) if loss == "l1" else np.mean(d * d)
-    best, best_perm = None, None
-    for perm in itertools.permutations(range(s)):
-        c = sum(cost[a, perm[a]] for a in range(s)) / s
-        if best is None or c < best:
-            best, best_perm = c, perm
-    return float(best), tuple(best_perm), cost
+    perm = lsap(cost)
+    best = sum(cost[a, perm[a]] for a in range(s)) / s
+    return float(best), tuple(perm), cost
 
 
 def dilate(arr: np.ndarray, iters: int) -> np.ndarray:

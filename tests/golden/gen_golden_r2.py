@@ -3,7 +3,7 @@
 gen_golden.py for the rules: the reference is imported in place, nothing of it is copied; only seeds and output
 tensors are written).
 
-    python tests/golden/gen_golden_r2.py       # writes variants_mc.npz, e2e60_mc.npz, e2e60_sc.npz, session_triple.json
+    python tests/golden/gen_golden_r2.py       # writes variants_mc.npz, e2e60_mc.npz, e2e60_sc.npz
 
   variants_mc.npz   the non-default CssCfg branches of css/css.py on a 6.05 s, 4-segment input (ragged tail):
                     normalize_segment_power (css.py:233-247), mc_mask_floor_db -6 / -12 (css.py:222-227), mc_mvdr=False
@@ -13,9 +13,6 @@ tensors are written).
   e2e60_mc.npz      BASELINE.json configs[1] at full size: the 60 s 7-ch meeting through the reference; decisions as
                     SHA-256 (+ the packed winner-take-all map), waveforms decimated and as windows
   e2e60_sc.npz      configs[2] at full size: channel 0 of the same meeting through the single-channel model
-  session_triple.json  css_inference (css.py:51-107) on a synthetic session: the input Series, the files written and
-                    the SHA-256 of every written sample block; soundfile and the checkpoint do not exist
-                    here: soundfile.read / .write are bound to this repo's PCM16 codec, load_css_model to the in-memory model
 """
 from __future__ import annotations
 
@@ -166,67 +163,10 @@ def main():
          "wav_len": len(ws[0])}
     np.savez_compressed(os.path.join(HERE, "e2e60_sc.npz"), **e)
 
-    # ------------------------------------------------------------------ css_inference triple (css.py:51-107)
-    import pandas as pd
-    WIO = __import__("importlib").import_module("notsofar1_challenge_amd.wavio")
-    written = {}
-    # the reference's own load_audio (css/helpers.py:40) and write_wav (utils/audio_utils.py:37) run unchanged; the two
-    # soundfile functions they call are bound to this repo's PCM16 codec (libsndfile: int16 * 2^-15 on read, default
-    # subtype PCM_16 = lrint(x * 32767) on write)
-    import soundfile as SF
-
-    def sf_read(path, dtype="float32"):
-        pcm, sr = WIO.read_wav_pcm16(path)
-        return pcm.astype(np.float32) / np.float32(32768.0), sr
-
-    def sf_write(path, samps, sr):
-        written[str(path)] = (np.asarray(samps).copy(), sr)
-        WIO.write_pcm16_samples(path, np.clip(np.rint(np.asarray(samps, np.float64) * 32767.0), -32768, 32767).astype(np.int16), sr)
-
-    SF.read, SF.write = sf_read, sf_write
-
-    with tempfile.TemporaryDirectory() as td:
-        sess_dir = os.path.join(td, "in")
-        os.makedirs(sess_dir)
-        n = 5 * 16000 + 321
-        pcm16 = np.clip(np.rint(mix60[0, 48000:48000 + n] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)
-        names = []
-        for c in range(7):
-            p = os.path.join(sess_dir, f"ch{c}.wav")
-            WIO.write_pcm16_samples(p, pcm16[:, c], 16000)
-            names.append(p)
-        session = pd.Series({"session_id": "MTG_SYNTH_mc_0", "is_mc": True, "wav_file_names": names, "device_name": "synth"})
-
-        RC.load_css_model = lambda model_dir: (model, None)   # no checkpoint / OmegaConf here: the model is in memory
-        out_dir = os.path.join(td, "out")
-        res = RC.css_inference(out_dir, "unused_models_dir", session, RC.CssCfg(**base, device="cpu"), fetch_from_cache=False)
-        rel = lambda p: os.path.relpath(str(p), out_dir)
-        files = sorted(rel(os.path.join(dp, f)) for dp, _, fs in os.walk(out_dir) for f in fs)
-        triple = {
-            "input": {"session_id": session.session_id, "is_mc": True, "n_samples": n, "mix_seed": 1, "mix_offset": 48000,
-                      "pcm16_gain": 0.05, "n_files": 7},
-            "output_columns": sorted(res.index.tolist()),
-            "sep_wav_file_names": [rel(p) for p in res["sep_wav_file_names"]],
-            "files": files,
-            "pcm16_sha256": {rel(k): sha(np.clip(np.rint(np.asarray(v[0], np.float64) * 32767.0), -32768, 32767).astype(np.int16))
-                             for k, v in written.items()},
-            "float_rms": {rel(k): float(np.sqrt(np.mean(np.asarray(v[0], np.float64) ** 2))) for k, v in written.items()},
-            "lengths": {rel(k): int(len(v[0])) for k, v in written.items()},
-        }
-        # decimated float samples of the separated streams (before PCM16), for a tolerance-based comparison
-        dec = {rel(k): np.asarray(v[0], np.float32)[::64] for k, v in written.items() if "sep_stream" in k}
-        np.savez_compressed(os.path.join(HERE, "session_triple_dec.npz"), **{k.replace("/", "__"): v for k, v in dec.items()})
-        # cache rule (css.py:79-82): second call returns the sorted glob of sep*.wav
-        res2 = RC.css_inference(out_dir, "unused_models_dir", session, RC.CssCfg(**base, device="cpu"), fetch_from_cache=True)
-        triple["cached_sep_wav_file_names"] = [rel(p) for p in res2["sep_wav_file_names"]]
-        res3 = RC.css_inference(out_dir, "unused", session, RC.CssCfg(**base, pass_through_ch0=True), fetch_from_cache=False)
-        triple["pass_through"] = [os.path.basename(p) for p in res3["sep_wav_file_names"]]
-    with open(os.path.join(HERE, "session_triple.json"), "w") as f:
-        json.dump(triple, f, indent=1)
+    # (the css_inference triple moved to gen_golden_r4.py: a longer, full-scale session)
     with open(os.path.join(HERE, "golden_report_r2.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
-    print(json.dumps(triple, indent=1)[:1500])
 
 
 if __name__ == "__main__":

@@ -105,7 +105,7 @@ def test_other_segmentations_vs_reference(L, sep_mc, mix60, golden, seg_hop):
         assert rel_rms(ww[k][keep], g[name + "_wav_windows"][k][keep]) < 1e-4, (name, k, keep)
 
 
-def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden):
+def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden, mc_state):
     """BASELINE.json configs[1] at full size against the reference's own 60 s run: decisions, winner-take-all maps,
     stitched masks, and the waveforms -- free-running where no decision differs, and on the reference's decisions."""
     CSS = pkg("css")
@@ -173,6 +173,35 @@ def test_config2_60s_mc_vs_reference(L, sep_mc, mix60, golden):
     assert stable_t.mean() >= 0.80 and clean_t.mean() >= 0.74, (stable_t.mean(), clean_t.mean())
     for k in range(S):
         assert free_err[k] < 1e-4, k
+    # ---- the frames left out above -- on-cut segments whose decisions moved, the ragged last one -- are held to the ORACLE,
+    # so that no frame of configs[1] goes unchecked: (a) their masks against the oracle's Conformer on the very feature rows
+    # the HIP kernel produced for the segment (the discontinuity sits in the features, not behind them); (b) the whole
+    # meeting's waveforms against the oracle's float64 chain on the HIP masks, reported for exactly the left-out samples
+    params = O.ConformerParams(mc_state[0])
+    left_out = sorted(set(moved + [39]))
+    mask_err = {}
+    for i in left_out:
+        h.begin(pcm, pcm.shape[0], pcm.shape[1], run_cfg)
+        h.stage_stft()
+        h.stage_masknet(i, i + 1)
+        feat = h.read(L.BUF_FEATURES)[:186, :1799]
+        om = O.conformer_forward(params, feat.T, affine_applied=True)
+        hm = h.read(L.BUF_MASKS).reshape(S + 1, F, 40, 186)[:, :, i]
+        assert np.array_equal(hm, m[:, :, i])                      # the segment alone == the segment in the free run
+        mask_err[i] = float(np.abs(hm - om).max())
+        assert mask_err[i] < 1.5e-5, (i, mask_err)
+    hip_masks = [(np.moveaxis(m[:S, :, i], 0, 2), np.moveaxis(m[S:, :, i], 0, 2)) for i in range(40)]
+    ow, oside = O.separate_and_stitch(mix60, None, 16000, O.OracleCssCfg(activity_th=0.3),
+                                      separate_fn=lambda i, seg: hip_masks[i], mvdr_cplx=np.complex128)
+    assert np.array_equal(np.array(oside["perms"]), perms) and np.array_equal(oside["activity_final"][0], act_f)
+    t_out = np.flatnonzero(~clean_t)
+    out_err = [rel_rms(free[k, ::256][t_out], ow[k][::256][t_out]) for k in range(S)]
+    all_err = [rel_rms(free[k, ::256], ow[k][::256]) for k in range(S)]
+    _report("config2_60s_mc_left_out_frames_vs_oracle", {
+        "segments": left_out, "frames": int((~clean_t).sum()), "masks_max_abs_vs_oracle_on_hip_features": mask_err,
+        "waveform_rel_rms_vs_oracle_on_hip_masks_left_out_frames": out_err, "waveform_rel_rms_vs_oracle_on_hip_masks_all_frames": all_err})
+    for k in range(S):
+        assert out_err[k] < 1e-4 and all_err[k] < 1e-4, (k, out_err, all_err)
 
 
 def test_config3_60s_sc_vs_reference(L, sc_state, mix60, golden):
@@ -195,17 +224,20 @@ def test_config3_60s_sc_vs_reference(L, sc_state, mix60, golden):
 
 
 def test_css_inference_against_the_captured_triple(tmp_path, mc_state, mix60):
-    """css_inference (css.py:51-107) on the session the reference was run on: same Series columns, same files, same
-    lengths, the input mixture bit for bit, the separated streams to within a PCM16 step; cache and pass-through rules."""
+    """css_inference (css.py:51-107) on the session the reference was run on (tests/golden/gen_golden_r4.py: 19.4 s of the
+    config-2 meeting at full scale, PCM16 files in, the reference's own load_audio / write_wav around its separate_and_stitch):
+    same Series columns, same files, same lengths, the input mixture bit for bit, and the separated streams -- the product
+    as a consumer sees it, wav in, wav out, free-running -- within ONE PCM16 step on >= 99.9 % of the samples of every
+    stream; cache and pass-through rules."""
     import pandas as pd
     import torch
     import yaml
-    with open(os.path.join(GOLDEN, "session_triple.json")) as f:
+    with open(os.path.join(GOLDEN, "session_triple_r4.json")) as f:
         t = json.load(f)
-    dec = np.load(os.path.join(GOLDEN, "session_triple_dec.npz"))
+    ref16 = np.load(os.path.join(GOLDEN, "session_triple_r4_pcm16.npz"))
     CSS, W = pkg("css"), pkg("wavio")
     n, off, gain = t["input"]["n_samples"], t["input"]["mix_offset"], t["input"]["pcm16_gain"]
-    pcm16 = np.clip(np.rint(mix60[0, off:off + n] * gain * 32768.0), -32768, 32767).astype(np.int16)
+    pcm16 = np.clip(np.rint(mix60[0, off:off + n] * np.float32(gain) * 32768.0), -32768, 32767).astype(np.int16)
     names = []
     for c in range(7):
         p = tmp_path / "in" / f"ch{c}.wav"
@@ -227,23 +259,19 @@ def test_css_inference_against_the_captured_triple(tmp_path, mc_state, mix60):
     assert [rel(p) for p in res["sep_wav_file_names"]] == t["sep_wav_file_names"]
     files = sorted(rel(os.path.join(dp, f)) for dp, _, fs in os.walk(out_dir) for f in fs)
     assert files == t["files"]
+    margins = {}
     for name in files:
         pcm, sr = W.read_wav_pcm16(out_dir / name)
         assert sr == 16000 and len(pcm) == t["lengths"][name]
         if name.endswith("input_mixture.wav"):
             assert sha(pcm.astype(np.int16)) == t["pcm16_sha256"][name]
         else:
-            # every 64th sample of the float stream the reference handed to soundfile.  This is a FREE-RUNNING comparison
-            # on a short, quiet, PCM16-quantised clip whose noise covariances are poorly conditioned: mask differences
-            # of 4e-6 (no winner-take-all flip, identical permutations) move the beamformer output by 3e-3 here
-            # (tools/debug_triple.py: the same HIP masks fed to the oracle reproduce the HIP streams to 1e-6; the two
-            # arithmetic modes differ from each other by as much).  Tight waveform parity is what the injected-decision
-            # tests above establish; this one pins the session contract: files, lengths, scaling, stream order.
-            ref = dec[name.replace("/", "__")].astype(np.float64)
-            got = pcm[::64].astype(np.float64) / 32767.0
-            gain = float(got @ ref / (ref @ ref))
-            assert abs(gain - 1) < 0.02, gain
-            assert rel_rms(got, gain * ref) < 2e-2, name
+            step = np.abs(pcm.astype(np.int64) - ref16[name.replace("/", "__")].astype(np.int64))
+            margins[os.path.basename(name)] = {"equal": round(float((step == 0).mean()), 5), "within_1_lsb": round(float((step <= 1).mean()), 6),
+                                               "max_steps": int(step.max())}
+            assert (step <= 1).mean() >= 0.999, (name, margins)
+    from test_hip_long import _report
+    _report("session_triple_pcm16_steps_vs_reference_files", margins)
     res2 = CSS.css_inference(str(out_dir), str(tmp_path / "models"), session, cfg, fetch_from_cache=True)
     assert [rel(p) for p in res2["sep_wav_file_names"]] == t["cached_sep_wav_file_names"]
     res3 = CSS.css_inference(str(out_dir), "unused", session, CSS.CssCfg(pass_through_ch0=True), fetch_from_cache=False)

@@ -17,7 +17,7 @@ def _toy(torch, S, rotate):
 
         def __init__(self):
             super().__init__()
-            self.calls, self.seen = 0, []
+            self.calls, self.seen, self.ndims = 0, [], []
 
         def stft(self, s):      # conformer_wrapper.py:106-129: 512-point periodic Hann, hop 256, no padding
             x = s if s.ndim == 3 else s[..., None]
@@ -27,6 +27,7 @@ def _toy(torch, S, rotate):
             return X if s.ndim == 3 else X[..., 0]
 
         def separate(self, stft):
+            self.ndims.append(stft.ndim)
             x = stft if stft.ndim == 4 else stft[..., None]
             mag = x[..., 0].abs()                                     # [1, F, T]
             F, T = mag.shape[1], mag.shape[2]
@@ -59,6 +60,7 @@ def test_foreign_separator_masks_through_the_hip_stages(channels, rotate):
     wavs, side = CSS.separate_and_stitch(mix, toy, 16000, "cuda:0", cfg)
     nseg = toy.calls
     assert nseg == len(toy.seen) and nseg >= 8 and len(wavs) == 3
+    assert set(toy.ndims) == {4}                                # [1, F, T, C] as css.py:199 passes it, C == 1 included
     ow, oside = O.separate_and_stitch(mix, None, 16000, O.OracleCssCfg(activity_th=0.45),
                                       separate_fn=lambda i, seg: toy.seen[i], mvdr_cplx=np.complex128)
     assert side['segment_frames'] == 186

@@ -169,11 +169,11 @@ def test_config3_60s_sc_vs_reference(sc_state, mix60, golden):
 def test_wav_codec_against_the_session_triple(tmp_path, mix60):
     """The reference's load_audio / write_wav ran over this codec when the triple was made: the input mixture it wrote
     (peak-normalised by ITS arithmetic, utils/audio_utils.py:44-45) must be what wavio.write_wav writes."""
-    with open(os.path.join(GOLDEN, "session_triple.json")) as f:
+    with open(os.path.join(GOLDEN, "session_triple_r4.json")) as f:
         t = json.load(f)
     W = pkg("wavio")
     n, off, gain = t["input"]["n_samples"], t["input"]["mix_offset"], t["input"]["pcm16_gain"]
-    pcm16 = np.clip(np.rint(mix60[0, off:off + n] * gain * 32768.0), -32768, 32767).astype(np.int16)
+    pcm16 = np.clip(np.rint(mix60[0, off:off + n] * np.float32(gain) * 32768.0), -32768, 32767).astype(np.int16)
     names = []
     for c in range(7):
         p = tmp_path / f"ch{c}.wav"
