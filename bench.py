@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--no-long", action="store_true", help="N = 1: skip the 30-min meeting")
     ap.add_argument("--lanes", type=int, default=0, help="kernel chains per mask-estimator batch (0 = the library's default)")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
-                    help="css_set_tuning options of the handle (A/B runs), e.g. --tune gemm_ws=1")
+                    help="css_set_tuning options of the handle (A/B runs), e.g. --tune tail_pieces=2")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

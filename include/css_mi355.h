@@ -197,9 +197,7 @@ enum css_tuning {
     CSS_TUNE_TAIL_PER_UNIT = 2, /* 1: stitch / synthesise after every lane's unit; 0 (default): once per batch             */
     CSS_TUNE_MVDR_ON_LANES = 3, /* 1 (default): covariances / MVDR / stitching costs at the end of each lane's chain; 0: after  */
     CSS_TUNE_PIPELINE_DEVICE = 4, /* 1: css_run_device also takes the unit pipeline; 0 (default): the plain stage sequence    */
-    CSS_TUNE_GEMM_WS = 5,       /* Linear layers whose launch is one round of 128 x 128 tiles: 1 = the specialised-wave LDS-DMA kernel
-                                 * (gemm_split_dma.hip), 2 = for every eligible launch; 0 (default): the 64-row weights-direct kernel. Same bits. */
-    CSS_TUNE_COUNT = 6
+    CSS_TUNE_COUNT = 5
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

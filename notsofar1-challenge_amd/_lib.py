@@ -311,9 +311,9 @@ class Handle:
         check(self.h, self.lib.css_set_lanes(self.h, int(lanes)))
 
     def set_tuning(self, which, value: int):
-        """which: "tail_pieces" | "out_mapped" | "tail_per_unit" (include/css_mi355.h css_tuning)"""
-        idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2, "mvdr_on_lanes": 3, "pipeline_device": 4,
-               "gemm_ws": 5}[which] if isinstance(which, str) else int(which)
+        """which: "tail_pieces" | "out_mapped" | "tail_per_unit" | "mvdr_on_lanes" | "pipeline_device" (include/css_mi355.h css_tuning)"""
+        idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2, "mvdr_on_lanes": 3,
+               "pipeline_device": 4}[which] if isinstance(which, str) else int(which)
         check(self.h, self.lib.css_set_tuning(self.h, idx, int(value)))
 
     def lanes(self) -> int:

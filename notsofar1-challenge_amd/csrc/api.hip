@@ -115,7 +115,7 @@ struct css_ctx {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -825,7 +825,6 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
                    int act, int split_out) {
         GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
         g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
-        g.allow_ws = h->tune[CSS_TUNE_GEMM_WS];
         g.range_flag = sp ? h->range_flag_dev : nullptr;
         return g;
     };
@@ -998,16 +997,20 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
 }
 
 // make_mvdr + mask floor / multiply (+ power normalisation) for segments [lo, hi) on `st`
-static void mvdr_on(css_ctx* h, int64_t seg_lo, int64_t seg_hi, hipStream_t st) {
-    if (seg_hi <= seg_lo) return;
+static int mvdr_on(css_ctx* h, int64_t seg_lo, int64_t seg_hi, hipStream_t st) {
+    if (seg_hi <= seg_lo) return CSS_OK;
     MvdrArgs a = mvdr_args(h, seg_lo, (int)(seg_hi - seg_lo));
     if (a.use_mvdr) {
-        { CSS_PROF(CSS_PROF_SCM, st); launch_scm(a, st); }
+        {
+            CSS_PROF(CSS_PROF_SCM, st);
+            if (!launch_scm(a, st)) return fail(h, CSS_ERR_HIP, "the covariance kernel's LDS could not be reserved");
+        }
         { CSS_PROF(CSS_PROF_MVDR_SOLVE, st); launch_mvdr_solve(a, st); }
     }
     CSS_PROF(CSS_PROF_BEAMFORM, st);
     launch_beamform(a, st);
     if (h->cfg.normalize_segment_power) launch_segment_power_norm(a, (double*)h->pnorm.p, st);
+    return CSS_OK;
 }
 
 int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
@@ -1015,7 +1018,7 @@ int css_stage_mvdr(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     if (rc) return rc;
     if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
-    mvdr_on(h, seg_lo, seg_hi, h->stream);
+    if ((rc = mvdr_on(h, seg_lo, seg_hi, h->stream)) != CSS_OK) return rc;
     hipEventRecord(h->ev[4], h->stream);
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -1415,7 +1418,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         struct { int64_t seg_lo; int64_t n; } u{units[k0].seg_lo, units[k1 - 1].seg_lo + units[k1 - 1].n - units[k0].seg_lo};
         const int64_t b_lo = std::max<int64_t>(u.seg_lo - 1, 0), b_hi = u.seg_lo + u.n - 1;
         if (!h->tune[CSS_TUNE_MVDR_ON_LANES]) {   // beamformer and costs here, after the lanes, instead of on them
-            mvdr_on(h, u.seg_lo, u.seg_lo + u.n, ts);
+            if (int e = mvdr_on(h, u.seg_lo, u.seg_lo + u.n, ts)) return e;
             pit_costs_on(h, b_lo, b_hi, ts);
         }
         // (the boundaries' costs were computed on the lanes, behind each unit's beamformer)
@@ -1502,7 +1505,8 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         for (size_t k = first; k < ui; ++k)
             if (units[k].seg_lo == seg_lo && units[k].n == cnt) u = &units[k];
         if (!u) return fail(h, CSS_ERR_STATE, "internal: unit schedule out of step");
-        if (h->tune[CSS_TUNE_MVDR_ON_LANES]) mvdr_on(h, seg_lo, seg_lo + cnt, st);
+        if (h->tune[CSS_TUNE_MVDR_ON_LANES])
+            if (int e = mvdr_on(h, seg_lo, seg_lo + cnt, st)) return e;
         HIPCHK(h, hipEventRecord(u->v, st));
         // raw stitching costs of this unit's boundaries (losses.py:50-71); the first one joins the previous unit's last
         // segment, whose masks / separated spectra are final once that unit's beamformer is

@@ -286,17 +286,12 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     if (g_in.M <= 0 || g_in.N <= 0) return;
     const GemmArgs& g = g_in;
     const int tiles_m = (g.M + WD_BM - 1) / WD_BM, tiles_n = (g.N + BN - 1) / BN;
-    const int pick = g.tile_rows;
-    // 128 x 128 tiles through LDS DMA with specialised waves (gemm_split_dma.hip): same bits; tile_rows = 3 asks for it,
-    // the automatic choice follows gemm_split_ws_pays() (which is "never" today: see that function)
-    if (pick == 33 && gemm_split_wsp_eligible(g)) return launch_gemm_split_dma(g, s);   // ... persistent over the tiles
-    if ((pick == 3 || pick == 33 || (!pick && gemm_split_ws_pays(g))) && gemm_split_ws_eligible(g)) {
-        GemmArgs q = g;
-        q.tile_rows = 3;
-        return launch_gemm_split_dma(q, s);
-    }
+    int pick = g.tile_rows;
     // (buffer loads -- BUF = true -- measured 1-6 % ahead of 64-bit global loads on every shape of the path, same bits;
-    // tile_rows = 65 keeps the global-load form of the 64-row kernel for A/B timing: tools/gemm_dma_bench.hip)
+    // tile_rows = 65 is the global-load form of the 64-row kernel: A/B timing, and the operands a 32-bit buffer offset
+    // cannot address -- an activation or weight extent of 2 GiB and more, i.e. M * lda beyond 2^29 floats)
+    const int64_t a_bytes = (int64_t)g.M * g.lda * (int64_t)sizeof(float), w_bytes = (int64_t)((g.N + 31) / 32 * 32) * g.K * (int64_t)sizeof(float);
+    if (a_bytes >= (int64_t)1 << 31 || w_bytes >= (int64_t)1 << 31) pick = 65;
     if (pick == 32) {
         const int tm32 = (g.M + 31) / 32;
         hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1, true>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);
@@ -308,7 +303,7 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     } else if (pick == 65) {
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, false>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
-    } else if (pick == 64 || pick == 3 || pick == 33 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
+    } else if (pick == 64 || !pick) {   // best or equal on every shape of the path, alone or beside another launch (tools/gemm_tile_bench.hip)
         const int tm64 = (g.M + 63) / 64;
         hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
     } else {

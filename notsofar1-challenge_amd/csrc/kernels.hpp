@@ -36,14 +36,13 @@ struct GemmArgs {
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
     int nt_store;   // epilogue stores bypass the caches (nontemporal)
-    int allow_ws;   // css_set_tuning(CSS_TUNE_GEMM_WS): the automatic choice may take gemm_split_dma.hip's specialised-wave kernel
     // weights-direct kernel only: columns n < 2 * frag_D (the q and k projections of the attention, D = heads * 64) leave
     // in the attention kernel's operand order instead of row-major C (encoder.hip qk fragment layout); rows are tokens
     // of segments of frag_T frames, frag_invT = 1.0f / frag_T
     float* frag_out;
     int frag_D, frag_T, frag_heads;
     float frag_invT;
-    int tile_rows;         // weights-direct kernel: 0 = choose, else 64 / 96 / 128 (8 waves) / 4 (128 rows, 4 waves) / 3 (gemm_split_dma.hip)
+    int tile_rows;         // weights-direct kernel: 0 = choose, else 32 / 64 / 96 / 128 (8 waves) / 4 (128 rows, 4 waves) / 65 (64 rows, 64-bit global loads)
     int narrow_epilogue;   // tools: keep the 4-byte-per-lane epilogue of the weights-direct kernel (A/B timing)
     // split kernels: *range_flag |= 1 when a finished accumulator is not finite -- an operand left the split-f16 range
     // (split_f16.hpp: nothing is clamped); checked here, in the consumer, because a ReLU downstream would launder a NaN
@@ -53,10 +52,6 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
 void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s);  // gemm_split_wd.hip (g.b_tiled)
-void launch_gemm_split_dma(const GemmArgs& g, hipStream_t s);  // gemm_split_dma.hip (g.b_tiled; both operands via LDS DMA)
-bool gemm_split_ws_eligible(const GemmArgs& g);                // ... whether its specialised-wave kernel can take the launch
-bool gemm_split_wsp_eligible(const GemmArgs& g);               // ... its persistent form (tile_rows = 33)
-bool gemm_split_ws_pays(const GemmArgs& g);                    // ... and whether it is the faster choice at this shape
 // float32 W [N][K] (row stride ld_src, K % 32 == 0) -> tile-major split-f16 weights, (N rounded up to 32) * K floats
 void launch_split_convert_tiled(const float* src, int64_t ld_src, float* dst, int N, int K, hipStream_t s);
 // float32 [rows][K] (row stride ld_src) -> split-f16 [rows][Kp] (Kp % 32 == 0, zero padded past K)
@@ -179,7 +174,7 @@ struct MvdrArgs {
     float mask_floor;
     int use_mvdr;
 };
-void launch_scm(const MvdrArgs& a, hipStream_t s);
+bool launch_scm(const MvdrArgs& a, hipStream_t s);   // false: the LDS of a long-segment launch could not be reserved
 void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s);
 void launch_beamform(const MvdrArgs& a, hipStream_t s);
 // optional power normalisation (css.py:233-247): scales sep of each segment in place

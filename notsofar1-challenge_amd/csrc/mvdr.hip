@@ -232,20 +232,21 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     }
 }
 
-void launch_scm(const MvdrArgs& a, hipStream_t s) {
+bool launch_scm(const MvdrArgs& a, hipStream_t s) {
     // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 98 doubles
     const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * 2 * NPACK * 2) * sizeof(float);
     const dim3 grid((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), block(64 * SCM_WAVES);
     if (a.T <= 256) {
         hipLaunchKernelGGL(scm_kernel<4>, grid, block, per_wave * SCM_WAVES, s, a);
     } else {   // up to 8 s segments: 82 KB of LDS per block
-        static bool raised = false;
-        if (!raised) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
-        }
+        // (the attribute is per device: set on every launch -- a host-side table lookup -- not behind a process-wide flag
+        // that a second device, or a second thread's first launch, would miss; stft.hip does the same)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(scm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(per_wave * SCM_WAVES)) != hipSuccess)
+            return false;
         hipLaunchKernelGGL(scm_kernel<8>, grid, block, per_wave * SCM_WAVES, s, a);
     }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------

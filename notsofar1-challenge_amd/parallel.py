@@ -37,6 +37,8 @@ from typing import List
 
 import numpy as np
 
+from . import _lib
+
 
 @dataclasses.dataclass
 class ShardPlan:
@@ -411,7 +413,9 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
 
     check_range=True (default) ends with backend.check_range(): one host synchronisation, after which a Linear-layer
     operand that left the split-f16 range (split_f16.hpp) raises CssError(CSS_ERR_RANGE) instead of returning NaN
-    waveforms (repeat the session after handle.set_linear_mode("exact_f32")).  check_range=False keeps the call
+    waveforms (repeat the session after handle.set_linear_mode("exact_f32")).  With world > 1 the verdict is agreed on
+    by all ranks (one all-reduce of a flag): every rank raises when any rank overflowed, none leaves the collective
+    sequence.  check_range=False keeps the call
     asynchronous on the backend's stream: the CALLER then checks once it has synchronised (bench.py does, at its barrier).
     trace: optional callable(label), called on the host between the phases (bench.py records an event on the stream)."""
     assert gather in ("all", "range"), gather
@@ -420,8 +424,29 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
     mark = trace if trace is not None else (lambda label: None)
 
     def finish(result):
-        if check_range and hasattr(backend, "check_range"):
+        if not (check_range and hasattr(backend, "check_range")):
+            return result
+        # The verdict is COLLECTIVE: a rank whose own segments overflowed has already sent NaN costs (and, with
+        # gather="all", its NaN shard) to every other rank, so all ranks must raise -- and all must stay in the same
+        # collective sequence for the next session.  Every rank reads its own flag, the ranks agree on the maximum.
+        mine, err = 0, None
+        try:
             backend.check_range()
+        except _lib.CssError as e:
+            if e.code != _lib.CSS_ERR_RANGE:
+                raise
+            mine, err = 1, e
+        if world > 1:
+            import torch
+            dev = comm_dev if comm_dev is not None else getattr(backend, "dev", "cpu")
+            flag = torch.tensor([mine], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and err is None:
+                err = _lib.CssError(_lib.CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range on another rank "
+                                                        "of this sharded session (its costs / shard reached this rank): "
+                                                        "repeat the session after set_linear_mode('exact_f32')")
+        if err is not None:
+            raise err
         return result
 
     with ss._ctx():

@@ -10,7 +10,7 @@ from conftest import pkg
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128, 3, 33)),   # 3 / 33: 128 x 128 tiles by LDS DMA, specialised waves (33: persistent)
+KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128, 65)),   # 65: the 64-row tile on 64-bit global loads (operands of 2 GiB and more)
            1: ("split-f16, LDS staged", (0, 8, 4, 64)),
            2: ("exact float32", (0, 8, 4, 64))}
 

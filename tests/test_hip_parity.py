@@ -532,7 +532,7 @@ def test_other_model_widths_vs_oracle(L, mix_stage, dims):
         sep.close()
 
 
-@pytest.mark.parametrize("frames", [2, 8, 24, 32, 33, 48, 64, 65, 97, 256])
+@pytest.mark.parametrize("frames", [2, 8, 24, 32, 33, 48, 64, 65, 97, 256, 371, 499])
 def test_short_and_odd_segment_lengths_vs_oracle(L, mix60, frames):
     """Every tile schedule of the attention kernel (one instantiation per ceil(T / 32); T <= 32 has a two-tile position
     prologue), the conv module's short runs and the GEMM tails at clip lengths the 3 s / 4 s configurations never reach:
@@ -560,5 +560,55 @@ def test_short_and_odd_segment_lengths_vs_oracle(L, mix60, frames):
             om = O.conformer_forward(params, O.features(O.stft(clips[b])))                # [4, F, frames]
             for mode, m in got.items():
                 assert np.abs(np.moveaxis(m[b], 2, 0) - om).max() < 5e-5, (frames, mode, b)
+    finally:
+        sep.close()
+
+
+def test_eight_second_segments_dense_hop_vs_oracle(L, CSS, mix60):
+    """segments of 371 .. 512 frames take kernels no fixture reached against an expected value -- the covariance
+    kernel's 82 KB LDS launch (scm_kernel<8>), features_kernel<512>, the attention's 11 .. 16 key tiles.  8 s segments (499
+    frames) every second (eight segments over a frame: the general overlap-add loops) on a 21 s recording, a 2-block
+    model: masks of the first and the ragged last segment against the oracle's features + Conformer, decisions exact,
+    covariances and beamformer weights of a segment against the oracle on the HIP masks, waveforms <= 1e-4 against the
+    oracle's float64 chain on the HIP masks."""
+    w = pkg("weights")
+    desc = w.ModelDesc(num_blocks=2)
+    st = w.apply_golden_recipe(w.portable_state_dict(desc, 23))
+    params = O.ConformerParams(st)
+    mix = np.ascontiguousarray(mix60[:, 8000:8000 + 21 * 16000 + 77])
+    cfg, ocfg = cfgs(CSS, segment_size_sec=8.0, hop_size_sec=1.0)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=5)
+    try:
+        wavs, side = CSS.separate_and_stitch(mix, sep, 16000, "cuda:0", cfg)
+        h = sep.handle
+        plan = h.get_plan()
+        nseg, Ts = int(plan.num_segments), 499
+        assert side["segment_frames"] == Ts and nseg >= 12
+        m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, Ts)
+        X = O.stft(mix[0])
+        for i in (0, nseg - 1):
+            seg = np.zeros((F, Ts, 7), np.complex64)
+            part = X[:, i * 62:i * 62 + Ts]
+            seg[:, :part.shape[1]] = part
+            om = O.conformer_forward(params, O.features(seg))
+            assert np.abs(m[:, :, i] - om).max() < 5e-5, i
+        hip_masks = [(np.moveaxis(m[:S, :, i], 0, 2), np.moveaxis(m[S:, :, i], 0, 2)) for i in range(nseg)]
+        taps = {}
+        ow, oside = O.separate_and_stitch(mix, params, 16000, ocfg, separate_fn=lambda i, seg: hip_masks[i],
+                                          mvdr_cplx=np.complex128, taps=taps)
+        assert oside["plan"].hop_frames == 62 and oside["plan"].num_segments == nseg
+        assert np.array_equal(h.read(L.BUF_PERMS), np.array(oside["perms"]))
+        assert np.array_equal(side["activity_final"].numpy(), oside["activity_final"])
+        # covariances (scm_kernel<8>) and beamformer weights of segment 1: [S + 1][F][7 real diagonal + 21 complex] / [S][F][7]
+        scm = h.read(L.BUF_SCM)[1]
+        o_scm = taps["mvdr1"]["scm"]                                  # [4, F, 7, 7] complex128
+        iu = np.triu_indices(7, 1)
+        packed = np.concatenate([np.real(np.diagonal(o_scm, axis1=2, axis2=3)),
+                                 np.stack([o_scm[:, :, iu[0], iu[1]].real, o_scm[:, :, iu[0], iu[1]].imag], -1).reshape(4, F, 42)], -1)
+        assert rel_rms(scm, packed) < 5e-6
+        bfw = h.read(L.BUF_BFW)[1].reshape(S, F, 7, 2)
+        assert rel_rms(bfw[..., 0] + 1j * bfw[..., 1], taps["mvdr1"]["w"]) < 1e-4
+        for k in range(S):
+            assert rel_rms(wavs[k], ow[k]) < 1e-4, k
     finally:
         sep.close()

@@ -161,6 +161,51 @@ def test_sharded_driver_over_gloo_matches_single_rank(tmp_path, world):
     assert edge == single.shape[1]
 
 
+def _range_worker(rank, world, port, out_dir, n_samples):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, HERE)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_backend import OracleStageBackend
+        par, lib = pkg("parallel"), pkg("_lib")
+        st, desc = _small_model()
+        mix = pkg("synth").synth_meeting(10.0, 7, seed=4)[:, :n_samples]
+
+        class Overflowing(OracleStageBackend):
+            """rank 1 alone reports a split-f16 range overflow, as css_check_range would"""
+            def check_range(self):
+                if rank == 1:
+                    raise lib.CssError(lib.CSS_ERR_RANGE, "range")
+
+        be = Overflowing(O.ConformerParams(st), O.OracleCssCfg(activity_th=0.3))
+        verdicts = []
+        for _ in range(2):          # twice: a rank that raised alone would have left the collective sequence
+            be.begin(mix[0], mix.shape[1], 7)
+            try:
+                par.sharded_separate_and_stitch(be, 3, 186, 93, 256, rank, world, dist, gather="range")
+                verdicts.append(0)
+            except lib.CssError as e:
+                verdicts.append(e.code)
+        np.save(os.path.join(out_dir, f"verdict_r{rank}.npy"), np.array(verdicts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_range_verdict_is_collective(tmp_path):
+    """ADVICE r3: with world > 1 a rank whose segments left the split-f16 range has already sent NaN costs to the others;
+    every rank must raise CSS_ERR_RANGE, and none may drop out of the collective sequence (the next session still runs)."""
+    lib = pkg("_lib")
+    world, n = 2, 5 * 16000
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_range_worker, args=(world, port, str(tmp_path), n), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f"verdict_r{r}.npy").tolist() == [lib.CSS_ERR_RANGE, lib.CSS_ERR_RANGE], r
+
+
 def test_upload_schedule_covers_the_ranks_segments_and_samples():
     """parallel.upload_schedule: the groups tile [seg_lo, seg_hi) in order, every group's last sample is inside the piece
     that ends at its cut, the cuts ascend inside the rank's sample range, no crumbs at the end."""

@@ -2,7 +2,7 @@
 """Per-shape launch times of the Linear-layer GEMMs INSIDE the mask estimator, from a rocprofv3 kernel trace of a
 single-lane run (the launches of a Conformer block come in a fixed order: ffn-up, ffn-down, qkv, attn-out, ffn-up,
 ffn-down; the first GEMM of a pass is the embed layer, the last the mask head).
-    rocprofv3 --kernel-trace --output-format csv -d DIR -o p -- python bench.py --lanes 1 --steps 3 --warmup 1 --no-long --no-cpu-baseline [--tune gemm_ws=1]
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o p -- python bench.py --lanes 1 --steps 3 --warmup 1 --no-long --no-cpu-baseline
     python tools/gemm_in_situ.py DIR/**/p_kernel_trace.csv"""
 import sys
 

@@ -26,6 +26,7 @@
 #include <algorithm>
 
 #include "gemm_common.hpp"
+#include "gemm_split_dma.hpp"
 
 namespace css {
 
@@ -870,26 +871,8 @@ bool gemm_split_ws_eligible(const GemmArgs& g) {
            (g.split_out == 0 || g.split_out % 128 == 0 || g.split_out >= g.N);
 }
 
-// Launch-shape rule of the automatic choice (launch_gemm_split_wd).  The kernel holds a CU per block, so it can only pay
-// when a launch is ONE round of 128 x 128 tiles that fills most CUs, or when the K loop is long enough to carry further
-// rounds.  Measured (round 3): alone, with L2-warm operands (tools/gemm_dma_bench.hip), M = 7440 x {512 x 512, 512 x 1024,
-// 512 x 1824} run 5 / 9 / 10 % faster than the 64-row weights-direct kernel (K loop 0.50 against 0.63 us per slab) and
-// N >= 1024 launches 8 % slower (one block per CU: the rounds' epilogues and prologues do not overlap); INSIDE the mask
-// estimator, where every operand was just written by the previous kernel, the same launches take 27.5 us against 27.1
-// (kernel trace, 10 285 launches) and the pass is unchanged (A/B on one box: 3.99 against 3.96 ms of GEMM time) -- one
-// block per CU hides the cold first touches worse than two independent 64-row blocks do.  So the automatic choice is
-// off by default (css_set_tuning(h, CSS_TUNE_GEMM_WS, 1) turns the shape rule below on, 2 takes every eligible launch);
-// tile_rows = 3 selects the kernel directly (tests, tools).
 // ... and the persistent form (tile_rows = 33): 16 slabs per tile, one epilogue chunk per slab
 bool gemm_split_wsp_eligible(const GemmArgs& g) { return gemm_split_ws_eligible(g) && g.K >= 512; }
-
-bool gemm_split_ws_pays(const GemmArgs& g) {
-    if (!g.allow_ws || g.concurrent) return false;
-    if (g.allow_ws == 2) return true;
-    const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (g.allow_ws == 3) return g.N <= 512 && g.K >= 1024 && tiles >= 192;   // only the long-K launches (ffn-down, embed)
-    return g.N <= 512 && tiles >= 192 && (tiles <= 256 || g.K >= 1024);
-}
 
 // g.tile_rows selects the variant (tools / tests): 3 = specialised waves (gemm_split_ws_kernel, three slab buffers);
 // 24 = gemm_split_dma_kernel (2 x 4 waves, 3 slab buffers; the 4 x 2 and two-buffer forms measured the same and are gone)
