@@ -19,7 +19,7 @@ __host__ __device__ inline void lsap_small(const double c[SMAX][SMAX], int n, in
         for (int it = 0; it < n; ++it) { remaining[it] = n - it - 1; sr[it] = false; sc[it] = false; spc[it] = inf; }
         double min_val = 0.0;
         int i = cur, sink = -1;
-        while (sink == -1) {
+        for (int step = 0; step < n && sink == -1; ++step) {   // (every step retires one column: at most n)
             int index = -1;
             double lowest = inf;
             sr[i] = true;
@@ -30,7 +30,7 @@ __host__ __device__ inline void lsap_small(const double c[SMAX][SMAX], int n, in
                 if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
             }
             min_val = lowest;
-            if (index < 0) {   // non-finite costs (scipy raises): keep the rows' own columns
+            if (index < 0 || !(lowest < inf)) {   // non-finite costs ("infeasible": scipy raises): keep the rows' own columns
                 for (int k = 0; k < n; ++k) col4row[k] = k;
                 return;
             }
@@ -40,13 +40,17 @@ __host__ __device__ inline void lsap_small(const double c[SMAX][SMAX], int n, in
             sc[j] = true;
             remaining[index] = remaining[--num_remaining];
         }
+        if (sink == -1) {   // cannot happen with finite costs; never loop on the device
+            for (int k = 0; k < n; ++k) col4row[k] = k;
+            return;
+        }
         u[cur] += min_val;
         for (int k = 0; k < n; ++k)
             if (sr[k] && k != cur) u[k] += min_val - spc[col4row[k]];
         for (int k = 0; k < n; ++k)
             if (sc[k]) v[k] -= min_val - spc[k];
         int j = sink;
-        while (true) {
+        for (int step = 0; step < n; ++step) {   // (the alternating path back to `cur` visits a row at most once)
             const int r = path[j];
             row4col[j] = r;
             const int t = col4row[r]; col4row[r] = j; j = t;

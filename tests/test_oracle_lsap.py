@@ -74,3 +74,15 @@ def test_pit_wrapper_known_answer():
     p = (3, 0, 2, 1)
     loss, perm, _ = O.pit_perm(t[..., p], t, "mse")
     assert loss == 0.0 and perm == p
+
+
+def test_non_finite_costs_terminate():
+    """a pass that left the split-f16 range hands NaN costs to the scan before the float32 repeat: scipy raises on such a
+    matrix ("infeasible"); the library's scan must terminate (it keeps the identity) -- on the device a loop here hangs the GPU"""
+    L = pkg("_lib")
+    for bad in (np.nan, np.inf, -np.inf):
+        costs = np.full((3, 3, 3), bad)
+        costs[1] = np.random.RandomState(0).rand(3, 3)
+        costs[2, 0, 0] = 1.0
+        perms = L.pit_scan(costs, 3)
+        assert perms.shape == (4, 3) and all(sorted(p) == [0, 1, 2] for p in perms.tolist())
