@@ -232,6 +232,18 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
  * returns CSS_ERR_RANGE instead. */
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     float* wav_host, int64_t cap);
+/* Queued sessions SHARE mask-estimator batches (round 4).  Segments are independent through the network
+ * (css/css.py:182-250 carries no state between them) and every kernel of it is batch invariant, so css_run_enqueue merges
+ * the segments of consecutive queued sessions -- same segmentation and windows, page-locked output -- into one
+ * [segments x T, .] problem for as long as they fit max_batch_segments (three 60 s meetings at the bench's 128): every
+ * Linear-layer launch then has M >= 22 k rows instead of 7 k.  Everything outside the estimator stays per session; each
+ * session's result is bit for bit its css_run result (tests/test_hip_schedules.py).  A session is accepted (arguments
+ * checked, CSS_ERR_* returned at once) and may be held back until its group is full, a session that cannot join arrives, or
+ * css_wait / any other call on the handle: LIFETIME -- pcm_host, wav_host AND the recording they describe must stay
+ * valid and untouched from css_run_enqueue until css_wait returns, for every session queued in between (css_wait may
+ * also re-read them: range rule above); cfg and its windows are copied at the call.
+ * css_set_queue_group(h, n): at most n sessions per estimator batch (1 .. 8, default 8; 1 = every session its own pass). */
+int css_set_queue_group(css_handle_t h, int max_sessions);
 /* Blocks until every pass queued on h has finished (results in their wav_host buffers); CssTimings describe the last. */
 int css_wait(css_handle_t h);
 /* Same with input and output resident in HBM (pcm_dev [n_samples][n_ch], wav_dev [S][n_out]). */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "css_set_lanes": (C.c_int, [_P, C.c_int]),
     "css_get_lanes": (C.c_int, [_P]),
     "css_set_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
+    "css_set_queue_group": (C.c_int, [_P, C.c_int]),
     "css_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "css_host_free": (C.c_int, [_P]),
     "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
@@ -315,6 +316,10 @@ class Handle:
         idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2, "mvdr_on_lanes": 3,
                "pipeline_device": 4}[which] if isinstance(which, str) else int(which)
         check(self.h, self.lib.css_set_tuning(self.h, idx, int(value)))
+
+    def set_queue_group(self, max_sessions: int):
+        """queued sessions (run_enqueue) merged into one mask-estimator batch: at most `max_sessions` (1 = none)"""
+        check(self.h, self.lib.css_set_queue_group(self.h, int(max_sessions)))
 
     def lanes(self) -> int:
         return int(self.lib.css_get_lanes(self.h))

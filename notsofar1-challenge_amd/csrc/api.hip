@@ -54,7 +54,28 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
-struct css_ctx {
+// What belongs to ONE session (recording) on a handle: its plan, its configuration and the device buffers the stages
+// after the mask estimator work on.  The handle IS a SessState (the session the stage entry points see); a group of
+// queued sessions that shares one estimator batch (run_group) parks the others in css_ctx::slots and swaps them in one
+// at a time, so every stage helper keeps addressing `h->X`, `h->plan` ... unchanged.
+struct SessState {
+    bool has_session = false;
+    CssRunCfg cfg{};
+    CssPlan plan{};
+    int n_ch = 0;
+    int64_t n_pad = 0, T_ld = 0;
+    bool stft_done = false, perms_done = false, have_override = false;
+    std::vector<float> w_host;   // segment weights of the session (cfg.w_* point into it)
+    DevBuf pcm_cm, X, scm, bfw, sep, costs, perms, mask_st, activity, act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, pit_part;
+    const float* pcm_src = nullptr;       // sample-major PCM on the device for the current session
+    unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
+    // the session's masks [(S+1)F][mask_ld], segment s at column s*T: the handle's mask buffer, or -- inside a group -- this
+    // session's columns of the group's buffer (the mask head of the shared estimator batch writes all of them at once)
+    float* masks_v = nullptr;
+    int64_t mask_ld_v = 0;
+};
+
+struct css_ctx : SessState {
     CssModelDesc d{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -74,16 +95,13 @@ struct css_ctx {
     float* stft_tab = nullptr;   // window and twiddles of the analysis FFT (stft.hip)
     float* dft_inv_t = nullptr;  // [frame_len][KIp]
 
-    // session
-    bool has_session = false;
-    CssRunCfg cfg{};
-    CssPlan plan{};
-    int n_ch = 0;
-    int64_t n_pad = 0, T_ld = 0;
-    bool stft_done = false, perms_done = false, have_override = false;
-    std::vector<float> w_host, w_on_device;   // segment weights of the session / what segw holds (uploaded when they change)
-    DevBuf pcm_in, pcm_cm, X, feat, hx, hu, ht, qkv, qkf, ctxb, masks, scm, bfw, sep, costs, perms, mask_st, activity,
-        act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, segw, stage, pit_part, in16, pcm_f, enc, level, mel_tab, mel_work;
+    // shared by the sessions of a handle: upload staging, the estimator's activations, the mask buffer, small tables
+    std::vector<float> w_on_device;   // what segw holds (uploaded when a session's windows differ)
+    DevBuf pcm_in, feat, hx, hu, ht, qkv, qkf, ctxb, masks, segw, stage, in16, pcm_f, enc, level, mel_tab, mel_work;
+    // sessions of a queued group other than the active one (run_group)
+    static constexpr int MAX_GROUP = 8;
+    std::vector<SessState> slots;
+    int group_limit = MAX_GROUP;      // css_set_queue_group: sessions merged into one estimator batch (1: none)
     // Second lane of the mask estimator: segments are independent through the whole network, so a batch is cut in `lanes`
     // parts that run as independent chains of kernels on as many streams.  One chain alone leaves the GPU idle in every
     // launch's prologue and epilogue (its waves are parked 51 % of the time, profiles/); two or three chains drift out of
@@ -96,14 +114,12 @@ struct css_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     DevBuf lfeat[MAX_LANES], lhx[MAX_LANES], lhu[MAX_LANES], lht[MAX_LANES], lqkv[MAX_LANES], lqkf[MAX_LANES], lctx[MAX_LANES];   // [0] unused
     int64_t last_batch_tokens = 0;
-    const float* pcm_src = nullptr;  // sample-major PCM on the device for the current session
     // PCIe pieces of css_run* travel on their own stream, beside the kernels: the upload of the samples a lane's segments
     // read is followed by that lane's analysis transform and mask-estimator chain while the next piece is in flight, and
     // finished ranges of the output leave while the last ranges are still being synthesised.
     // range check of the split-f16 operand format (split_f16.hpp): a device word set when the stitched activity or the
     // waveforms hold a non-finite value, mirrored into page-locked host memory at the end of every pass
     int mel_bands = 0;                    // the filterbank mel_tab holds (0: none yet)
-    unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
     unsigned int* range_flag_dev = nullptr;
     unsigned int* range_flag_host = nullptr;
     bool range_fallback = true;      // repeat such a pass on the exact float32 kernels (else: CSS_ERR_RANGE)
@@ -137,6 +153,12 @@ struct css_ctx {
     // them on the exact float32 kernels (the caller keeps pcm_host valid and wav_host untouched until css_wait anyway)
     struct QueuedPass { const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; float* wav; int64_t cap; };
     std::vector<QueuedPass> queue_log;
+    // css_run_enqueue: sessions accepted and not yet on the streams -- they wait for company: sessions of one segment
+    // length are merged into ONE estimator batch (run_group) as long as their segments fit max_batch_segments
+    struct Pending { const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; std::vector<float> w; float* wav; int64_t cap;
+                     float* wav_mapped; int64_t nseg; };
+    std::vector<Pending> pending;
+    int64_t pending_segments = 0;
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
     std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -328,8 +350,8 @@ GemmArgs linear(const float* A, int64_t lda, const float* W, int64_t ldw, const 
 StitchArgs stitch_args(css_ctx* h) {
     StitchArgs a{};
     const int T = h->cfg.segment_frames;
-    a.masks = (const float*)h->masks.p;
-    a.mask_ld = h->plan.num_segments * T;
+    a.masks = h->masks_v;
+    a.mask_ld = h->mask_ld_v;
     a.sep = (const float*)h->sep.p;
     a.S = h->d.num_spks; a.F = h->d.num_bins; a.T = T; a.hop = h->cfg.hop_frames;
     a.num_segments = h->plan.num_segments; a.T_long = h->plan.mix_frames;
@@ -349,7 +371,7 @@ MvdrArgs mvdr_args(css_ctx* h, int64_t lo, int nseg) {
     const int T = h->cfg.segment_frames;
     a.X = (const float*)h->X.p; a.T_ld = h->T_ld; a.stft_frames = h->plan.stft_frames;
     a.C = h->n_ch; a.F = h->d.num_bins;
-    a.masks = (const float*)h->masks.p; a.mask_ld = h->plan.num_segments * T;
+    a.masks = h->masks_v; a.mask_ld = h->mask_ld_v;
     a.S = h->d.num_spks; a.T = T; a.hop = h->cfg.hop_frames;
     a.seg_lo = lo; a.nseg = nseg;
     a.wta_override = h->have_override ? (const uint8_t*)h->wta.p : nullptr;
@@ -427,7 +449,7 @@ int check_session(css_ctx* h) {
 // queued passes (css_run_enqueue) finish before anything else touches the handle's state or buffers
 #define CSS_DRAIN(h)                                                  \
     do {                                                              \
-        if ((h) && (h)->queued) {                                     \
+        if ((h) && ((h)->queued || !(h)->pending.empty())) {          \
             const int rc_drain_ = css_wait(h);                        \
             if (rc_drain_ != CSS_OK) return rc_drain_;                \
         }                                                             \
@@ -560,6 +582,10 @@ int css_destroy(css_handle_t h) {
     }
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
+    for (SessState& sl : h->slots)
+        for (DevBuf* b : {&sl.pcm_cm, &sl.X, &sl.scm, &sl.bfw, &sl.sep, &sl.costs, &sl.perms, &sl.mask_st, &sl.activity, &sl.act_b,
+                          &sl.act_tmp, &sl.act_final, &sl.Y, &sl.G, &sl.wav, &sl.wta, &sl.pnorm, &sl.pit_part})
+            if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->tail_end) hipEventDestroy(h->tail_end);
@@ -598,7 +624,7 @@ int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, in
 
 // -------------------------------------------------------------------------------------------------
 // Opens a session: validates the configuration, fixes the plan, sizes the workspace.  No sample moves here.
-static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg) {
+static int check_run_args(css_handle_t h, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg, CssPlan* plan_out) {
     if (!h || !cfg) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
     if (n_ch != h->d.num_mics)
         return fail(h, CSS_ERR_SHAPE, "input has " + std::to_string(n_ch) + " channels, the model expects " + std::to_string(h->d.num_mics));
@@ -609,10 +635,19 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if (cfg->stitching_loss < 0 || cfg->stitching_loss > 1 || cfg->stitching_input < 0 || cfg->stitching_input > 1)
         return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     if (hop <= 0 || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy 1 <= hop < T (at least one frame of overlap for the stitching cost, css.py:276)");
-    HIPCHK(h, hipSetDevice(h->device));
     CssPlan p{};
     if (plan_impl(h->d, *cfg, n_samples, &p) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "bad segment configuration");
     if (p.zero_weight) return fail(h, CSS_ERR_ZERO_WEIGHT, "zero weights found. check hop_size, segment_size or m0, m1");
+    *plan_out = p;
+    return CSS_OK;
+}
+
+static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg) {
+    CssPlan p{};
+    int rc0 = check_run_args(h, n_samples, n_ch, cfg, &p);
+    if (rc0 != CSS_OK) return rc0;
+    const int T = cfg->segment_frames;
+    HIPCHK(h, hipSetDevice(h->device));
     h->cfg = *cfg;
     h->w_host.assign(3 * (size_t)T, 0.f);
     std::memcpy(h->w_host.data(), cfg->w_first, T * sizeof(float));
@@ -664,8 +699,12 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     ENS(pnorm, (size_t)nseg * sizeof(double))
     ENS(segw, (size_t)3 * T * sizeof(float))
 #undef ENS
+    h->masks_v = (float*)h->masks.p;
+    h->mask_ld_v = nseg * T;
     // (a copy from pageable memory makes the host wait for the stream: paid only when the windows change)
     if (h->w_on_device != h->w_host) {
+        // (the tail of an overlapping queued pass may still read the previous windows)
+        if (h->tail_pending && h->tail_end) HIPCHK(h, hipStreamWaitEvent(h->stream, h->tail_end, 0));
         HIPCHK(h, hipMemcpyAsync(h->segw.p, h->w_host.data(), 3 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
         h->w_on_device = h->w_host;
     }
@@ -799,9 +838,13 @@ int css_stage_stft(css_handle_t h) {
 }
 
 // Where one batched pass of the mask estimator reads its spectra and writes its masks.
+struct GroupSess { const float* X; int64_t T_ld, stft_frames; int64_t off; int n; };   // a session's planes; its segments are the batch's [off, off + n)
 struct MaskIo {
     const float* X; int64_t T_ld; int64_t stft_frames; int hop; int T;   // planes [C][2F][T_ld], segment s at s*hop
     float* masks; int64_t mask_ld;                                       // [(S+1)F][mask_ld], segment s at column s*T
+    // a batch over the segments of SEVERAL sessions (run_group): the features of batch segment c come from the session
+    // that holds it, everything behind them is one [segments * T, .] problem; X / T_ld / stft_frames above are unused
+    const std::vector<GroupSess>* group = nullptr;
 };
 
 // The mask estimator over `nb` segments starting at `s0` on one lane (stream + activation set), phases [ph_lo, ph_hi):
@@ -829,7 +872,15 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         return g;
     };
     if (ph_lo < 0) {
-        {
+        if (io.group) {
+            for (const GroupSess& gs : *io.group) {
+                const int64_t lo = std::max<int64_t>(s0, gs.off), hi = std::min<int64_t>(s0 + nb, gs.off + gs.n);
+                if (hi <= lo) continue;
+                CSS_PROF(CSS_PROF_FEATURES, st);
+                launch_features(gs.X, gs.T_ld, gs.stft_frames, d.num_mics, F, feat + (lo - s0) * (int64_t)T * h->Kp, h->Kp, W.input_bias,
+                                W.input_scale, lo - gs.off, (int)(hi - lo), T, io.hop, sp, h->feat_opts, st);
+            }
+        } else {
             CSS_PROF(CSS_PROF_FEATURES, st);
             launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
                             io.hop, sp, h->feat_opts, st);
@@ -985,8 +1036,7 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     HIPCHK(h, hipSetDevice(h->device));
     const int T = h->cfg.segment_frames;
     const int64_t cap = batch_len(seg_hi - seg_lo, std::min<int64_t>(h->max_batch, h->plan.num_segments));
-    MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, (float*)h->masks.p,
-              h->plan.num_segments * T};
+    MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, h->masks_v, h->mask_ld_v};
     for (int64_t s0 = seg_lo; s0 < seg_hi; s0 += cap) {
         const int nb = (int)std::min<int64_t>(cap, seg_hi - s0);
         if ((rc = masknet_batch(h, io, s0, nb)) != CSS_OK) return rc;
@@ -1482,7 +1532,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     };
 
     // ---- the estimator, unit by unit; each lane appends the beamformer of its own segments
-    MaskIo mio{(const float*)h->X.p, h->T_ld, pl.stft_frames, hop, T, (float*)h->masks.p, nseg * T};
+    MaskIo mio{(const float*)h->X.p, h->T_ld, pl.stft_frames, hop, T, h->masks_v, h->mask_ld_v};
     size_t ui = 0;
     const LanePrep prep = [&](int64_t seg_lo, int cnt, hipStream_t st) -> int {
         Unit& u = units[ui];
@@ -1570,11 +1620,188 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     return finish_timings(h, host_t0, host_t1, host_t2, false);
 }
 
+// Several queued sessions as ONE pass of the mask estimator (css_run_enqueue).  Segments are independent through the whole
+// network and every kernel of it is batch invariant (a row's bits do not depend on the launch shape), so the segments of
+// G sessions go through features -> Conformer -> mask head as one [sum of segments x T, .] problem: every Linear-layer
+// launch then has three times the rows of a 60 s meeting's (M = 22 320 for three of them), the regime where the same
+// kernel runs at 0.31 - 0.34 of its ceiling instead of 0.26.  Everything around the estimator stays per
+// session, on that session's own buffers (SessState): upload and analysis transform before, covariances / MVDR /
+// beamformer / stitching costs after (the sessions dealt over the lanes' streams), then -- session by session on the tail
+// stream, beside the NEXT pass's estimator -- permutation scan, overlap-add, gate, synthesis and the zero-copy overlap-add
+// into the session's page-locked output.  The overlap protocol between consecutive passes is run_once's (sample-buffer
+// halves and level words by pass parity, the mask head waits for the previous tail), so grouped and single passes may
+// follow each other in one queue.  Results are bit for bit those of css_run on each session.
+namespace {
+// session j of a group of G lives in the handle itself (j == G - 1: the last session stays the handle's session, as after
+// a single pass) or in slots[j]; Active swaps it in for the scope
+struct Active {
+    css_ctx* h; SessState* other;
+    Active(css_ctx* h_, int j, int G) : h(h_), other(j == G - 1 ? nullptr : &h_->slots[(size_t)j]) {
+        if (other) std::swap(static_cast<SessState&>(*h), *other);
+    }
+    ~Active() { if (other) std::swap(static_cast<SessState&>(*h), *other); }
+};
+}  // namespace
+
+static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
+    const int G = (int)grp.size();
+    const auto host_t0 = std::chrono::steady_clock::now();
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->queued && h->last_piped != 1) {   // a non-overlapping pass is queued in front: drain it on the device (see run_once)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->tail_stream));
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        h->tail_pending = false;
+    }
+    h->last_piped = 1;
+    const int par = (int)(h->pass_no & 1);
+    if ((int)h->slots.size() < G - 1) h->slots.resize((size_t)(G - 1));
+    const int S = h->d.num_spks, F = h->d.num_bins;
+    int rc;
+    // ---- the sessions: plans, buffers
+    std::vector<int64_t> off((size_t)G), pcm_off((size_t)G);
+    int64_t total = 0;
+    size_t pcm_bytes = 0;
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        h->peak_dev = (unsigned int*)h->level.p + 8 * par + j;
+        h->piped_now = true;
+        rc = begin_impl(h, grp[(size_t)j].n, grp[(size_t)j].n_ch, &grp[(size_t)j].cfg);
+        h->piped_now = false;
+        if (rc != CSS_OK) return rc;
+        off[(size_t)j] = total;
+        total += h->plan.num_segments;
+        pcm_off[(size_t)j] = (int64_t)pcm_bytes;
+        pcm_bytes += ((size_t)grp[(size_t)j].n * grp[(size_t)j].n_ch * sizeof(float) + 255) / 256 * 256;
+    }
+    const int T = grp[0].cfg.segment_frames, hop = grp[0].cfg.hop_frames;
+    if ((rc = ensure(h, h->pcm_in, 2 * pcm_bytes)) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->masks, (size_t)(S + 1) * F * total * T * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure_activations(h, total, T)) != CSS_OK) return rc;
+    const char* pcm_base = (const char*)h->pcm_in.p + (par ? h->pcm_in.cap / 2 / 256 * 256 : 0);
+    std::vector<GroupSess> gs((size_t)G);
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        h->pcm_src = (const float*)(pcm_base + pcm_off[(size_t)j]);
+        h->masks_v = (float*)h->masks.p + off[(size_t)j] * T;
+        h->mask_ld_v = total * T;
+        gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments};
+    }
+    h->ev_pool_used = 0;
+    std::vector<hipEvent_t> up((size_t)G), done((size_t)G);
+    for (int j = 0; j < G; ++j) { up[(size_t)j] = pool_event(h); done[(size_t)j] = pool_event(h); }
+    // ---- the overlap protocol of queued passes (run_once, `piped`)
+    for (int b = 0; b < 2; ++b) {
+        if (!h->pcm_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcm_free[b], hipEventDisableTiming));
+        if (!h->level_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->level_free[b], hipEventDisableTiming));
+    }
+    if (!h->tail_end) HIPCHK(h, hipEventCreateWithFlags(&h->tail_end, hipEventDisableTiming));
+    for (auto& e : h->pass_end)
+        if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (h->pass_no >= CSS_QUEUE_LEAD) HIPCHK(h, hipEventSynchronize(h->pass_end[(h->pass_no - CSS_QUEUE_LEAD) & 3]));
+    if (h->pass_no >= 2) {
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->pcm_free[par], 0));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->level_free[par], 0));
+    }
+    HIPCHK(h, hipMemsetAsync((unsigned int*)h->level.p + 8 * par, 0, 8 * sizeof(unsigned int), h->copy_stream));
+    // ---- PCIe: every session's samples as one piece, its level scanned behind it
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        const css_ctx::Pending& q = grp[(size_t)j];
+        HIPCHK(h, hipMemcpyAsync(const_cast<float*>(h->pcm_src), q.pcm, (size_t)q.n * q.n_ch * sizeof(float), hipMemcpyHostToDevice,
+                                 h->copy_stream));
+        HIPCHK(h, hipEventRecord(up[(size_t)j], h->copy_stream));
+        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, q.n) * q.n_ch, h->peak_dev, h->copy_stream);
+    }
+    {
+        hipEvent_t level = pool_event(h);
+        HIPCHK(h, hipEventRecord(level, h->copy_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, level, 0));
+    }
+    hipEventRecord(h->ev[1], h->stream);
+    // ---- analysis transforms, session by session, as their samples land
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        HIPCHK(h, hipStreamWaitEvent(h->stream, up[(size_t)j], 0));
+        if (h->plan.stft_frames < h->plan.mix_frames)   // short input: zero-padded frames (css.py:159-164)
+            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->stream)) != CSS_OK) return rc;
+        h->stft_done = true;
+    }
+    hipEventRecord(h->ev[2], h->stream);
+    HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
+    // ---- one estimator batch over all their segments (the mask head waits for the previous pass's tail: it overwrites
+    // the mask buffer that tail reads)
+    MaskIo io{nullptr, 0, 0, hop, T, (float*)h->masks.p, total * T, &gs};
+    const LanePrep none = [](int64_t, int, hipStream_t) { return (int)CSS_OK; };
+    if ((rc = masknet_batch(h, io, 0, (int)total, none, none, h->tail_pending ? h->tail_end : nullptr)) != CSS_OK) return rc;
+    hipEventRecord(h->ev[3], h->stream);
+    // ---- covariances, MVDR, beamformer and stitching costs per session, the sessions dealt over the lanes' streams
+    const LaneSplit ls = lane_split(h, (int)total);
+    hipEvent_t masks_ready = pool_event(h);
+    HIPCHK(h, hipEventRecord(masks_ready, h->stream));
+    for (int l = 1; l < ls.nl && l < G; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], masks_ready, 0));
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        hipStream_t st = (ls.nl > 1 && j % ls.nl) ? h->lane_stream[j % ls.nl] : h->stream;
+        const int64_t nseg = h->plan.num_segments;
+        if ((rc = mvdr_on(h, 0, nseg, st)) != CSS_OK) return rc;
+        pit_costs_on(h, 0, nseg - 1, st);
+        HIPCHK(h, hipEventRecord(done[(size_t)j], st));
+    }
+    // (the next pass's transforms and beamformers follow this pass's on the main stream)
+    for (int j = 0; j < G; ++j)
+        if (ls.nl > 1 && j % ls.nl) HIPCHK(h, hipStreamWaitEvent(h->stream, done[(size_t)j], 0));
+    hipEventRecord(h->ev[4], h->stream);
+    // ---- the tails, session by session
+    hipStream_t ts = h->tail_stream;
+    for (int j = 0; j < G; ++j) {
+        Active act(h, j, G);
+        const css_ctx::Pending& q = grp[(size_t)j];
+        const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
+        HIPCHK(h, hipStreamWaitEvent(ts, done[(size_t)j], 0));
+        pit_scan_on(h, 0, nseg - 1, ts);
+        const StitchArgs sa = stitch_args(h);
+        { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, 0, TL, ts); }
+        { CSS_PROF(CSS_PROF_GATE, ts); launch_morphology(sa, 0, TL, ts); }
+        { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, 0, TL, ts); }
+        if (j == G - 1) hipEventRecord(h->ev[5], ts);
+        istft_gemm_on(h, 0, TL, ts);
+        wave_ola_on(h, 0, TL, 0, TL + 1, q.wav_mapped, q.cap, 0, ts);
+        h->perms_done = true;
+    }
+    hipEventRecord(h->ev[6], ts);
+    HIPCHK(h, hipEventRecord(h->tail_end, ts));
+    HIPCHK(h, hipEventRecord(h->level_free[par], ts));
+    HIPCHK(h, hipEventRecord(h->pass_end[h->pass_no & 3], ts));
+    hipEventRecord(h->ev[7], ts);
+    h->tail_pending = true;
+    h->pass_no += 1;
+    h->queued += 1;
+    HIPCHK(h, hipGetLastError());
+    h->tim.host_enqueue = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    return CSS_OK;
+}
+
+// the sessions css_run_enqueue has accepted and not yet put on the streams: one alone takes run_once's pipeline (its
+// lanes hide a single meeting's PCIe legs better), several take run_group
+static int flush_pending(css_handle_t h) {
+    if (h->pending.empty()) return CSS_OK;
+    std::vector<css_ctx::Pending> grp;
+    grp.swap(h->pending);
+    h->pending_segments = 0;
+    if (grp.size() == 1) {
+        RunIo io; io.pcm_host = grp[0].pcm; io.wav_host = grp[0].wav; io.cap = grp[0].cap; io.enqueue_only = true;
+        return run_once(h, grp[0].n, grp[0].n_ch, &grp[0].cfg, io);
+    }
+    return run_group(h, grp);
+}
+
 // The pass, and -- when an operand left the split-f16 range (a split GEMM saw a non-finite accumulator) -- the same pass
 // again on the exact float32 kernels (css_set_range_fallback(h, 0): CSS_ERR_RANGE instead).
 static int run_impl(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cfg, const RunIo& io) {
     int rc;
-    if (h && h->queued && (rc = css_wait(h)) != CSS_OK) return rc;   // queued passes first (and their range verdict)
+    if (h && (h->queued || !h->pending.empty()) && (rc = css_wait(h)) != CSS_OK) return rc;   // queued passes first (and their range verdict)
     rc = run_once(h, n, n_ch, cfg, io);
     if (rc != CSS_OK) return rc;
     h->range_last = 0;
@@ -1601,14 +1828,66 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
 int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                     float* wav_host, int64_t cap) {
     if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
-    RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
-    const int rc = run_once(h, n_samples, n_ch, cfg, io);
-    if (rc == CSS_OK) h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
-    return rc;
+    CssPlan pl{};
+    int rc = check_run_args(h, n_samples, n_ch, cfg, &pl);
+    if (rc != CSS_OK) return rc;
+    if (cap < pl.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(pl.n_out) + " samples per stream");
+    // Can the session share an estimator batch with its neighbours in the queue?  It must take the overlapping form of a
+    // queued pass (page-locked output, beamformer on the lanes) and fit a batch; sessions of another segmentation or
+    // window start a new group.  A pass under the per-launch profile stays alone only when grouping is off.
+    float* mapped = nullptr;
+    if (h->mapped_key != wav_host) { h->mapped_key = wav_host; h->mapped_val = mapped_host(wav_host); }
+    mapped = (float*)h->mapped_val;
+    const bool groupable = h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= h->max_batch;
+    if (!groupable) {
+        if ((rc = flush_pending(h)) != CSS_OK) return rc;
+        RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
+        rc = run_once(h, n_samples, n_ch, cfg, io);
+        if (rc == CSS_OK) h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
+        return rc;
+    }
+    const int T = cfg->segment_frames;
+    if (!h->pending.empty()) {
+        const css_ctx::Pending& f = h->pending.front();
+        const bool same = f.cfg.segment_frames == T && f.cfg.hop_frames == cfg->hop_frames &&
+                          std::memcmp(f.w.data(), cfg->w_first, T * sizeof(float)) == 0 &&
+                          std::memcmp(f.w.data() + T, cfg->w_mid, T * sizeof(float)) == 0 &&
+                          std::memcmp(f.w.data() + 2 * T, cfg->w_last, T * sizeof(float)) == 0;
+        if (!same || h->pending_segments + pl.num_segments > h->max_batch || (int)h->pending.size() >= h->group_limit)
+            if ((rc = flush_pending(h)) != CSS_OK) return rc;
+    }
+    css_ctx::Pending q{pcm_host, n_samples, n_ch, *cfg, {}, wav_host, cap, mapped, pl.num_segments};
+    q.w.resize(3 * (size_t)T);
+    std::memcpy(q.w.data(), cfg->w_first, T * sizeof(float));
+    std::memcpy(q.w.data() + T, cfg->w_mid, T * sizeof(float));
+    std::memcpy(q.w.data() + 2 * T, cfg->w_last, T * sizeof(float));
+    h->pending.push_back(std::move(q));
+    {   // (the vector may have moved: point the copies of the configuration at their own windows)
+        for (css_ctx::Pending& e : h->pending) {
+            e.cfg.w_first = e.w.data(); e.cfg.w_mid = e.w.data() + e.cfg.segment_frames; e.cfg.w_last = e.w.data() + 2 * e.cfg.segment_frames;
+        }
+    }
+    h->pending_segments += pl.num_segments;
+    h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
+    // no session of this length would still fit, or the group is full: off it goes -- nothing waits for a css_wait that
+    // could already run
+    if (h->pending_segments + pl.num_segments > h->max_batch || (int)h->pending.size() >= h->group_limit) return flush_pending(h);
+    return CSS_OK;
+}
+
+int css_set_queue_group(css_handle_t h, int max_sessions) {
+    CSS_DRAIN(h);
+    if (!h || max_sessions < 1 || max_sessions > css_ctx::MAX_GROUP) return fail(h, CSS_ERR_INVALID_ARG, "max_sessions must be in [1, 8]");
+    h->group_limit = max_sessions;
+    return CSS_OK;
 }
 
 int css_wait(css_handle_t h) {
     if (!h) return CSS_ERR_INVALID_ARG;
+    if (!h->pending.empty()) {
+        const int rc_flush = flush_pending(h);
+        if (rc_flush != CSS_OK) { h->queue_log.clear(); return rc_flush; }
+    }
     if (!h->queued) return CSS_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const auto t0 = std::chrono::steady_clock::now();
@@ -2163,7 +2442,9 @@ static int buffer_info(css_ctx* h, int which, DevBuf** buf, int64_t dims[4], int
     switch (which) {
         case CSS_BUF_X: *buf = &h->X; dims[0] = h->n_ch; dims[1] = 2 * F; dims[2] = h->T_ld; break;
         case CSS_BUF_FEATURES: *buf = &h->feat; dims[0] = h->last_batch_tokens; dims[1] = h->Kp; break;
-        case CSS_BUF_MASKS: *buf = &h->masks; dims[0] = (int64_t)(S + 1) * F; dims[1] = nseg * T; break;
+        case CSS_BUF_MASKS:   // (a session of a queued group holds its masks as columns of the group's buffer: not readable)
+            if (h->masks_v != (float*)h->masks.p || h->mask_ld_v != nseg * T) return CSS_ERR_STATE;
+            *buf = &h->masks; dims[0] = (int64_t)(S + 1) * F; dims[1] = nseg * T; break;
         case CSS_BUF_SCM: *buf = &h->scm; dims[0] = nseg; dims[1] = S + 1; dims[2] = F; dims[3] = 49; *elem = 8; break;
         case CSS_BUF_BFW: *buf = &h->bfw; dims[0] = nseg; dims[1] = S; dims[2] = F; dims[3] = 14; *elem = 8; break;
         case CSS_BUF_SEP: *buf = &h->sep; dims[0] = nseg; dims[1] = S; dims[2] = F; dims[3] = (int64_t)T * 2; break;
@@ -2243,6 +2524,7 @@ int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes
     if (nbytes != need) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
     HIPCHK(h, hipSetDevice(h->device));
     if ((rc = ensure(h, *b, (size_t)need)) != CSS_OK) return rc;
+    if (which == CSS_BUF_MASKS) h->masks_v = (float*)h->masks.p;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(b->p, host, (size_t)need, hipMemcpyHostToDevice));
     if (which == CSS_BUF_WTA_OVERRIDE) h->have_override = true;

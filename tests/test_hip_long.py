@@ -148,7 +148,7 @@ def test_masks_deep_in_the_meeting_vs_oracle(L, long_run, mc_state):
 
 
 def _report(key, value):
-    """parity bookkeeping: the measured margins of this run, next to the test output (profiles/r03_parity_margins.txt)"""
+    """parity bookkeeping: the measured margins of this run, next to the test output (profiles/r04_parity_coverage.json)"""
     import json
     print(f"[parity] {key}: {value}")
     out = os.path.join(ROOT, "gpurun_out")
@@ -156,11 +156,17 @@ def _report(key, value):
         path = os.path.join(out, "parity_coverage.json")
         data = {}
         if os.path.exists(path):
-            with open(path) as f:
-                data = json.load(f)
+            try:
+                with open(path) as f:
+                    data = json.load(f)
+            except ValueError:
+                data = {}
         data[key] = value
-        with open(path, "w") as f:
-            json.dump(data, f, indent=1, sort_keys=True)
+        plain = lambda o: o.item() if hasattr(o, "item") else (o.tolist() if hasattr(o, "tolist") else str(o))   # numpy scalars / arrays
+        text = json.dumps(data, indent=1, sort_keys=True, default=plain)
+        with open(path + ".tmp", "w") as f:
+            f.write(text)
+        os.replace(path + ".tmp", path)
 
 
 def _two_rank_worker(rank, world, port, seconds, out_dir):

@@ -73,7 +73,7 @@ def test_realistic_masks_60s_mc_vs_reference(conversation):
     out64 = [rel_rms(wav[k, ::dec][~ok_s[k]], g["mc_wav_c64"][k][~ok_s[k]]) for k in range(3)]
     toggles = [int(np.abs(np.diff(act_f[:, k].astype(int))).sum()) for k in range(3)]
     _report("realistic_masks_60s_mc", {
-        "frames": shape[0], "segments": nseg, "mask_statistics": masks.statistics(nseg),
+        "frames": int(shape[0]), "segments": nseg, "mask_statistics": masks.statistics(nseg),
         "distinct_stitching_permutations": len({tuple(p) for p in perms}), "gate_toggles_per_stream": toggles,
         "gate_open_fraction_per_stream": act_f.mean(0).round(4).tolist(),
         "permutations_equal": True, "activity_b_equal": True, "activity_final_equal": True,

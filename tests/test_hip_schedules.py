@@ -220,3 +220,50 @@ def test_queued_sessions_with_the_host_passes_ahead(mc_state):
                 assert np.array_equal(got, ref), (presized, k, float(np.abs(got - ref).max()))
     finally:
         sep.close()
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 8])
+def test_queued_sessions_share_estimator_batches(mc_state, group):
+    """css_run_enqueue merges the segments of consecutive queued sessions into ONE mask-estimator batch (run_group:
+    M = 22 k rows per Linear-layer launch for three 60 s meetings): sessions of different lengths, levels and CssCfg
+    (threshold, mask floor, stitching loss -- everything but the segmentation may differ inside a group), a session of
+    ANOTHER segmentation in the middle (it starts a group of its own), a single left-over session at the end -- each, bit
+    for bit, its own synchronous css_run; for every group limit, twice over the same buffers, and with the per-launch
+    profile on (one lane)."""
+    L, CSS = pkg("_lib"), pkg("css")
+    st, desc = mc_state
+    mk = lambda **kw: CSS.make_run_cfg(CSS.CssCfg(show_progressbar=False, **kw), 16000, 7)
+    cfgs = [mk(activity_th=0.3), mk(activity_th=0.45), mk(activity_th=0.3, mc_mask_floor_db=-6.0), mk(activity_th=0.3, stitching_loss="mse"),
+            mk(activity_th=0.3, segment_size_sec=4.0, hop_size_sec=2.0), mk(activity_th=0.3), mk(activity_th=0.5), mk(activity_th=0.3)]
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([60.0, 41.0, 20.0, 60.0, 33.0, 27.0, 60.0, 12.3]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=700 + k)
+            pcm = L.pinned_copy(np.ascontiguousarray(mix[0, :mix.shape[1] - 11 * k] * (0.01 if k % 3 == 2 else 1.0)))
+            sessions.append((pcm, cfgs[k], h.run(pcm, cfgs[k]).copy()))
+        h.set_queue_group(group)
+        for profile in (False, True):
+            h.set_profile(profile)
+            for rounds in range(2):
+                outs = []
+                for pcm, cfg, ref in sessions:
+                    out = L.pinned_empty(ref.shape, np.float32)
+                    out[:] = np.nan
+                    outs.append(h.run_enqueue(pcm, cfg, out))
+                h.wait()
+                for k, (got, (_, _, ref)) in enumerate(zip(outs, sessions)):
+                    assert np.array_equal(got, ref), (group, profile, rounds, k, float(np.abs(got - ref).max()))
+        h.set_profile(False)
+        # the handle's session after a queue is the LAST session queued (its plan, its decisions)
+        assert h.get_plan().n_samples == sessions[-1][0].shape[0]
+        # a bad session is refused when it is queued, not when its group runs; the sessions around it are untouched
+        a = h.run_enqueue(sessions[0][0], cfgs[0], L.pinned_empty(sessions[0][2].shape, np.float32))
+        with pytest.raises(L.CssError):                                                    # three channels into the 7-channel model
+            h.run_enqueue(L.pinned_copy(np.ascontiguousarray(sessions[1][0][:, :3])), cfgs[1], L.pinned_empty(sessions[1][2].shape, np.float32))
+        b = h.run_enqueue(sessions[2][0], cfgs[2], L.pinned_empty(sessions[2][2].shape, np.float32))
+        h.wait()
+        assert np.array_equal(a, sessions[0][2]) and np.array_equal(b, sessions[2][2])
+    finally:
+        sep.close()
