@@ -2144,6 +2144,7 @@ int css_get_timings(css_handle_t h, CssTimings* out) {
 }
 
 int css_get_plan(css_handle_t h, CssPlan* out) {
+    CSS_DRAIN(h);   // (a session css_run_enqueue holds back becomes the handle's session when it runs)
     int rc = check_session(h);
     if (rc) return rc;
     if (!out) return CSS_ERR_INVALID_ARG;
@@ -2305,11 +2306,18 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
             noise += q[9];
         }
         // the assignment of least mean loss (losses.py:43, linear_sum_assignment): perm[a] = ground truth assigned to prediction a
-        double cm[SMAX][SMAX] = {};
-        for (int a = 0; a < S; ++a)
-            for (int k = 0; k < S; ++k) cm[a][k] = mat[a * 3 + k];
+        V4<V4<double>> cm;
+        for (int a = 0; a < SMAX; ++a) {
+            V4<double> row;
+            row.fill(0.0);
+            for (int k = 0; k < S; ++k)
+                if (a < S) row.set(k, mat[a * 3 + k]);
+            cm.set(a, row);
+        }
+        V4<int> assigned;
+        lsap_small(cm, S, assigned);
         int best_p[SMAX];
-        lsap_small(cm, S, best_p);
+        for (int a = 0; a < SMAX; ++a) best_p[a] = assigned.get(a);
         double best = 0.0;
         for (int a = 0; a < S; ++a) best += mat[a * 3 + best_p[a]];
         const double sl = best * inv / S, nl = noise * inv;
@@ -2465,6 +2473,7 @@ static int buffer_info(css_ctx* h, int which, DevBuf** buf, int64_t dims[4], int
 }
 
 int css_buffer_dims(css_handle_t h, int which, int64_t dims[4], int32_t* elem_bytes) {
+    CSS_DRAIN(h);
     int rc = check_session(h);
     if (rc) return rc;
     DevBuf* b;
@@ -2533,6 +2542,7 @@ int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes
 }
 
 int css_buffer_devptr(css_handle_t h, int which, void** out) {
+    CSS_DRAIN(h);
     int rc = check_session(h);
     if (rc) return rc;
     DevBuf* b;

@@ -120,12 +120,17 @@ __host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_bou
         const double* c = costs + b * S * S;
         const int32_t* lp = perms + b * S;
         int32_t* rp = perms + (b + 1) * S;
-        double m[SMAX][SMAX];
-        for (int a = 0; a < S; ++a)
-            for (int k = 0; k < S; ++k) m[a][k] = c[lp[a] * S + k];   // the left segment's channels in their stitched order
-        int sig[SMAX];
+        V4<V4<double>> m;
+        for (int a = 0; a < SMAX; ++a) {
+            V4<double> row;
+            row.fill(0.0);
+            for (int k = 0; k < S; ++k)
+                if (a < S) row.set(k, c[lp[a] * S + k]);   // the left segment's channels in their stitched order
+            m.set(a, row);
+        }
+        V4<int> sig;
         lsap_small(m, S, sig);
-        for (int a = 0; a < S; ++a) rp[a] = sig[a];
+        for (int a = 0; a < S; ++a) rp[a] = sig.get(a);
     }
 }
 
@@ -138,40 +143,60 @@ __host__ __device__ inline void pit_scan_impl(const double* costs, int64_t n_bou
 constexpr int SCAN_CHUNK = 4096;
 constexpr int NPMAX = 24;
 
-__device__ __forceinline__ void perm_from_index(int idx, int S, int* p) {
+__device__ __forceinline__ V4<int> perm_from_index(int idx, int S) {
     // idx-th permutation of 0..S-1 in lexicographic order (factorial number system)
-    int avail[SMAX] = {0, 1, 2, 3};
+    V4<int> avail{0, 1, 2, 3}, p;
+    p.fill(0);
     int f = 1;
     for (int i = 2; i < S; ++i) f *= i;  // (S-1)!
     int n = S;
     for (int a = 0; a < S; ++a) {
         const int d = idx / f;
         idx -= d * f;
-        p[a] = avail[d];
-        for (int i = d; i + 1 < n; ++i) avail[i] = avail[i + 1];
+        p.set(a, avail.get(d));
+        for (int i = 0; i < SMAX - 1; ++i)
+            if (i >= d) avail.set(i, avail.get(i + 1));
         --n;
         if (n > 1) f /= (n);
     }
+    return p;
 }
+// lexicographic index of a permutation of 0..S-1 (its Lehmer code in the factorial number system)
+__device__ __forceinline__ int index_of_perm(const V4<int>& p, int S) {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < SMAX; ++a) {
+        int smaller = 0, fact = 1;
+#pragma unroll
+        for (int b = a + 1; b < SMAX; ++b) {
+            if (b < S && a < S && p.get(b) < p.get(a)) ++smaller;
+            if (b < S) fact *= (b - a);     // (S - 1 - a)!
+        }
+        idx += smaller * fact;
+    }
+    return idx;
+}
+__device__ __forceinline__ V4<int> unpack_perm(unsigned v) { return V4<int>{(int)(v & 15u), (int)((v >> 4) & 15u), (int)((v >> 8) & 15u), (int)((v >> 12) & 15u)}; }
 
 __global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict__ costs, int64_t b_lo, int64_t n_boundaries, int S,
                                                        int32_t* __restrict__ perms) {
     __shared__ uint8_t next[SCAN_CHUNK * NPMAX];
     __shared__ uint8_t state_of[SCAN_CHUNK];
+    __shared__ unsigned short ptab[NPMAX];   // the S! permutations in lexicographic order, four bits per entry
     __shared__ int carry;
     int np = 1;
     for (int i = 2; i <= S; ++i) np *= i;
+    if ((int)threadIdx.x < np) {
+        const V4<int> p = perm_from_index((int)threadIdx.x, S);
+        ptab[threadIdx.x] = (unsigned short)(p.a | (p.b << 4) | (p.c << 8) | (p.d << 12));
+    }
     if (threadIdx.x == 0) {
         carry = 0;  // identity = lexicographic index 0
         if (b_lo > 0) {   // resume: the lexicographic index of the permutation segment b_lo already has
-            int want[SMAX], p[SMAX];
-            for (int a = 0; a < S; ++a) want[a] = perms[b_lo * S + a];
-            for (int k = 0; k < np; ++k) {
-                perm_from_index(k, S, p);
-                bool same = true;
-                for (int a = 0; a < S; ++a) same &= p[a] == want[a];
-                if (same) carry = k;
-            }
+            V4<int> want;
+            want.fill(0);
+            for (int a = 0; a < S; ++a) want.set(a, perms[b_lo * S + a]);
+            carry = index_of_perm(want, S);
         }
     }
     if (b_lo == 0 && threadIdx.x < S) perms[threadIdx.x] = threadIdx.x;
@@ -181,20 +206,18 @@ __global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict_
         for (int e = threadIdx.x; e < nb * np; e += blockDim.x) {
             const int b = e / np, pin = e - b * np;
             const double* c = costs + (b0 + b) * S * S;
-            int lp[SMAX], sig[SMAX], q[SMAX];
-            perm_from_index(pin, S, lp);
-            double m[SMAX][SMAX];
-            for (int a = 0; a < S; ++a)
-                for (int k = 0; k < S; ++k) m[a][k] = c[lp[a] * S + k];
-            lsap_small(m, S, sig);
-            int arg = 0;
-            for (int k = 0; k < np; ++k) {  // the state (lexicographic index) of the assignment found
-                perm_from_index(k, S, q);
-                bool same = true;
-                for (int a = 0; a < S; ++a) same &= q[a] == sig[a];
-                if (same) arg = k;
+            const V4<int> lp = unpack_perm(ptab[pin]);
+            V4<V4<double>> m;
+            for (int a = 0; a < SMAX; ++a) {
+                V4<double> row;
+                row.fill(0.0);
+                for (int k = 0; k < SMAX; ++k)
+                    if (a < S && k < S) row.set(k, c[lp.get(a) * S + k]);
+                m.set(a, row);
             }
-            next[b * np + pin] = (uint8_t)arg;
+            V4<int> sig;
+            lsap_small(m, S, sig);
+            next[b * np + pin] = (uint8_t)index_of_perm(sig, S);   // the state (lexicographic index) of the assignment found
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -207,9 +230,8 @@ __global__ __launch_bounds__(256) void pit_scan_kernel(const double* __restrict_
         }
         __syncthreads();
         for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-            int p[SMAX];
-            perm_from_index(state_of[b], S, p);
-            for (int a = 0; a < S; ++a) perms[(b0 + b + 1) * S + a] = p[a];
+            const V4<int> p = unpack_perm(ptab[state_of[b]]);
+            for (int a = 0; a < S; ++a) perms[(b0 + b + 1) * S + a] = p.get(a);
         }
         __syncthreads();
     }
@@ -226,19 +248,23 @@ void pit_scan_host(const double* costs, int64_t n_boundaries, int S, int32_t* pe
 // ------------------------------------------------------------------------------------------------
 // helpers shared by the two overlap-add kernels
 // ------------------------------------------------------------------------------------------------
-struct Contrib { int64_t seg; int tl; float w; };
-
 __device__ __forceinline__ float seg_weight(const StitchArgs& a, int64_t seg, int tl) {
     // css.py:258,290: segment 0 is built with is_first_seg, the last one with is_last_seg
     const float* w = seg == 0 ? a.w_first : (seg == a.num_segments - 1 ? a.w_last : a.w_mid);
     return w[tl];
 }
 
-// the segments covering frame t in ascending segment order.  Up to MAXC of them (hop >= T / MAXC; two with the shipped
-// 3 s / 1.5 s configuration) are listed once per frame by contributors(); denser segmentations (any hop >= 1 the reference
-// accepts, css.py:144-171) take the *_general loops below, which walk first_seg(t) .. last_seg(t) per value.
+// The segments covering frame t, in ascending segment order.  NC = ceil(T / hop) of them at most: two with the shipped
+// 3 s / 1.5 s configuration, up to four take the same code (the kernels are instantiated for NC = 2 and 4: slot i is
+// ALWAYS segment t / hop - (NC - 1) + i, present or not, so every index is a compile-time constant and nothing lives in
+// private scratch); denser segmentations (any hop >= 1 the reference accepts, css.py:144-171) take the NC = 0
+// instantiation, which walks first_seg(t) .. last_seg(t) per value.  The sums start from zero exactly as the reference's
+// `zeros += w * x` does (css.py:254-295): 0 + w x is w x, so the float32 operation order is the reference's.
 constexpr int MAXC = 4;
-__device__ __forceinline__ bool few_contributors(const StitchArgs& a) { return (a.T + a.hop - 1) / a.hop <= MAXC; }
+__host__ __device__ inline int contributor_class(int T, int hop) {
+    const int nc = (T + hop - 1) / hop;
+    return nc <= 2 ? 2 : (nc <= MAXC ? MAXC : 0);
+}
 __device__ __forceinline__ int64_t first_seg(const StitchArgs& a, int64_t t) {
     const int64_t lo = t - a.T + 1;
     const int64_t s0 = lo <= 0 ? 0 : (lo + a.hop - 1) / a.hop;
@@ -248,20 +274,32 @@ __device__ __forceinline__ int64_t last_seg(const StitchArgs& a, int64_t t) {
     const int64_t s1 = t / a.hop;
     return s1 < a.num_segments ? s1 : a.num_segments - 1;
 }
-__device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Contrib c[MAXC]) {
-    const int64_t i1 = t / a.hop;
-    int n = 0;
-    for (int64_t seg = i1 - (MAXC - 1); seg <= i1; ++seg) {
-        if (seg < 0 || seg >= a.num_segments) continue;
-        const int64_t tl = t - seg * a.hop;
-        if (tl < 0 || tl >= a.T) continue;
-        c[n].seg = seg;
-        c[n].tl = (int)tl;
-        c[n].w = seg_weight(a, seg, (int)tl);
-        ++n;
+template <int NC>
+struct Covering {
+    int64_t seg[NC];
+    int tl[NC];
+    float w[NC];      // 0 for an absent slot
+    bool on[NC];
+    __device__ __forceinline__ void build(const StitchArgs& a, int64_t t) {
+        const int64_t i1 = t / a.hop;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int64_t sg = i1 - (NC - 1) + i;
+            const int64_t l = t - sg * a.hop;
+            on[i] = sg >= 0 && sg < a.num_segments && l >= 0 && l < a.T;
+            seg[i] = on[i] ? sg : 0;
+            tl[i] = on[i] ? (int)l : 0;
+            w[i] = on[i] ? seg_weight(a, sg, (int)l) : 0.f;
+        }
     }
-    return n;
-}
+    __device__ __forceinline__ float weight_sum() const {
+        float ws = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (on[i]) ws = __fadd_rn(ws, w[i]);
+        return ws;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Weighted overlap-add of the (permuted) masks + mean over frequency (css.py:254-299, 303-304):
@@ -274,27 +312,15 @@ __device__ __forceinline__ int contributors(const StitchArgs& a, int64_t t, Cont
 // partial sums are added in a fixed order.
 // ------------------------------------------------------------------------------------------------
 constexpr int OM_T = 16, OM_FG = 16;
+template <int NC>
 __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_lo, int64_t t_hi) {
     __shared__ double red[OM_FG][OM_T];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & (OM_T - 1), fg = threadIdx.x / OM_T;
     const int64_t t = t_lo + (int64_t)blockIdx.x * OM_T + lane;
     const bool active = t < t_hi;
-    Contrib c[MAXC];
-    int n = 0;
-    float wsum = 0.f;
-    const float* mp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
-    if (active && few_contributors(a)) {
-        n = contributors(a, t, c);
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i)
-            if (i < n) {
-                wsum = __fadd_rn(wsum, c[i].w);
-                mp[i] = a.masks + (int64_t)a.perms[c[i].seg * a.S + s] * a.F * a.mask_ld + c[i].seg * a.T + c[i].tl;
-            }
-    }
     double sum = 0.0;
-    if (!few_contributors(a)) {   // (uniform over the launch)
+    if constexpr (NC == 0) {
         if (active) {
             const int64_t s0 = first_seg(a, t), s1 = last_seg(a, t);
             float ws = 0.f;
@@ -305,24 +331,32 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
                 for (int64_t seg = s0; seg <= s1; ++seg) {
                     const int tl = (int)(t - seg * a.hop);
                     const float m = a.masks[((int64_t)a.perms[seg * a.S + s] * a.F + f) * a.mask_ld + seg * a.T + tl];
-                    const float wm = __fmul_rn(seg_weight(a, seg, tl), m);
-                    v = seg == s0 ? wm : __fadd_rn(v, wm);
+                    v = __fadd_rn(v, __fmul_rn(seg_weight(a, seg, tl), m));
                 }
                 v = __fdiv_rn(v, ws);
                 out[(int64_t)f * a.T_long] = v;
                 sum += (double)v;
             }
         }
-    } else if (active && n > 0) {
-        float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
-        for (int f = fg; f < a.F; f += OM_FG) {
-            float v = __fmul_rn(c[0].w, mp[0][(int64_t)f * a.mask_ld]);
+    } else {
+        if (active) {
+            Covering<NC> c;
+            c.build(a, t);
+            const float wsum = c.weight_sum();
+            const float* mp[NC];
 #pragma unroll
-            for (int i = 1; i < MAXC; ++i)
-                if (i < n) v = __fadd_rn(v, __fmul_rn(c[i].w, mp[i][(int64_t)f * a.mask_ld]));
-            v = __fdiv_rn(v, wsum);
-            out[(int64_t)f * a.T_long] = v;
-            sum += (double)v;
+            for (int i = 0; i < NC; ++i)
+                mp[i] = a.masks + (int64_t)(c.on[i] ? a.perms[c.seg[i] * a.S + s] : 0) * a.F * a.mask_ld + c.seg[i] * a.T + c.tl[i];
+            float* out = a.mask_st + (int64_t)s * a.F * a.T_long + t;
+            for (int f = fg; f < a.F; f += OM_FG) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+                    if (c.on[i]) v = __fadd_rn(v, __fmul_rn(c.w[i], mp[i][(int64_t)f * a.mask_ld]));
+                v = __fdiv_rn(v, wsum);
+                out[(int64_t)f * a.T_long] = v;
+                sum += (double)v;
+            }
         }
     }
     red[fg][lane] = sum;
@@ -339,7 +373,12 @@ __global__ __launch_bounds__(256) void ola_masks_kernel(StitchArgs a, int64_t t_
 
 void launch_ola_masks(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
     if (t_hi <= t_lo) return;
-    hipLaunchKernelGGL(ola_masks_kernel, dim3((unsigned)((t_hi - t_lo + OM_T - 1) / OM_T), a.S), dim3(OM_T * OM_FG), 0, s, a, t_lo, t_hi);
+    const dim3 grid((unsigned)((t_hi - t_lo + OM_T - 1) / OM_T), a.S), block(OM_T * OM_FG);
+    switch (contributor_class(a.T, a.hop)) {
+        case 2: hipLaunchKernelGGL(ola_masks_kernel<2>, grid, block, 0, s, a, t_lo, t_hi); break;
+        case 4: hipLaunchKernelGGL(ola_masks_kernel<4>, grid, block, 0, s, a, t_lo, t_hi); break;
+        default: hipLaunchKernelGGL(ola_masks_kernel<0>, grid, block, 0, s, a, t_lo, t_hi); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,6 +417,7 @@ void launch_morphology(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStrea
 // ------------------------------------------------------------------------------------------------
 constexpr int OT = 16;
 
+template <int NC>
 __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_lo, int64_t t_hi) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [OT][2F + 1] (odd stride: no bank conflicts)
     const int TS = 2 * a.F + 1;
@@ -386,59 +426,63 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
     const int tx = threadIdx.x & (OT - 1), fy = threadIdx.x >> 4;  // 16 frames x 16 bins per pass
     const int64_t t = t0 + tx;
     const bool active = t < t_hi;
-    Contrib c[MAXC];
-    int n = 0;
-    float wsum = 0.f, gate = 0.f;
-    const float2* pp[MAXC] = {nullptr, nullptr, nullptr, nullptr};
-    const bool few = few_contributors(a);
     const float2* sep = reinterpret_cast<const float2*>(a.sep);
-    int64_t gs0 = 0, gs1 = -1;
-    if (active && !few) {
-        gs0 = first_seg(a, t); gs1 = last_seg(a, t);
-        gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
-        for (int64_t seg = gs0; seg <= gs1; ++seg) wsum = __fadd_rn(wsum, seg_weight(a, seg, (int)(t - seg * a.hop)));
-    }
-    if (active && few) {
-        n = contributors(a, t, c);
-        gate = a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
+    const float gate = active && a.act_final[(int64_t)s * a.T_long + t] ? 1.f : 0.f;
+    if constexpr (NC == 0) {
+        int64_t gs0 = 0, gs1 = -1;
+        float wsum = 0.f;
+        if (active) {
+            gs0 = first_seg(a, t); gs1 = last_seg(a, t);
+            for (int64_t seg = gs0; seg <= gs1; ++seg) wsum = __fadd_rn(wsum, seg_weight(a, seg, (int)(t - seg * a.hop)));
+        }
+        for (int f = fy; f < a.F; f += 16) {
+            float re = 0.f, im = 0.f;
+            if (active) {
+                for (int64_t seg = gs0; seg <= gs1; ++seg) {
+                    const int tl = (int)(t - seg * a.hop);
+                    const float w = seg_weight(a, seg, tl);
+                    const float2 v = sep[((seg * a.S + a.perms[seg * a.S + s]) * (int64_t)a.F + f) * a.T + tl];
+                    re = __fadd_rn(re, __fmul_rn(w, v.x));
+                    im = __fadd_rn(im, __fmul_rn(w, v.y));
+                }
+                if (gs1 >= gs0) {
+                    re = __fmul_rn(__fdiv_rn(re, wsum), gate);
+                    im = __fmul_rn(__fdiv_rn(im, wsum), gate);
+                }
+            }
+            tile[tx * TS + f] = re;
+            tile[tx * TS + a.F + f] = im;
+        }
+    } else {
+        Covering<NC> c;
+        const float2* pp[NC];
+        float wsum = 1.f;
+        bool any = false;
+        if (active) {
+            c.build(a, t);
+            wsum = c.weight_sum();
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i)
-            if (i < n) {
-                wsum = __fadd_rn(wsum, c[i].w);
-                pp[i] = sep + (c[i].seg * a.S + a.perms[c[i].seg * a.S + s]) * (int64_t)a.F * a.T + c[i].tl;
+            for (int i = 0; i < NC; ++i) {
+                any |= c.on[i];
+                pp[i] = sep + (c.seg[i] * a.S + (c.on[i] ? a.perms[c.seg[i] * a.S + s] : 0)) * (int64_t)a.F * a.T + c.tl[i];
             }
-    }
-    for (int f = fy; f < a.F; f += 16) {
-        float re = 0.f, im = 0.f;
-        if (active && !few) {
-            for (int64_t seg = gs0; seg <= gs1; ++seg) {
-                const int tl = (int)(t - seg * a.hop);
-                const float w = seg_weight(a, seg, tl);
-                const float2 v = sep[((seg * a.S + a.perms[seg * a.S + s]) * (int64_t)a.F + f) * a.T + tl];
-                const float wr = __fmul_rn(w, v.x), wi = __fmul_rn(w, v.y);
-                re = seg == gs0 ? wr : __fadd_rn(re, wr);
-                im = seg == gs0 ? wi : __fadd_rn(im, wi);
-            }
-            if (gs1 >= gs0) {
+        }
+        for (int f = fy; f < a.F; f += 16) {
+            float re = 0.f, im = 0.f;
+            if (active && any) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+                    if (c.on[i]) {
+                        const float2 v = pp[i][(int64_t)f * a.T];
+                        re = __fadd_rn(re, __fmul_rn(c.w[i], v.x));
+                        im = __fadd_rn(im, __fmul_rn(c.w[i], v.y));
+                    }
                 re = __fmul_rn(__fdiv_rn(re, wsum), gate);
                 im = __fmul_rn(__fdiv_rn(im, wsum), gate);
             }
-        } else if (active && n > 0) {
-            const float2 v0 = pp[0][(int64_t)f * a.T];
-            re = __fmul_rn(c[0].w, v0.x);
-            im = __fmul_rn(c[0].w, v0.y);
-#pragma unroll
-            for (int i = 1; i < MAXC; ++i)
-                if (i < n) {
-                    const float2 v1 = pp[i][(int64_t)f * a.T];
-                    re = __fadd_rn(re, __fmul_rn(c[i].w, v1.x));
-                    im = __fadd_rn(im, __fmul_rn(c[i].w, v1.y));
-                }
-            re = __fmul_rn(__fdiv_rn(re, wsum), gate);
-            im = __fmul_rn(__fdiv_rn(im, wsum), gate);
+            tile[tx * TS + f] = re;
+            tile[tx * TS + a.F + f] = im;
         }
-        tile[tx * TS + f] = re;
-        tile[tx * TS + a.F + f] = im;
     }
     __syncthreads();
     const float lvl = a.y_split ? level_gain(a.level) : 1.f;
@@ -456,7 +500,12 @@ __global__ __launch_bounds__(256) void ola_stft_kernel(StitchArgs a, int64_t t_l
 void launch_ola_stft(const StitchArgs& a, int64_t t_lo, int64_t t_hi, hipStream_t s) {
     if (t_hi <= t_lo) return;
     const size_t lds = (size_t)OT * (2 * a.F + 1) * sizeof(float);
-    hipLaunchKernelGGL(ola_stft_kernel, dim3((unsigned)((t_hi - t_lo + OT - 1) / OT), a.S), dim3(256), lds, s, a, t_lo, t_hi);
+    const dim3 grid((unsigned)((t_hi - t_lo + OT - 1) / OT), a.S), block(256);
+    switch (contributor_class(a.T, a.hop)) {
+        case 2: hipLaunchKernelGGL(ola_stft_kernel<2>, grid, block, lds, s, a, t_lo, t_hi); break;
+        case 4: hipLaunchKernelGGL(ola_stft_kernel<4>, grid, block, lds, s, a, t_lo, t_hi); break;
+        default: hipLaunchKernelGGL(ola_stft_kernel<0>, grid, block, lds, s, a, t_lo, t_hi); break;
+    }
 }
 
 }  // namespace css
