@@ -67,6 +67,8 @@ struct SessState {
     bool stft_done = false, perms_done = false, have_override = false;
     std::vector<float> w_host;   // segment weights of the session (cfg.w_* point into it)
     DevBuf pcm_cm, X, scm, bfw, sep, costs, perms, mask_st, activity, act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, pit_part;
+    DevBuf X_alt;   // run_group: consecutive grouped passes alternate between X and X_alt (the beamformer of pass P reads its
+                    // planes on the tail stream while pass P + 1's transform already writes the other set)
     const float* pcm_src = nullptr;       // sample-major PCM on the device for the current session
     unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
     // the session's masks [(S+1)F][mask_ld], segment s at column s*T: the handle's mask buffer, or -- inside a group -- this
@@ -277,6 +279,94 @@ void exact_cs(int64_t k, int N, double* c, double* s) {
     *s = sin(ang);
     if ((2 * k) % N == 0) *s = 0.0;
     if ((4 * k) % N == 0) *c = std::round(*c);
+}
+
+// ---- which hardware queue a stream lands on ------------------------------------------------------------------------
+// The runtime deals its streams onto a few hardware queues (four by default) in creation order, and two streams on one
+// queue run strictly one after the other: an upload on a "copy stream" that shares the main stream's queue starts
+// only when the main stream's kernels are through, lanes that share a queue are no lanes at all.  Which streams collide
+// depends on how many streams the PROCESS created before -- a handle created second, or on a stream torch made first, got
+// a different deal (round 3: the same 30-min pass 7 % slower on such a handle, the first 22 MB piece of a sharded upload
+// "taking" 14.9 ms because it waited for the 784 MB behind it; tools/rccl_slowdown_probe.py).  So css_create does not
+// take the streams as they come: it creates candidates, MEASURES which ones can run beside the main stream and beside each
+// other (a 200 us spin kernel on one, an empty kernel on the other), and deals them out itself: every lane on a queue of
+// its own where there are enough, none of them on the main stream's, the copy and tail streams together on another (they
+// meet anyway: uploads and transforms of the next pass, stitching and synthesis of the previous one).
+__global__ void css_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();   // constant 100 MHz
+    while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void css_nop_kernel() {}
+
+bool streams_share_a_queue(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1) {
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    hipEventRecord(e0, a);
+    hipLaunchKernelGGL(css_spin_kernel, dim3(1), dim3(64), 0, a, (long long)20000);   // 200 us
+    hipLaunchKernelGGL(css_nop_kernel, dim3(1), dim3(1), 0, b);
+    hipEventRecord(e1, b);
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return ms > 0.1f;
+}
+
+// streams for lanes 1 .. 3, the copy stream and the tail stream, none of them on `main`'s hardware queue where that can
+// be had; false: something failed, the caller creates them plainly
+bool deal_streams(hipStream_t main, hipStream_t lane[4], hipStream_t* copy, hipStream_t* tail) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
+    std::vector<std::vector<hipStream_t>> cls;   // classes of candidates that share a queue; none shares the main stream's
+    std::vector<hipStream_t> with_main;
+    auto enough = [&]() {
+        if (cls.size() < 3) return false;
+        std::vector<size_t> n;
+        for (auto& c : cls) n.push_back(c.size());
+        std::sort(n.begin(), n.end());
+        return n[n.size() - 1] >= 3;   // one class with three streams (copy, tail, fourth lane), two more for lanes 1 and 2
+    };
+    bool ok = true;
+    for (int k = 0; k < 20 && ok && !enough(); ++k) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
+        if (streams_share_a_queue(main, st, e0, e1)) { with_main.push_back(st); continue; }
+        bool placed = false;
+        for (auto& c : cls)
+            if (streams_share_a_queue(c[0], st, e0, e1)) { c.push_back(st); placed = true; break; }
+        if (!placed) cls.push_back({st});
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (hipGetLastError() != hipSuccess) ok = false;
+    std::vector<hipStream_t> take;   // lane1, lane2, copy, tail, lane3
+    if (ok && !cls.empty()) {
+        std::sort(cls.begin(), cls.end(), [](const std::vector<hipStream_t>& x, const std::vector<hipStream_t>& y) { return x.size() > y.size(); });
+        // cls[0]: the largest class -> copy, tail, fourth lane; the next two -> lanes 1 and 2
+        auto pop = [&](size_t c) -> hipStream_t {
+            for (size_t q = 0; q < cls.size(); ++q) {
+                auto& v = cls[(c + q) % cls.size()];
+                if (!v.empty()) { hipStream_t s_ = v.back(); v.pop_back(); return s_; }
+            }
+            if (!with_main.empty()) { hipStream_t s_ = with_main.back(); with_main.pop_back(); return s_; }
+            return nullptr;
+        };
+        const size_t nc = cls.size();
+        take = {pop(nc > 1 ? 1 : 0), pop(nc > 2 ? 2 : (nc > 1 ? 1 : 0)), pop(0), pop(0), pop(0)};
+        for (hipStream_t s_ : take) ok = ok && s_ != nullptr;
+    } else {
+        ok = false;
+    }
+    for (auto& c : cls)
+        for (hipStream_t s_ : c) hipStreamDestroy(s_);
+    for (hipStream_t s_ : with_main) hipStreamDestroy(s_);
+    if (!ok) {
+        for (hipStream_t s_ : take)
+            if (s_) hipStreamDestroy(s_);
+        return false;
+    }
+    lane[1] = take[0]; lane[2] = take[1]; *copy = take[2]; *tail = take[3]; lane[3] = take[4];
+    return true;
 }
 
 int plan_impl(const CssModelDesc& d, const CssRunCfg& cfg, int64_t n, CssPlan* p) {
@@ -515,12 +605,13 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         if (hipEventCreate(&e) != hipSuccess) return bail(CSS_ERR_HIP, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return bail(CSS_ERR_HIP, "hipEventCreate failed");
+    const bool dealt = deal_streams(h->stream, h->lane_stream, &h->copy_stream, &h->tail_stream);
     for (int l = 1; l < css_ctx::MAX_LANES; ++l)
-        if (hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+        if ((!dealt && hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) != hipSuccess) ||
             hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
             return bail(CSS_ERR_HIP, "lane stream / event could not be created");
-    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess)
+    if (!dealt && (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+                   hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess))
         return bail(CSS_ERR_HIP, "copy / tail stream could not be created");
     if (hipMalloc(&h->level.p, 64) != hipSuccess || hipMemset(h->level.p, 0, 64) != hipSuccess ||
         hipMalloc((void**)&h->range_flag_dev, 64) != hipSuccess ||
@@ -573,7 +664,7 @@ int css_destroy(css_handle_t h) {
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->qkf, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
                       &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
-                      &h->in16, &h->pcm_f, &h->enc, &h->level, &h->mel_tab, &h->mel_work};
+                      &h->in16, &h->pcm_f, &h->enc, &h->level, &h->mel_tab, &h->mel_work, &h->X_alt};
     for (int l = 1; l < css_ctx::MAX_LANES; ++l) {
         for (DevBuf* b : {&h->lfeat[l], &h->lhx[l], &h->lhu[l], &h->lht[l], &h->lqkv[l], &h->lqkf[l], &h->lctx[l]})
             if (b->p) hipFree(b->p);
@@ -584,7 +675,7 @@ int css_destroy(css_handle_t h) {
         if (b->p) hipFree(b->p);
     for (SessState& sl : h->slots)
         for (DevBuf* b : {&sl.pcm_cm, &sl.X, &sl.scm, &sl.bfw, &sl.sep, &sl.costs, &sl.perms, &sl.mask_st, &sl.activity, &sl.act_b,
-                          &sl.act_tmp, &sl.act_final, &sl.Y, &sl.G, &sl.wav, &sl.wta, &sl.pnorm, &sl.pit_part})
+                          &sl.act_tmp, &sl.act_final, &sl.Y, &sl.G, &sl.wav, &sl.wta, &sl.pnorm, &sl.pit_part, &sl.X_alt})
             if (b->p) hipFree(b->p);
     if (h->blob) hipFree(h->blob);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1664,6 +1755,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     size_t pcm_bytes = 0;
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
+        std::swap(h->X, h->X_alt);   // (every grouped pass takes the planes the previous one did not)
         h->peak_dev = (unsigned int*)h->level.p + 8 * par + j;
         h->piped_now = true;
         rc = begin_impl(h, grp[(size_t)j].n, grp[(size_t)j].n_ch, &grp[(size_t)j].cfg);
@@ -1688,8 +1780,8 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments};
     }
     h->ev_pool_used = 0;
-    std::vector<hipEvent_t> up((size_t)G), done((size_t)G);
-    for (int j = 0; j < G; ++j) { up[(size_t)j] = pool_event(h); done[(size_t)j] = pool_event(h); }
+    std::vector<hipEvent_t> planes((size_t)G);
+    for (int j = 0; j < G; ++j) planes[(size_t)j] = pool_event(h);
     // ---- the overlap protocol of queued passes (run_once, `piped`)
     for (int b = 0; b < 2; ++b) {
         if (!h->pcm_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcm_free[b], hipEventDisableTiming));
@@ -1699,67 +1791,57 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     for (auto& e : h->pass_end)
         if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (h->pass_no >= CSS_QUEUE_LEAD) HIPCHK(h, hipEventSynchronize(h->pass_end[(h->pass_no - CSS_QUEUE_LEAD) & 3]));
+    {   // whatever the handle's stream holds from before the queue (weights, an earlier synchronous pass) comes first
+        hipEvent_t opened = pool_event(h);
+        HIPCHK(h, hipEventRecord(opened, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, opened, 0));
+    }
     if (h->pass_no >= 2) {
+        // this parity's sample buffer, level words and planes were last used by the pass before last: its transforms are
+        // on this very stream; its beamformers (readers of the planes) and its tail (reader of the level words) ended with
+        // level_free
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->pcm_free[par], 0));
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->level_free[par], 0));
     }
     HIPCHK(h, hipMemsetAsync((unsigned int*)h->level.p + 8 * par, 0, 8 * sizeof(unsigned int), h->copy_stream));
-    // ---- PCIe: every session's samples as one piece, its level scanned behind it
+    // ---- copy stream: every session's samples as one piece, its level scanned and its analysis transform behind it --
+    // all of it beside the PREVIOUS pass's estimator (the host runs passes ahead), so that the main stream carries nothing
+    // but estimators, back to back
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         const css_ctx::Pending& q = grp[(size_t)j];
         HIPCHK(h, hipMemcpyAsync(const_cast<float*>(h->pcm_src), q.pcm, (size_t)q.n * q.n_ch * sizeof(float), hipMemcpyHostToDevice,
                                  h->copy_stream));
-        HIPCHK(h, hipEventRecord(up[(size_t)j], h->copy_stream));
         launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, q.n) * q.n_ch, h->peak_dev, h->copy_stream);
-    }
-    {
-        hipEvent_t level = pool_event(h);
-        HIPCHK(h, hipEventRecord(level, h->copy_stream));
-        HIPCHK(h, hipStreamWaitEvent(h->tail_stream, level, 0));
-    }
-    hipEventRecord(h->ev[1], h->stream);
-    // ---- analysis transforms, session by session, as their samples land
-    for (int j = 0; j < G; ++j) {
-        Active act(h, j, G);
-        HIPCHK(h, hipStreamWaitEvent(h->stream, up[(size_t)j], 0));
         if (h->plan.stft_frames < h->plan.mix_frames)   // short input: zero-padded frames (css.py:159-164)
-            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
-        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->stream)) != CSS_OK) return rc;
+            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->copy_stream));
+        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->copy_stream)) != CSS_OK) return rc;
         h->stft_done = true;
+        HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
     }
+    HIPCHK(h, hipEventRecord(h->pcm_free[par], h->copy_stream));
+    hipEventRecord(h->ev[1], h->stream);
+    for (int j = 0; j < G; ++j) HIPCHK(h, hipStreamWaitEvent(h->stream, planes[(size_t)j], 0));
     hipEventRecord(h->ev[2], h->stream);
-    HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
     // ---- one estimator batch over all their segments (the mask head waits for the previous pass's tail: it overwrites
     // the mask buffer that tail reads)
     MaskIo io{nullptr, 0, 0, hop, T, (float*)h->masks.p, total * T, &gs};
     const LanePrep none = [](int64_t, int, hipStream_t) { return (int)CSS_OK; };
     if ((rc = masknet_batch(h, io, 0, (int)total, none, none, h->tail_pending ? h->tail_end : nullptr)) != CSS_OK) return rc;
     hipEventRecord(h->ev[3], h->stream);
-    // ---- covariances, MVDR, beamformer and stitching costs per session, the sessions dealt over the lanes' streams
-    const LaneSplit ls = lane_split(h, (int)total);
     hipEvent_t masks_ready = pool_event(h);
     HIPCHK(h, hipEventRecord(masks_ready, h->stream));
-    for (int l = 1; l < ls.nl && l < G; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], masks_ready, 0));
-    for (int j = 0; j < G; ++j) {
-        Active act(h, j, G);
-        hipStream_t st = (ls.nl > 1 && j % ls.nl) ? h->lane_stream[j % ls.nl] : h->stream;
-        const int64_t nseg = h->plan.num_segments;
-        if ((rc = mvdr_on(h, 0, nseg, st)) != CSS_OK) return rc;
-        pit_costs_on(h, 0, nseg - 1, st);
-        HIPCHK(h, hipEventRecord(done[(size_t)j], st));
-    }
-    // (the next pass's transforms and beamformers follow this pass's on the main stream)
-    for (int j = 0; j < G; ++j)
-        if (ls.nl > 1 && j % ls.nl) HIPCHK(h, hipStreamWaitEvent(h->stream, done[(size_t)j], 0));
     hipEventRecord(h->ev[4], h->stream);
-    // ---- the tails, session by session
+    // ---- tail stream, session by session, beside the NEXT pass's estimator: covariances, MVDR, beamformer, stitching
+    // costs, permutation scan, overlap-add, gate, synthesis, zero-copy overlap-add into the session's page-locked output
     hipStream_t ts = h->tail_stream;
+    HIPCHK(h, hipStreamWaitEvent(ts, masks_ready, 0));
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         const css_ctx::Pending& q = grp[(size_t)j];
         const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
-        HIPCHK(h, hipStreamWaitEvent(ts, done[(size_t)j], 0));
+        if ((rc = mvdr_on(h, 0, nseg, ts)) != CSS_OK) return rc;
+        pit_costs_on(h, 0, nseg - 1, ts);
         pit_scan_on(h, 0, nseg - 1, ts);
         const StitchArgs sa = stitch_args(h);
         { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, 0, TL, ts); }

@@ -267,3 +267,44 @@ def test_queued_sessions_share_estimator_batches(mc_state, group):
         assert np.array_equal(a, sessions[0][2]) and np.array_equal(b, sessions[2][2])
     finally:
         sep.close()
+
+
+def test_copy_stream_runs_beside_the_main_stream_on_any_handle(model):
+    """css_create deals its streams onto hardware queues by measurement (api.hip deal_streams): whatever the process
+    created before -- other handles, a torch-owned main stream -- the copy stream must not share the main stream's queue.
+    Round 3 measured what happens otherwise: the first 22 MB piece of a sharded upload "took" 14.9 ms because the event
+    behind it waited for the 784 MB that followed on the copy stream.  Here: 300 s of audio (134 MB), first piece 32
+    segments; the event behind the first piece must fire long before the rest has crossed PCIe (2.5 ms at 53 GB/s)."""
+    import torch
+    L, CSS, PAR = pkg("_lib"), pkg("css"), pkg("parallel")
+    st, desc = model
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    dev = torch.device("cuda", 0)
+    n = 300 * 16000
+    pcm = L.pinned_copy(np.zeros((n, 7), np.float32))
+    plan = L.plan(desc, run_cfg, n)
+    me = PAR.make_shard_plan(int(plan.num_segments), int(plan.mix_frames), int(plan.stft_frames), 186, 93, 256, 0, 1)
+    groups, cuts = PAR.upload_schedule(me, 186, 93, 512, n)
+    seps, worst = [], 0.0
+    try:
+        for k in range(4):
+            ts = torch.cuda.Stream(device=dev) if k % 2 else None
+            sep = pkg("separator").HipSeparator(st, None, device=0, **({"stream": int(ts.cuda_stream)} if ts is not None else {}))
+            seps.append((sep, ts))
+            h = sep.handle
+            stream = ts if ts is not None else torch.cuda.ExternalStream(h.stream_ptr(), device=dev)
+            be = PAR.HipShardBackend(h, dev, dev, torch_stream=ts) if ts is not None else PAR.HipShardBackend(h, dev, dev)
+            for rep in range(3):
+                h.sync(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                be.begin(pcm, n, 7, run_cfg, sample_range=(0, n), slice_only=False, cuts=cuts)
+                b.record(stream)
+                h.sync(); torch.cuda.synchronize()
+                if rep:
+                    worst = max(worst, a.elapsed_time(b))
+            be.close()
+        assert worst < 1.6, f"the first piece waited {worst:.2f} ms: the copy stream shares the main stream's hardware queue"
+    finally:
+        for sep, _ in seps:
+            sep.close()
