@@ -511,8 +511,19 @@ def main():
             "gather_all_rank0_download": rec_n(el_r0, max(args.steps // 2, 3), "as `value`, but rank 0 alone downloads the complete "
                                                                                "waveforms (S x n_out x 4 B over one PCIe link)"),
             "phase_ms": phase_ms,
+            # what the step time SHOULD be from its parts -- the slowest rank's segments + the three exchanges + its download
+            # (device time between events on the handle's stream, one instrumented step): a `value` well below this
+            # projection is host-side or launch-side overhead, one at it is the sum of the phases
+            "projected_from_phase_ms": {
+                "ms_per_step": phase_ms["all"]["sum_of_max_ms"],
+                "value": round(seconds / (phase_ms["all"]["sum_of_max_ms"] * 1e-3), 2),
+                "measured_over_projected": round(ms_all / max(phase_ms["all"]["sum_of_max_ms"], 1e-9), 3),
+                "largest_phase": max(zip(phase_ms["all"]["max_over_ranks_ms"], phase_ms["all"]["phases"]))[1],
+                "note": "sum over the phases of the maximum over ranks (upload of the first piece, segments, cost exchange, scan + "
+                        "mask overlap-add, activity exchange, gate + synthesis, waveform exchange, download)"},
             "collective": evidence,
             "roofline": roof,
+            "clocks": gpu_clocks(),
         })
         if rank == 0:
             # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)

@@ -94,8 +94,11 @@ typedef struct CssFeatureCfg {
  * seconds->frames conversion of css/css.py:144-152, which the host shim performs with the same
  * Python float expressions. */
 typedef struct CssRunCfg {
-    int32_t segment_frames;          /* 186  (css.py:147)                                         */
-    int32_t hop_frames;              /* 93   (css.py:148)                                         */
+    int32_t segment_frames;          /* 186  (css.py:147).  2 .. 512: PERMANENT LIMIT of this library -- the attention kernel
+                                      * keeps a query tile's scores over all keys in registers (16 key tiles), the
+                                      * feature / covariance kernels a segment's rows in LDS; segments beyond 8 s
+                                      * (the reference accepts any segment_size_sec) return CSS_ERR_INVALID_ARG       */
+    int32_t hop_frames;              /* 93   (css.py:148).  1 <= hop < segment_frames (css.py:276 needs an overlap)   */
     int32_t dilation_frames;         /* 24   (css.py:151)                                         */
     int32_t erosion_frames;          /* 12   (css.py:152)                                         */
     int32_t mc_mvdr;                 /* css.py:211                                                */

@@ -289,9 +289,13 @@ void exact_cs(int64_t k, int N, double* c, double* s) {
 // a different deal (round 3: the same 30-min pass 7 % slower on such a handle, the first 22 MB piece of a sharded upload
 // "taking" 14.9 ms because it waited for the 784 MB behind it; tools/rccl_slowdown_probe.py).  So css_create does not
 // take the streams as they come: it creates candidates, MEASURES which ones can run beside the main stream and beside each
-// other (a 200 us spin kernel on one, an empty kernel on the other), and deals them out itself: every lane on a queue of
-// its own where there are enough, none of them on the main stream's, the copy and tail streams together on another (they
-// meet anyway: uploads and transforms of the next pass, stitching and synthesis of the previous one).
+// other (a 200 us spin kernel on one, an empty kernel on the other), and deals them out itself.  With the usual four queues
+// M (the main stream's), A, B, C:  lane 1 -> A,  lane 2 -> B,  copy -> C,  tail -> B,  lane 3 -> A.  The copy stream gets a
+// queue to itself: in a queue of passes its uploads (and, for grouped passes, transforms) of pass P + 1 must run beside pass
+// P's estimator, and anything else on its queue would hold them back -- the tail of pass P, enqueued before them, starts
+// only when P's estimator ends (measured with copy and tail on one queue: 5.07 -> 5.65 ms per session).  The tail shares
+// with lane 2: grouped passes use two lanes (run_group), which leaves that queue to the tail alone; a single queued pass
+// with three lanes has its third lane start behind the previous tail, as it always did.
 __global__ void css_spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();   // constant 100 MHz
     while (wall_clock64() - t0 < ticks) {}
@@ -324,7 +328,7 @@ bool deal_streams(hipStream_t main, hipStream_t lane[4], hipStream_t* copy, hipS
         std::vector<size_t> n;
         for (auto& c : cls) n.push_back(c.size());
         std::sort(n.begin(), n.end());
-        return n[n.size() - 1] >= 3;   // one class with three streams (copy, tail, fourth lane), two more for lanes 1 and 2
+        return n[n.size() - 1] >= 2 && n[n.size() - 2] >= 2;   // two classes with two streams (lane 1 + lane 3, lane 2 + tail), one more for the copy stream
     };
     bool ok = true;
     for (int k = 0; k < 20 && ok && !enough(); ++k) {
@@ -342,7 +346,7 @@ bool deal_streams(hipStream_t main, hipStream_t lane[4], hipStream_t* copy, hipS
     std::vector<hipStream_t> take;   // lane1, lane2, copy, tail, lane3
     if (ok && !cls.empty()) {
         std::sort(cls.begin(), cls.end(), [](const std::vector<hipStream_t>& x, const std::vector<hipStream_t>& y) { return x.size() > y.size(); });
-        // cls[0]: the largest class -> copy, tail, fourth lane; the next two -> lanes 1 and 2
+        // cls[0] (two streams or more) -> lane 1, lane 3;  cls[1] -> lane 2, tail;  cls[2] -> copy
         auto pop = [&](size_t c) -> hipStream_t {
             for (size_t q = 0; q < cls.size(); ++q) {
                 auto& v = cls[(c + q) % cls.size()];
@@ -352,7 +356,13 @@ bool deal_streams(hipStream_t main, hipStream_t lane[4], hipStream_t* copy, hipS
             return nullptr;
         };
         const size_t nc = cls.size();
-        take = {pop(nc > 1 ? 1 : 0), pop(nc > 2 ? 2 : (nc > 1 ? 1 : 0)), pop(0), pop(0), pop(0)};
+        const size_t cA = 0, cB = nc > 1 ? 1 : 0, cC = nc > 2 ? 2 : cB;
+        take.resize(5);
+        take[2] = pop(cC);   // copy first: a queue of its own if there is one
+        take[0] = pop(cA);   // lane 1
+        take[1] = pop(cB);   // lane 2
+        take[3] = pop(cB);   // tail
+        take[4] = pop(cA);   // lane 3
         for (hipStream_t s_ : take) ok = ok && s_ != nullptr;
     } else {
         ok = false;
@@ -1767,6 +1777,10 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         pcm_bytes += ((size_t)grp[(size_t)j].n * grp[(size_t)j].n_ch * sizeof(float) + 255) / 256 * 256;
     }
     const int T = grp[0].cfg.segment_frames, hop = grp[0].cfg.hop_frames;
+    // a shared batch runs on at most TWO lanes: measured equal to three (profiles/r04_queue_group_ab.md), and it leaves the
+    // hardware queue the tail stream shares with lane 2 (deal_streams) to the tail alone
+    struct LaneGuard { css_ctx* h; int keep; ~LaneGuard() { h->lanes = keep; } } lane_guard{h, h->lanes};
+    h->lanes = std::min(h->lanes, 2);
     if ((rc = ensure(h, h->pcm_in, 2 * pcm_bytes)) != CSS_OK) return rc;
     if ((rc = ensure(h, h->masks, (size_t)(S + 1) * F * total * T * sizeof(float))) != CSS_OK) return rc;
     if ((rc = ensure_activations(h, total, T)) != CSS_OK) return rc;

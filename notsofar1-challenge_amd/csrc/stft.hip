@@ -48,15 +48,26 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2
 // computed from a clamped frame and not stored), so that a group of four consecutive frames of one plane row is a
 // 16-byte-aligned piece whatever range a launch covers (row_ld % 4 == 0, out 16-byte aligned): the spectrum leaves as
 // float4 stores, 8 per thread instead of 32 scalar ones -- the store phase was bound by store issue.
+// Block order: workgroup L runs on XCD L % 8, and a tile's 64-byte row pieces are HALF an L2 line -- the other half is the
+// next tile's.  Tiles dealt round robin put the two halves into two different L2s, which then write 64-byte partial lines
+// to rows that lie T_ld * 4 bytes apart (450 KB for a 30-min meeting: 1.6 TB/s there against 2.4 TB/s at 60 s, where the
+// planes never leave the Infinity Cache).  So every XCD takes a CONTIGUOUS range of the (channel, tile) space: neighbouring
+// tiles pass through one L2 back to back and leave as whole lines (and the hop-overlapped sample reads hit that L2 too).
+__device__ __forceinline__ int stft_xcd_tile(int L, int n_tiles) {
+    const int q = n_tiles >> 3, rem = n_tiles & 7, xcd = L & 7;
+    return xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
+}
+
 __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int t_lo, int t_hi,
                                                                const float* __restrict__ tab, float* __restrict__ out,
-                                                               int64_t row_ld, int wide) {
+                                                               int64_t row_ld, int wide, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
     float2* bufA = fft_lds;
     float2* twl = fft_lds + FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
     const int tid = threadIdx.x;
-    const int c = blockIdx.y;
-    const int t0 = (t_lo / FFT_TB + blockIdx.x) * FFT_TB;
+    const int item = stft_xcd_tile((int)blockIdx.x, (int)gridDim.x);   // position in the (channel, tile) space
+    const int c = item / tiles;
+    const int t0 = (t_lo / FFT_TB + (item - c * tiles)) * FFT_TB;
     const float* xc = x + (int64_t)c * x_stride;
     const float* win = tab;
     const float2* tw256 = reinterpret_cast<const float2*>(tab + FFT_N);
@@ -181,8 +192,8 @@ bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int6
         return false;
     const int tiles = (int)((t_hi + FFT_TB - 1) / FFT_TB - t_lo / FFT_TB);
     const int wide = (row_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(stft_fft_kernel, dim3(tiles, C), dim3(FFT_THREADS), lds, s, x, x_stride, (int)t_lo, (int)t_hi, tables, out,
-                       row_ld, wide);
+    hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)tiles * (unsigned)C), dim3(FFT_THREADS), lds, s, x, x_stride, (int)t_lo,
+                       (int)t_hi, tables, out, row_ld, wide, tiles);
     return true;
 }
 

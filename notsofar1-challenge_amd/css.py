@@ -25,30 +25,31 @@ from .wavio import NUM_MICS_MC, load_audio, read_wav_pcm16, write_pcm16_samples,
 _LOG = logging.getLogger('css')
 
 
-# CSS inference configuration -- field-for-field the reference's CssCfg (css/css.py:24-48)
+# CSS inference configuration: the reference's CssCfg (css/css.py:24-48) field for field -- names, types and defaults are
+# the drop-in contract (configs/inference/*.yaml are merged into it); the notes say where each one acts on the HIP path.
 @dataclass
 class CssCfg:
-    segment_size_sec: float = 3.  # in seconds
-    hop_size_sec: float = 1.5     # in seconds
-    normalize_segment_power: bool = False
-    stitching_loss: str = 'l1'  # loss function for stitching adjacent segments ('l1' or 'mse')
-    stitching_input: str = 'mask'  # type of input for stitching loss ('mask' or 'separation_result')
-    seg_weight_m0_sec: float = 0.15  # see calc_segment_weight
-    seg_weight_m1_sec: float = 0.3
-    activity_th: float = 0.4  # threshold for segmentation mask
-    activity_dilation_sec: float = 0.4  # dilation and erosion for segmentation mask
-    activity_erosion_sec: float = 0.2
-    device: Optional[str] = None
-    show_progressbar: bool = True
-    checkpoint_sc: str = 'notsofar/conformer1.0/sc'
-    checkpoint_mc: str = 'notsofar/conformer1.0/mc'
-    device_id: int = 0
-    num_spks: int = 3  # the number of streams the separation models outputs
-    mc_mvdr: bool = True  # if True, applies MVDR to the multi-channel input
-    mc_mask_floor_db: float = 0.  # mask floor in db. -inf means no floor. 0 means mask has no effect
-    sc_mask_floor_db: float = -np.inf
-    pass_through_ch0: bool = False  # if True, simply returns the first channel of the input and skips CSS
-    slice_audio_for_debug: bool = False  # if True, only processes 10 seconds of the input audio
+    segment_size_sec: float = 3.           # sliding window: length ...
+    hop_size_sec: float = 1.5              # ... and stride (css.py:144-171 -> CssRunCfg.segment_frames / hop_frames)
+    normalize_segment_power: bool = False  # rescale every separated segment to the mixture's power (css.py:233-247)
+    stitching_loss: str = 'l1'             # cost that aligns adjacent segments: 'l1' | 'mse' (css.py:263)
+    stitching_input: str = 'mask'          # what the cost compares: 'mask' | 'separation_result' (css.py:267-271)
+    seg_weight_m0_sec: float = 0.15        # overlap-add window: zero up to m0 ...
+    seg_weight_m1_sec: float = 0.3         # ... ramp up to m1 (calc_segment_weight)
+    activity_th: float = 0.4               # gate: mean mask over frequency >= this (css.py:303-304; shipped yaml: 0.3)
+    activity_dilation_sec: float = 0.4     # gate smoothing: dilate ...
+    activity_erosion_sec: float = 0.2      # ... then erode (css.py:305-308)
+    device: Optional[str] = None           # (ignored by the reference too: css.py:87)
+    show_progressbar: bool = True          # (no per-segment loop to show here)
+    checkpoint_sc: str = 'notsofar/conformer1.0/sc'   # model directory under models_dir, one microphone
+    checkpoint_mc: str = 'notsofar/conformer1.0/mc'   # ... seven microphones
+    device_id: int = 0                     # GPU the session runs on
+    num_spks: int = 3                      # output streams of the model
+    mc_mvdr: bool = True                   # multi-channel: MVDR beamformer instead of masking channel 0 (css.py:211-221)
+    mc_mask_floor_db: float = 0.           # floor of the mask applied after it, dB <= 0; 0 dB: the mask does nothing
+    sc_mask_floor_db: float = -np.inf      # ... single channel; -inf: plain mask multiplication (css.py:222-227)
+    pass_through_ch0: bool = False         # skip separation, hand channel 0 on (css.py:73-75)
+    slice_audio_for_debug: bool = False    # separate only seconds 20 .. 30 (css.py:91-92)
 
 
 def _linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
