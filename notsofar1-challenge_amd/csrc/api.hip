@@ -133,7 +133,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 0, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -1423,6 +1423,9 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     const int par = piped ? (int)(h->pass_no & 1) : 0;
     h->peak_dev = (unsigned int*)h->level.p + 8 * par;
     h->piped_now = piped;
+    // (overlapping passes alternate between the two sets of planes: a grouped pass in front of this one may still read
+    // its own on the tail stream -- run_group -- while this pass's transform writes)
+    if (piped) std::swap(h->X, h->X_alt);
     rc = begin_impl(h, n, n_ch, cfg);
     h->piped_now = false;
     if (rc != CSS_OK) return rc;
@@ -1780,7 +1783,8 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     // a shared batch runs on at most TWO lanes: measured equal to three (profiles/r04_queue_group_ab.md), and it leaves the
     // hardware queue the tail stream shares with lane 2 (deal_streams) to the tail alone
     struct LaneGuard { css_ctx* h; int keep; ~LaneGuard() { h->lanes = keep; } } lane_guard{h, h->lanes};
-    h->lanes = std::min(h->lanes, 2);
+    h->lanes = std::min(h->lanes, std::max(h->tune[CSS_TUNE_GROUP_LANES], 1));
+    const bool xf_main = h->tune[CSS_TUNE_GROUP_TRANSFORM_ON_MAIN] != 0, mvdr_lanes = h->tune[CSS_TUNE_GROUP_MVDR_ON_LANES] != 0;
     if ((rc = ensure(h, h->pcm_in, 2 * pcm_bytes)) != CSS_OK) return rc;
     if ((rc = ensure(h, h->masks, (size_t)(S + 1) * F * total * T * sizeof(float))) != CSS_OK) return rc;
     if ((rc = ensure_activations(h, total, T)) != CSS_OK) return rc;
@@ -1794,8 +1798,8 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments};
     }
     h->ev_pool_used = 0;
-    std::vector<hipEvent_t> planes((size_t)G);
-    for (int j = 0; j < G; ++j) planes[(size_t)j] = pool_event(h);
+    std::vector<hipEvent_t> planes((size_t)G), done((size_t)G);
+    for (int j = 0; j < G; ++j) { planes[(size_t)j] = pool_event(h); done[(size_t)j] = pool_event(h); }
     // ---- the overlap protocol of queued passes (run_once, `piped`)
     for (int b = 0; b < 2; ++b) {
         if (!h->pcm_free[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcm_free[b], hipEventDisableTiming));
@@ -1827,15 +1831,28 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         HIPCHK(h, hipMemcpyAsync(const_cast<float*>(h->pcm_src), q.pcm, (size_t)q.n * q.n_ch * sizeof(float), hipMemcpyHostToDevice,
                                  h->copy_stream));
         launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, q.n) * q.n_ch, h->peak_dev, h->copy_stream);
+        if (xf_main) {   // (A/B: the transforms as a prefix of the main stream)
+            HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
+            continue;
+        }
         if (h->plan.stft_frames < h->plan.mix_frames)   // short input: zero-padded frames (css.py:159-164)
             HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->copy_stream));
         if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->copy_stream)) != CSS_OK) return rc;
         h->stft_done = true;
         HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
     }
-    HIPCHK(h, hipEventRecord(h->pcm_free[par], h->copy_stream));
+    if (!xf_main) HIPCHK(h, hipEventRecord(h->pcm_free[par], h->copy_stream));
     hipEventRecord(h->ev[1], h->stream);
-    for (int j = 0; j < G; ++j) HIPCHK(h, hipStreamWaitEvent(h->stream, planes[(size_t)j], 0));
+    for (int j = 0; j < G; ++j) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, planes[(size_t)j], 0));
+        if (!xf_main) continue;
+        Active act(h, j, G);
+        if (h->plan.stft_frames < h->plan.mix_frames)
+            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->stream)) != CSS_OK) return rc;
+        h->stft_done = true;
+    }
+    if (xf_main) HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
     hipEventRecord(h->ev[2], h->stream);
     // ---- one estimator batch over all their segments (the mask head waits for the previous pass's tail: it overwrites
     // the mask buffer that tail reads)
@@ -1850,12 +1867,29 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     // costs, permutation scan, overlap-add, gate, synthesis, zero-copy overlap-add into the session's page-locked output
     hipStream_t ts = h->tail_stream;
     HIPCHK(h, hipStreamWaitEvent(ts, masks_ready, 0));
+    if (mvdr_lanes) {   // (A/B: covariances / MVDR / costs dealt over the lanes' streams, the main stream waits for them)
+        const LaneSplit ls = lane_split(h, (int)total);
+        for (int l = 1; l < ls.nl && l < G; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], masks_ready, 0));
+        for (int j = 0; j < G; ++j) {
+            Active act(h, j, G);
+            hipStream_t st = (ls.nl > 1 && j % ls.nl) ? h->lane_stream[j % ls.nl] : h->stream;
+            if ((rc = mvdr_on(h, 0, h->plan.num_segments, st)) != CSS_OK) return rc;
+            pit_costs_on(h, 0, h->plan.num_segments - 1, st);
+            HIPCHK(h, hipEventRecord(done[(size_t)j], st));
+        }
+        for (int j = 0; j < G; ++j)
+            if (ls.nl > 1 && j % ls.nl) HIPCHK(h, hipStreamWaitEvent(h->stream, done[(size_t)j], 0));
+    }
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         const css_ctx::Pending& q = grp[(size_t)j];
         const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
-        if ((rc = mvdr_on(h, 0, nseg, ts)) != CSS_OK) return rc;
-        pit_costs_on(h, 0, nseg - 1, ts);
+        if (mvdr_lanes) {
+            HIPCHK(h, hipStreamWaitEvent(ts, done[(size_t)j], 0));
+        } else {
+            if ((rc = mvdr_on(h, 0, nseg, ts)) != CSS_OK) return rc;
+            pit_costs_on(h, 0, nseg - 1, ts);
+        }
         pit_scan_on(h, 0, nseg - 1, ts);
         const StitchArgs sa = stitch_args(h);
         { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, 0, TL, ts); }
