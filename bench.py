@@ -699,8 +699,17 @@ def main():
         tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic.json")
         if os.path.exists(tj):
             with open(tj) as f:
-                roof["traffic"] = round(json.load(f)["traffic_bytes_per_launch"])
-            roof["traffic_source"] = f"profiles/{tag}_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                tr = json.load(f)
+            # the counters of the launches the profile above timed (same rows per launch), when the file has them per shape
+            key = f"M{roof.get('rows_per_launch', int(plan.num_segments) * T)}"
+            pick = tr.get(key, tr)
+            if "traffic_bytes_per_launch" in pick:
+                roof["traffic"] = round(pick["traffic_bytes_per_launch"])
+                if "algorithmic_bytes_per_launch" in pick:
+                    roof["algorithmic_bytes_per_launch"] = round(pick["algorithmic_bytes_per_launch"])
+                    roof["traffic_over_algorithmic"] = round(pick["traffic_bytes_per_launch"] / pick["algorithmic_bytes_per_launch"], 3)
+                roof["traffic_source"] = (f"profiles/{tag}_gemm_traffic.json [{key if key in tr else 'launch mix of that round'}] (rocprofv3 --pmc "
+                                          f"FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)")
             break
     result["roofline"] = roof
     # ---- the memory-bound kernel families of the same profiled pass: algorithmic bytes / live HIP-event time

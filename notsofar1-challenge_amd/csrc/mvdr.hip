@@ -67,7 +67,7 @@ constexpr int SCM_WAVES = 2;   // bins per block
 template <int NI>   // 64-frame pieces of a segment: 4 (T <= 256) or 8 (T <= 512)
 __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float scm_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (wave-uniform for the compiler: the rows' buffer descriptors live in scalar registers)
     const int k = lane >> 4, l16 = lane & 15;
     const int f = blockIdx.x * SCM_WAVES + wave, segl = blockIdx.y;
     const int64_t seg = a.seg_lo + segl;
@@ -76,13 +76,18 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     if (f >= F) return;   // (whole waves; no block-wide barrier below)
     const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
     const int64_t st = seg * (int64_t)a.hop;
-    // wave-private tile: x[14][T] (rows c: Re, 7 + c: Im), m[4][T], then the four frame lists (uint16) and 4 x 98 doubles
-    float* xs = scm_lds + (size_t)wave * ((14 + 4) * T + 2 * T + 4 * 2 * NPACK * 2);
-    float* ms = xs + 14 * T;
-    unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * T);    // [4][T]
-    double* tot = reinterpret_cast<double*>(ms + 4 * T + 2 * T);              // [4][2 * NPACK] group totals (8-byte aligned)
+    // wave-private tile: x[14][TS] (rows c: Re, 7 + c: Im), m[4][TS], TS = NI * 64 (whole 64-frame pieces, so that a piece is
+    // stored without a lane mask), then the four frame lists (uint16) and 4 x 98 doubles
+    constexpr int TS = NI * 64;
+    float* xs = scm_lds + (size_t)wave * ((14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2);
+    float* ms = xs + 14 * TS;
+    unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * TS);    // [4][TS]
+    double* tot = reinterpret_cast<double*>(ms + 4 * TS + 2 * TS);             // [4][2 * NPACK] group totals (8-byte aligned)
     // ---- the bin's rows, contiguous along time: every load of the 18 rows is in flight before the first LDS store
-    // (row by row, a wave waited out 18 memory round trips; T <= NI x 64 lanes)
+    // (row by row, a wave waited out 18 memory round trips).  Buffer loads: a row is a buffer of `tv` floats (0 for a mask
+    // row the model does not have), frames past it read as zero by the hardware's bounds check -- no lane mask, no branch
+    // per load (72 loads and stores of this phase each sat in their own exec-mask bracket: ~600 scalar instructions per
+    // wave); pieces entirely past the segment are skipped with a wave-uniform test.
     {
         float v[2 * NC + 4][NI];
 #pragma unroll
@@ -90,19 +95,16 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
             const float* src = r < 2 * NC ? a.X + ((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st
                                           : a.masks + ((int64_t)(r - 2 * NC) * F + f) * a.mask_ld + seg * (int64_t)T;
             const bool row_ok = r < 2 * NC + nm;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, row_ok ? tv * 4 : 0, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int t = lane + 64 * i;
-                v[r][i] = (row_ok && t < tv) ? src[t] : 0.f;
-            }
+            for (int i = 0; i < NI; ++i)
+                v[r][i] = (64 * i < tv) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (lane + 64 * i) * 4, 0, 0)) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 2 * NC + 4; ++r)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int t = lane + 64 * i;
-                if (t < tv) xs[r * T + t] = v[r][i];   // rows 14 .. 17 are the mask rows (ms = xs + 14 T)
-            }
+            for (int i = 0; i < NI; ++i)
+                if (64 * i < tv) xs[r * TS + lane + 64 * i] = v[r][i];   // rows 14 .. 17 are the mask rows (ms = xs + 14 TS)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
         float mv[4], mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mv[j] = (ok && j < nm) ? ms[j * T + t] : -INFINITY;
+            mv[j] = (ok && j < nm) ? ms[j * TS + t] : -INFINITY;
             mx = fmaxf(mx, mv[j]);
         }
         const int ovv = (ok && ov) ? ov[t] : -1;
@@ -126,26 +128,30 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
             // ties keep every tied mask, like mask == mask_max in the reference
             const bool win = ok && j < nm && (ov ? (ovv == j) : (mv[j] == mx));
             const unsigned long long b = __ballot(win);
-            if (win) lists[j * T + cnt[j] + __popcll(b & lt)] = (unsigned short)(t | (seen ? 0 : 0x8000));
+            if (win) lists[j * TS + cnt[j] + __popcll(b & lt)] = (unsigned short)(t | (seen ? 0 : 0x8000));
             cnt[j] += __popcll(b);
             seen |= win;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- group k walks its list
+    // ---- group k walks its list.  Two accumulator sets per lane: the weighted sum and the plain sum -- held CROSSWISE in
+    // the two halves of the group (lanes 0..7: acc = weighted, pl = plain; lanes 8..15: acc = plain, pl = weighted), so that
+    // the first step of the reduce-scatter below needs no selects: every lane keeps `acc` and receives its partner's `pl`
     double acc[NPACK], pl[NPACK];
 #pragma unroll
     for (int i = 0; i < NPACK; ++i) { acc[i] = 0.0; pl[i] = 0.0; }
     const int nk = k == 0 ? cnt[0] : (k == 1 ? cnt[1] : (k == 2 ? cnt[2] : cnt[3]));
+    const bool upper = l16 >= 8;
     for (int i = l16; i < nk; i += 16) {
-        const unsigned e = lists[k * T + i];
+        const unsigned e = lists[k * TS + i];
         const int t = e & 0x7fff;
-        const double first = (e & 0x8000) ? 1.0 : 0.0;
-        const double w = (double)ms[k * T + t] - 1e-10;
+        const double first_ = (e & 0x8000) ? 1.0 : 0.0;
+        const double w_ = (double)ms[k * TS + t] - 1e-10;
+        const double w = upper ? first_ : w_, first = upper ? w_ : first_;   // (names as in the lower half)
         double xr[NC], xi[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { xr[c] = (double)xs[c * T + t]; xi[c] = (double)xs[(NC + c) * T + t]; }
+        for (int c = 0; c < NC; ++c) { xr[c] = (double)xs[c * TS + t]; xi[c] = (double)xs[(NC + c) * TS + t]; }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const double p = xr[c] * xr[c] + xi[c] * xi[c];
@@ -173,12 +179,9 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     //   j + 49 b0 + 25 b1 + 13 b2 + 7 b3,  j = 0..6,  b0 = l16 >= 8, b1 = (l16 & 7) >= 4, b2 = bit 1, b3 = bit 0
     double v1[49], v2[25], v3[13], v4[7];
     {
-        const bool up = l16 >= 8;            // partner: 15 - l16 (row_mirror)
+        // partner: 15 - l16 (row_mirror), in the other half: its `pl` is what this lane's `acc` is (see above)
 #pragma unroll
-        for (int j = 0; j < 49; ++j) {
-            const double keep = up ? pl[j] : acc[j], send = up ? acc[j] : pl[j];
-            v1[j] = keep + dpp_get<0x140>(send);
-        }
+        for (int j = 0; j < 49; ++j) v1[j] = acc[j] + dpp_get<0x140>(pl[j]);
     }
     {
         const bool up = (l16 & 7) >= 4;      // partner: 7 - (l16 & 7) inside the half row (row_half_mirror)
@@ -233,8 +236,9 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
 }
 
 bool launch_scm(const MvdrArgs& a, hipStream_t s) {
-    // per wave: 18 rows of T floats, 4 lists of T uint16 (= 2 T floats), 4 x 98 doubles
-    const size_t per_wave = ((size_t)(14 + 4) * a.T + 2 * a.T + 4 * 2 * NPACK * 2) * sizeof(float);
+    // per wave: 18 rows of TS floats, 4 lists of TS uint16 (= 2 TS floats), 4 x 98 doubles; TS = 256 or 512
+    const int TS = a.T <= 256 ? 256 : 512;
+    const size_t per_wave = ((size_t)(14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2) * sizeof(float);
     const dim3 grid((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), block(64 * SCM_WAVES);
     if (a.T <= 256) {
         hipLaunchKernelGGL(scm_kernel<4>, grid, block, per_wave * SCM_WAVES, s, a);

@@ -39,19 +39,67 @@ for k, r in m.iterrows():
     print(f"| `{k}` | {int(r['n'])} | {r['dur_us']:.1f} | {r['clk_GHz']:.2f} | {100 * r['mfma_util']:.1f}% | {100 * r['wait_frac']:.0f}% | "
           f"{r['fetch_MB']:.1f} | {r['write_MB']:.1f} | {r['hbm_GBps_raw']:.0f} | {r['hbm_GBps_fetch_x2']:.0f} |")
 
-# HBM traffic per launch of the dominant kernel for bench.py's roofline.traffic (FETCH_SIZE doubled as the guide
-# prescribes for gfx950's wide reads, + WRITE_SIZE), launch-weighted over the Linear-layer GEMM instantiations
-import json, os
-# (the full-batch launches of bench.py's single-lane profile pass, which is what roofline.achieved is measured on:
-#  117 row tiles x N / 128 column tiles = 468 / 936 / 1404 workgroups; the three-lane launches have a third of that)
-g = m[m.index.str.contains("gemm_split_wd_kernel", regex=False) & (m.index.str.extract(r"g=(\d+)", expand=False).astype(float) >= 400)]
-if len(g):
-    wgt = g["n"]
-    out = {"kernel": "css::gemm_split_wd_kernel", "launches": int(wgt.sum()),
-           "fetch_bytes_raw": float((g["fetch_kb"] * 1024 * wgt).sum() / wgt.sum()),
-           "write_bytes": float((g["write_kb"] * 1024 * wgt).sum() / wgt.sum()),
-           "traffic_bytes_per_launch": float(((2 * g["fetch_kb"] + g["write_kb"]) * 1024 * wgt).sum() / wgt.sum()),
+# HBM traffic per launch of the dominant kernel for bench.py's roofline.traffic (FETCH_SIZE doubled as the guide prescribes
+# for gfx950's wide reads, + WRITE_SIZE), PER LAUNCH SHAPE, beside the algorithmic bytes of that shape (VERDICT r3 #7/#10:
+# `traffic` and `achieved` must describe the same launches).  A launch of the weights-direct kernel has
+# ceil(M / 64) x (N / 128) workgroups; the rows M a bench run can produce are known (a 60 s meeting has 40 segments of 186
+# frames: 2 480 rows per lane of three, 7 440 alone, 11 160 per lane of a two-lane batch shared by three queued sessions,
+# 22 320 for that batch on one lane -- the per-launch profile), so (M, N) follows from the workgroup count; the N = 512
+# class mixes K = 512 (attention output, x18), 1024 (feed-forward down, x36) and 1824 (embedding, x1) per pass.
+import json, os, re
+
+
+def algorithmic_bytes(M, N):
+    f = 4.0
+    if N == 1024:   # feed-forward up: A [M, 512], W [1024, 512], C [M, 1024] (split rows: same bytes)
+        return M * 512 * f + N * 512 * f + M * N * f
+    if N == 1536:   # QKV
+        return M * 512 * f + N * 512 * f + M * N * f
+    # N = 512: attention output (+ residual), feed-forward down (+ residual), embedding
+    wo = M * 512 * f + N * 512 * f + 2 * M * N * f
+    dn = M * 1024 * f + N * 1024 * f + 2 * M * N * f
+    em = M * 1824 * f + N * 1824 * f + M * N * f
+    return (18 * wo + 36 * dn + em) / 55.0
+
+
+rows_known = {2480: "one lane of three, 60 s meeting alone", 7440: "60 s meeting alone, one lane (per-launch profile of a single session)",
+              11160: "one lane of two, three queued sessions sharing the batch (the headline's launches)",
+              22320: "three queued sessions sharing the batch, one lane (the headline's per-launch profile)"}
+g = m[m.index.str.contains("gemm_split_wd_kernel", regex=False)].copy()
+shapes = []
+for k, r in g.iterrows():
+    wg = int(re.search(r"g=(\d+)", k).group(1))
+    hit = [(M, N) for M in rows_known for N in (512, 1024, 1536) if -(-M // 64) * (N // 128) == wg]
+    if len(hit) != 1:
+        continue   # (ambiguous or another workload's shape)
+    M, N = hit[0]
+    traffic = (2 * r["fetch_kb"] + r["write_kb"]) * 1024
+    alg = algorithmic_bytes(M, N)
+    shapes.append({"rows_M": M, "cols_N": N, "workgroups": wg, "launches": int(r["n"]), "avg_us": round(float(r["dur_us"]), 2),
+                   "fetch_bytes_raw": float(r["fetch_kb"] * 1024), "write_bytes": float(r["write_kb"] * 1024),
+                   "traffic_bytes": float(traffic), "algorithmic_bytes": float(alg), "traffic_over_algorithmic": round(float(traffic / alg), 3),
+                   "what": rows_known[M]})
+if shapes:
+    print("\n## Linear-layer GEMM: HBM traffic per launch shape against the shape's algorithmic bytes\n")
+    print("| rows M | cols N | workgroups | launches | avg us | traffic MB (FETCH x2 + WRITE) | algorithmic MB | ratio |")
+    print("|---:|---:|---:|---:|---:|---:|---:|---:|")
+    for q in sorted(shapes, key=lambda q: (q["rows_M"], q["cols_N"])):
+        print(f"| {q['rows_M']} | {q['cols_N']} | {q['workgroups']} | {q['launches']} | {q['avg_us']} | {q['traffic_bytes'] / 1e6:.1f} | "
+              f"{q['algorithmic_bytes'] / 1e6:.1f} | {q['traffic_over_algorithmic']} |")
+    # per-launch average over one estimator pass (55 / 36 / 18 launches of the three classes), for the profile's launches
+    out = {"kernel": "css::gemm_split_wd_kernel", "shapes": shapes,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 per MI355X_MICROARCH.md"}
+    for M in (22320, 7440):
+        cls = {q["cols_N"]: q for q in shapes if q["rows_M"] == M}
+        if len(cls) == 3:
+            wgt = {512: 55, 1024: 36, 1536: 18}
+            out[f"M{M}"] = {"traffic_bytes_per_launch": sum(cls[N]["traffic_bytes"] * wgt[N] for N in wgt) / 109.0,
+                           "algorithmic_bytes_per_launch": sum(cls[N]["algorithmic_bytes"] * wgt[N] for N in wgt) / 109.0}
+    best = out.get("M22320") or out.get("M7440")
+    if best:
+        out["traffic_bytes_per_launch"] = best["traffic_bytes_per_launch"]
+        out["algorithmic_bytes_per_launch"] = best["algorithmic_bytes_per_launch"]
+        out["rows_of_those_launches"] = 22320 if "M22320" in out else 7440
     dst = os.environ.get("CSS_TRAFFIC_JSON")
     if dst:
         with open(dst, "w") as f:
