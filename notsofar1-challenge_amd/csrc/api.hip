@@ -2044,13 +2044,19 @@ int css_wait(css_handle_t h) {
             return fail(h, CSS_ERR_RANGE, "an operand of a Linear layer left the split-f16 range in one of the queued passes "
                                           "(|x| > 65504): use CSS_LINEAR_EXACT_F32");
         int rc = css_set_linear_mode(h, CSS_LINEAR_EXACT_F32);
-        for (size_t i = 0; i < log.size() && rc == CSS_OK; ++i) {
-            RunIo io; io.pcm_host = log[i].pcm; io.wav_host = log[i].wav; io.cap = log[i].cap;
-            rc = run_once(h, log[i].n, log[i].n_ch, &log[i].cfg, io);
+        size_t repeated = 0;
+        for (; repeated < log.size() && rc == CSS_OK; ++repeated) {
+            const css_ctx::QueuedPass& q = log[repeated];
+            RunIo io; io.pcm_host = q.pcm; io.wav_host = q.wav; io.cap = q.cap;
+            rc = run_once(h, q.n, q.n_ch, &q.cfg, io);
         }
+        const std::string why = h->err;
         const int rc2 = css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16);
-        h->range_fallbacks += (int64_t)log.size();
-        return rc != CSS_OK ? rc : rc2;
+        h->range_fallbacks += (int64_t)repeated;
+        if (rc != CSS_OK)   // (which outputs are float32 results and which still hold the overflowed split-f16 ones)
+            return fail(h, rc, "float32 repeat of the queued sessions stopped at session " + std::to_string(repeated - 1) + " of " +
+                                   std::to_string(log.size()) + " (sessions before it hold their float32 results, it and the later ones do not): " + why);
+        return rc2;
     }
     return CSS_OK;
 }
