@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A queue of sessions on one GPU (css_run_enqueue / css_wait): every session goes from float PCM in page-locked host
-memory to separated waveforms in page-locked host memory; a session's PCIe legs run under its neighbours' kernels.
+memory to separated waveforms in page-locked host memory; a session's PCIe legs run under its neighbours' kernels, and
+consecutive sessions share mask-estimator batches (up to max_batch_segments segments per batch).
 
     python examples/session_queue.py [n_sessions]"""
 import importlib, os, sys, time
@@ -23,6 +24,9 @@ for k in range(n_sessions):
     plan = _lib.plan(desc, run_cfg, pcm.shape[0])
     sessions.append((pcm, _lib.pinned_empty((3, int(plan.n_out)), np.float32)))
 h.run(max((p for p, _ in sessions), key=lambda p: p.shape[0]), run_cfg)   # warm-up: buffers sized for the longest session
+for pcm, out in sessions:                                            # ... and one untimed queue: the handle allocates the
+    h.run_enqueue(pcm, run_cfg, out)                                 # per-session buffers of a shared batch on first use
+h.wait()
 
 t0 = time.perf_counter()
 views = [h.run_enqueue(pcm, run_cfg, out) for pcm, out in sessions]  # returns at once

@@ -50,6 +50,9 @@ struct Weights {
 };
 
 inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
+// X holds the planes [C][2F][T_ld] (Re | Im) and, behind them, the phase planes [C][F][T_ld] the analysis transform writes
+// with them (kernels.hpp launch_stft_fft): one allocation, so that whatever swaps or re-sizes X takes the phases along
+constexpr int X_ROWS_PER_BIN = 3;
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -65,6 +68,7 @@ struct SessState {
     int n_ch = 0;
     int64_t n_pad = 0, T_ld = 0;
     bool stft_done = false, perms_done = false, have_override = false;
+    bool ph_valid = false;       // the phase planes behind X belong to X (false after css_write_buffer(CSS_BUF_X): the feature kernel forms them itself)
     std::vector<float> w_host;   // segment weights of the session (cfg.w_* point into it)
     DevBuf pcm_cm, X, scm, bfw, sep, costs, perms, mask_st, activity, act_b, act_tmp, act_final, Y, G, wav, wta, pnorm, pit_part;
     DevBuf X_alt;   // run_group: consecutive grouped passes alternate between X and X_alt (the beamformer of pass P reads its
@@ -780,7 +784,8 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     if (!h->piped_now) HIPCHK(h, hipMemsetAsync(h->peak_dev, 0, sizeof(unsigned int), h->stream));
     if (!h->queued) HIPCHK(h, hipMemsetAsync(h->range_flag_dev, 0, sizeof(unsigned int), h->stream));   // queued passes accumulate
     ENS(pcm_cm, (size_t)n_ch * h->n_pad * sizeof(float))
-    ENS(X, (size_t)n_ch * 2 * F * h->T_ld * sizeof(float))
+    ENS(X, (size_t)n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float))
+    h->ph_valid = false;
     if ((rc = ensure_activations(h, std::min<int64_t>(h->max_batch, nseg), T)) != CSS_OK) return rc;
     ENS(masks, (size_t)(S + 1) * F * nseg * T * sizeof(float))
     ENS(scm, (size_t)nseg * (S + 1) * F * 49 * sizeof(double))
@@ -904,8 +909,10 @@ static int stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* pl
         else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
     }
     CSS_PROF(CSS_PROF_STFT, st);
-    if (!launch_stft_fft((const float*)h->pcm_cm.p, h->n_pad, h->n_ch, t_lo, f_hi, h->stft_tab, (float*)h->X.p, h->T_ld, st))
+    if (!launch_stft_fft((const float*)h->pcm_cm.p, h->n_pad, h->n_ch, t_lo, f_hi, h->stft_tab, (float*)h->X.p, h->T_ld, st,
+                         (float*)h->X.p + (int64_t)h->n_ch * 2 * F * h->T_ld))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
+    h->ph_valid = true;
     (void)F;
     return CSS_OK;
 }
@@ -918,7 +925,7 @@ int css_stage_stft_range(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     HIPCHK(h, hipSetDevice(h->device));
     const int F = h->d.num_bins;
     if (h->plan.stft_frames < h->plan.mix_frames && !h->stft_done)  // short input: zero-padded frames (css.py:159-164)
-        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->stream));
     {   // pieces of the recording still crossing PCIe (css_upload_range): wait for the ones these frames read
         const int64_t f_hi = std::min<int64_t>(t_hi, h->plan.stft_frames);
         const int64_t i_lo = t_lo * h->d.frame_hop, i_hi = f_hi > t_lo ? (f_hi - 1) * h->d.frame_hop + h->d.frame_len : i_lo;
@@ -939,13 +946,14 @@ int css_stage_stft(css_handle_t h) {
 }
 
 // Where one batched pass of the mask estimator reads its spectra and writes its masks.
-struct GroupSess { const float* X; int64_t T_ld, stft_frames; int64_t off; int n; };   // a session's planes; its segments are the batch's [off, off + n)
+struct GroupSess { const float* X; int64_t T_ld, stft_frames; int64_t off; int n; const float* PH; };   // a session's planes (+ phase planes); its segments are the batch's [off, off + n)
 struct MaskIo {
     const float* X; int64_t T_ld; int64_t stft_frames; int hop; int T;   // planes [C][2F][T_ld], segment s at s*hop
     float* masks; int64_t mask_ld;                                       // [(S+1)F][mask_ld], segment s at column s*T
     // a batch over the segments of SEVERAL sessions (run_group): the features of batch segment c come from the session
     // that holds it, everything behind them is one [segments * T, .] problem; X / T_ld / stft_frames above are unused
     const std::vector<GroupSess>* group = nullptr;
+    const float* PH = nullptr;   // phase planes [C][F][T_ld] beside X (nullptr: the feature kernel forms the phases itself)
 };
 
 // The mask estimator over `nb` segments starting at `s0` on one lane (stream + activation set), phases [ph_lo, ph_hi):
@@ -979,12 +987,12 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
                 if (hi <= lo) continue;
                 CSS_PROF(CSS_PROF_FEATURES, st);
                 launch_features(gs.X, gs.T_ld, gs.stft_frames, d.num_mics, F, feat + (lo - s0) * (int64_t)T * h->Kp, h->Kp, W.input_bias,
-                                W.input_scale, lo - gs.off, (int)(hi - lo), T, io.hop, sp, h->feat_opts, st);
+                                W.input_scale, lo - gs.off, (int)(hi - lo), T, io.hop, sp, h->feat_opts, st, gs.PH);
             }
         } else {
             CSS_PROF(CSS_PROF_FEATURES, st);
             launch_features(io.X, io.T_ld, io.stft_frames, d.num_mics, F, feat, h->Kp, W.input_bias, W.input_scale, s0, nb, T,
-                            io.hop, sp, h->feat_opts, st);
+                            io.hop, sp, h->feat_opts, st, io.PH);
         }
         // embed: Linear -> LayerNorm -> ReLU (conformer.py:205-210)
         gemm(h, lin(feat, h->Kp, W.embed_w, W.embed_b, u, D, D, h->Kp, ACT_NONE, 0), st);
@@ -1138,6 +1146,7 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     const int T = h->cfg.segment_frames;
     const int64_t cap = batch_len(seg_hi - seg_lo, std::min<int64_t>(h->max_batch, h->plan.num_segments));
     MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, h->masks_v, h->mask_ld_v};
+    io.PH = h->ph_valid ? (const float*)h->X.p + (int64_t)h->n_ch * 2 * h->d.num_bins * h->T_ld : nullptr;
     for (int64_t s0 = seg_lo; s0 < seg_hi; s0 += cap) {
         const int nb = (int)std::min<int64_t>(cap, seg_hi - s0);
         if ((rc = masknet_batch(h, io, s0, nb)) != CSS_OK) return rc;
@@ -1552,7 +1561,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->tail_stream);
     }
     if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
-        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->stream));
 
     // ---- the tail of unit `k` (all earlier tails are already enqueued on the tail stream)
     const int64_t halo = h->cfg.dilation_frames + h->cfg.erosion_frames;
@@ -1637,6 +1646,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
 
     // ---- the estimator, unit by unit; each lane appends the beamformer of its own segments
     MaskIo mio{(const float*)h->X.p, h->T_ld, pl.stft_frames, hop, T, h->masks_v, h->mask_ld_v};
+    mio.PH = (const float*)h->X.p + (int64_t)h->n_ch * 2 * F * h->T_ld;   // (every frame a segment reads was transformed in this pass)
     size_t ui = 0;
     const LanePrep prep = [&](int64_t seg_lo, int cnt, hipStream_t st) -> int {
         Unit& u = units[ui];
@@ -1795,7 +1805,8 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         h->pcm_src = (const float*)(pcm_base + pcm_off[(size_t)j]);
         h->masks_v = (float*)h->masks.p + off[(size_t)j] * T;
         h->mask_ld_v = total * T;
-        gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments};
+        gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments,
+                                  (const float*)h->X.p + (int64_t)h->n_ch * 2 * F * h->T_ld};
     }
     h->ev_pool_used = 0;
     std::vector<hipEvent_t> planes((size_t)G), done((size_t)G);
@@ -1836,7 +1847,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
             continue;
         }
         if (h->plan.stft_frames < h->plan.mix_frames)   // short input: zero-padded frames (css.py:159-164)
-            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->copy_stream));
+            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->copy_stream));
         if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->copy_stream)) != CSS_OK) return rc;
         h->stft_done = true;
         HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
@@ -1848,7 +1859,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         if (!xf_main) continue;
         Active act(h, j, G);
         if (h->plan.stft_frames < h->plan.mix_frames)
-            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * 2 * F * h->T_ld * sizeof(float), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->stream));
         if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->stream)) != CSS_OK) return rc;
         h->stft_done = true;
     }
@@ -2358,23 +2369,25 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     const int64_t TT = (int64_t)batch * T;
     const int64_t n_pad = (n_samples + 31) / 32 * 32;
     const size_t in_f = (size_t)batch * n_samples * C, cm_f = (size_t)batch * C * n_pad;
-    const size_t x_f = (size_t)C * 2 * F * TT, m_f = (size_t)nm * F * TT;
+    const size_t x_f = (size_t)C * 2 * F * TT, ph_f = (size_t)C * F * TT, m_f = (size_t)nm * F * TT;
     int rc;
-    if ((rc = ensure(h, h->stage, (in_f + cm_f + x_f + m_f + extra_floats + 128) * sizeof(float))) != CSS_OK) return rc;
+    if ((rc = ensure(h, h->stage, (in_f + cm_f + x_f + ph_f + m_f + extra_floats + 160) * sizeof(float))) != CSS_OK) return rc;
     float* in = (float*)h->stage.p;
     float* cm = in + (in_f + 15) / 16 * 16;
     float* X = cm + (cm_f + 15) / 16 * 16;
-    float* M = X + (x_f + 15) / 16 * 16;
+    float* PH = X + (x_f + 15) / 16 * 16;
+    float* M = PH + (ph_f + 15) / 16 * 16;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
     for (int b = 0; b < batch; ++b) {
         // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
         launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
-        if (!launch_stft_fft(cm + (size_t)b * C * n_pad, n_pad, C, 0, T, h->stft_tab, X + (int64_t)b * T, TT, h->stream))
+        if (!launch_stft_fft(cm + (size_t)b * C * n_pad, n_pad, C, 0, T, h->stft_tab, X + (int64_t)b * T, TT, h->stream, PH + (int64_t)b * T))
             return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     }
     const int64_t cap = std::min<int64_t>(h->max_batch, batch);
     if ((rc = ensure_activations(h, cap, T)) != CSS_OK) return rc;
     MaskIo io{X, TT, TT, T, T, M, TT};  // clip b is the "segment" starting at frame b*T
+    io.PH = PH;
     for (int64_t s0 = 0; s0 < batch; s0 += cap)
         if ((rc = masknet_batch(h, io, s0, (int)std::min<int64_t>(cap, batch - s0))) != CSS_OK) return rc;
     *Xo = X; *Mo = M; *To = T;
@@ -2672,6 +2685,7 @@ int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes
     if (which == CSS_BUF_MASKS) h->masks_v = (float*)h->masks.p;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(b->p, host, (size_t)need, hipMemcpyHostToDevice));
+    if (which == CSS_BUF_X) h->ph_valid = false;   // (the planes no longer come from the transform: phases are formed in the feature kernel)
     if (which == CSS_BUF_WTA_OVERRIDE) h->have_override = true;
     if (which == CSS_BUF_PERMS) h->perms_done = true;
     return CSS_OK;

@@ -176,19 +176,14 @@ void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_
 // IPD feature depends on that (DESIGN.md "Numerical hazards").  PHASE_NEG_REAL is that value.
 // ------------------------------------------------------------------------------------------------
 // FEAT_TMAX: segment lengths an instantiation covers (256: up to 4 s, the shipped 3 s; 512: up to 8 s)
-#define CSS_PHASE_NEG_REAL (-3.14159250259399414f) /* 0xC0490FDA */
 #define CSS_EPS32 1.1920928955078125e-07f
-
-__device__ __forceinline__ float phase_of(float re, float im) {
-    return (im == 0.f && re < 0.f) ? CSS_PHASE_NEG_REAL : atan2f(im, re);
-}
 
 template <int FEAT_TMAX>
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, int64_t T_ld, int64_t stft_frames,
                                                        int F, float* __restrict__ feat, int Kp,
                                                        const float* __restrict__ in_bias,
                                                        const float* __restrict__ in_scale, int64_t seg_lo, int T,
-                                                       int hop, int split_out, FeatOpts o) {
+                                                       int hop, int split_out, FeatOpts o, const float* __restrict__ PH) {
     constexpr int FEAT_LD = FEAT_TMAX + 1;
     __shared__ float tile[32 * FEAT_LD];
     // blockIdx.y = 0: the spectral rows (microphone 0); y >= 1: IPD pair y - 1 = phase[ml] - phase[mr]
@@ -209,14 +204,23 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
         const float* im0 = X + ((int64_t)mr * 2 * F + F + f_) * T_ld + st;
         const float* rem = X + ((int64_t)ml * 2 * F + f_) * T_ld + st;       // the pair's left microphone
         const float* imm = X + ((int64_t)ml * 2 * F + F + f_) * T_ld + st;
+        // (with phase planes an IPD block reads the two phases of its pair -- n_rm: left, n_im: right -- instead of four planes)
+        const float* phl = PH ? PH + ((int64_t)ml * F + f_) * T_ld + st : nullptr;
+        const float* phr = PH ? PH + ((int64_t)mr * F + f_) * T_ld + st : nullptr;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int t = lane + 64 * i;
             const bool ok = t < tv;   // (tv <= T)
-            n_r0[i] = ok ? re0[t] : 0.f;
-            n_i0[i] = ok ? im0[t] : 0.f;
-            n_rm[i] = (ok && m != 0) ? rem[t] : 0.f;
-            n_im[i] = (ok && m != 0) ? imm[t] : 0.f;
+            if (PH && m != 0) {
+                n_r0[i] = 0.f; n_i0[i] = 0.f;
+                n_rm[i] = ok ? phl[t] : 0.f;
+                n_im[i] = ok ? phr[t] : 0.f;
+            } else {
+                n_r0[i] = ok ? re0[t] : 0.f;
+                n_i0[i] = ok ? im0[t] : 0.f;
+                n_rm[i] = (ok && m != 0) ? rem[t] : 0.f;
+                n_im[i] = (ok && m != 0) ? imm[t] : 0.f;
+            }
         }
     };
     fetch(0);
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                     s0 += a[i];
                 } else {
                     const float rm = c_rm[i], imv = c_im[i];
-                    const float d = phase_of(rm, imv) - phase_of(r0, i0);
+                    // (zero-padded frames: both phases 0, as css_phase_of(0, 0))
+                    const float d = PH ? rm - imv : css_phase_of(rm, imv) - css_phase_of(r0, i0);
                     dd[i] = d;
                     a[i] = cosf(d);
                     bq[i] = sinf(d);
@@ -318,15 +323,15 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     int split_out, const FeatOpts& opts, hipStream_t s) {
+                     int split_out, const FeatOpts& opts, hipStream_t s, const float* PH) {
     (void)C;
     const dim3 grid((F + 31) / 32, 1 + opts.num_pairs, nseg), block(256);
     if (T <= 256)
         hipLaunchKernelGGL(features_kernel<256>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out, opts);
+                           seg_lo, T, hop, split_out, opts, PH);
     else
         hipLaunchKernelGGL(features_kernel<512>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out, opts);
+                           seg_lo, T, hop, split_out, opts, PH);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -102,8 +102,20 @@ size_t stft_table_floats();
 void stft_build_tables(float* host);   // window | radix-4 twiddles | real-spectrum twiddles
 // frames 0 .. nf-1 of C channels (channel c's first sample at x + c * x_stride, frame t at sample 256 t) -> planes
 // out[(c * 514 + r) * row_ld + t], r = f (Re) / 257 + f (Im).  false: the kernel's LDS could not be reserved.
+// phase != nullptr: also the PHASE planes phase[(c * 257 + f) * row_ld + t] = css_phase_of(Re, Im) -- the angle the IPD
+// features are made of (feature.py:214-221), formed once per frame here instead of once per segment and microphone pair in
+// the feature kernel (a frame lies in two segments, microphone 0 in six pairs: 18 atan2 per feature element became 6 + 7/2).
 bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
-                     int64_t row_ld, hipStream_t s);
+                     int64_t row_ld, hipStream_t s, float* phase = nullptr);
+
+// Phase of a spectrum value as the reference reaches it.  An exactly real negative bin (DC / Nyquist have Im == +0 by
+// construction of the transform) goes through polar() -> angle() in the reference (conformer_wrapper.py:124,94), which
+// maps it to the float32 value just inside -pi; the side of the atan2 branch cut of the IPD feature depends on that
+// (DESIGN.md "Numerical hazards").  CSS_PHASE_NEG_REAL is that value.
+#define CSS_PHASE_NEG_REAL (-3.14159250259399414f) /* 0xC0490FDA */
+__device__ __forceinline__ float css_phase_of(float re, float im) {
+    return (im == 0.f && re < 0.f) ? CSS_PHASE_NEG_REAL : atan2f(im, re);
+}
 
 // ------------------------------------------------------------------------------------------------
 // frontend.hip -- PCM layout, features, inverse-transform overlap-add
@@ -128,9 +140,11 @@ struct FeatOpts {   // CssFeatureCfg in kernel-argument form
     int log_mag, mvn, ipd_norm, ipd_version, ipd_cos, num_pairs;
     unsigned char pair_l[16], pair_r[16];
 };
+// PH: the phase planes launch_stft_fft wrote beside X (same T_ld), or nullptr: the kernel forms the phases itself (same
+// function on the same values: the features are the same bits either way)
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
-                     int split_out, const FeatOpts& opts, hipStream_t s);
+                     int split_out, const FeatOpts& opts, hipStream_t s, const float* PH = nullptr);
 // out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
 // only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
 // level (may be null): the samples are multiplied by 1 / level_gain(level) (undoes the scaling of the split spectra rows)

@@ -60,7 +60,7 @@ __device__ __forceinline__ int stft_xcd_tile(int L, int n_tiles) {
 
 __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int t_lo, int t_hi,
                                                                const float* __restrict__ tab, float* __restrict__ out,
-                                                               int64_t row_ld, int wide, int tiles) {
+                                                               int64_t row_ld, int wide, int tiles, float* __restrict__ phase) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
     float2* bufA = fft_lds;
     float2* twl = fft_lds + FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
         }
     };
     float* oc = out + (int64_t)c * 2 * F * row_ld + t0;
+    float* pc = phase ? phase + (int64_t)c * F * row_ld + t0 : nullptr;
     if (wide) {
         // a thread owns one bin row of a four-frame group: lanes 0..3 cover the tile's 64 bytes of that row
         const int g4 = (tid & 3) * 4;
@@ -158,13 +159,20 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
             for (int q = 0; q < 4; ++q) bin(g4 + q, f, w5, re[q], im[q]);
             float* pr = oc + (int64_t)f * row_ld + g4;
             float* pi = oc + (int64_t)(F + f) * row_ld + g4;
+            float* pp = pc ? pc + (int64_t)f * row_ld + g4 : nullptr;
             if (all_in) {
                 *reinterpret_cast<float4*>(pr) = make_float4(re[0], re[1], re[2], re[3]);
                 *reinterpret_cast<float4*>(pi) = make_float4(im[0], im[1], im[2], im[3]);
+                if (pp)
+                    *reinterpret_cast<float4*>(pp) = make_float4(css_phase_of(re[0], im[0]), css_phase_of(re[1], im[1]),
+                                                                 css_phase_of(re[2], im[2]), css_phase_of(re[3], im[3]));
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (ta + q >= t_lo && ta + q < t_hi) { pr[q] = re[q]; pi[q] = im[q]; }
+                    if (ta + q >= t_lo && ta + q < t_hi) {
+                        pr[q] = re[q]; pi[q] = im[q];
+                        if (pp) pp[q] = css_phase_of(re[q], im[q]);
+                    }
             }
         }
     } else {
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
             if (store) {
                 oc[(int64_t)f * row_ld + tl] = re;
                 oc[(int64_t)(F + f) * row_ld + tl] = im;
+                if (pc) pc[(int64_t)f * row_ld + tl] = css_phase_of(re, im);
             }
         }
     }
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
 
 // frames [t_lo, t_hi) of C channels; x and out are the bases of frame 0
 bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
-                     int64_t row_ld, hipStream_t s) {
+                     int64_t row_ld, hipStream_t s, float* phase) {
     if (t_hi <= t_lo || C <= 0) return true;
     const size_t lds = ((size_t)FFT_TB * FFT_FS + FFT_H) * sizeof(float2);   // 34.9 KB
     // (the attribute is per device: set it on every launch -- a host-side table lookup -- rather than behind a
@@ -193,7 +202,7 @@ bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int6
     const int tiles = (int)((t_hi + FFT_TB - 1) / FFT_TB - t_lo / FFT_TB);
     const int wide = (row_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)tiles * (unsigned)C), dim3(FFT_THREADS), lds, s, x, x_stride, (int)t_lo,
-                       (int)t_hi, tables, out, row_ld, wide, tiles);
+                       (int)t_hi, tables, out, row_ld, wide, tiles, phase);
     return true;
 }
 
