@@ -154,8 +154,10 @@ def hbm_kernel_bytes(plan, desc, T, hop, n):
     masks_seg = (S + 1) * F * T * 4
     return {
         "deinterleave": 2 * n * C * 4,
-        "stft": n * C * 4 + C * 2 * F * TL * 4,
-        "features": nseg * (planes_seg + T * Kp * 4),
+        # (round 4: the transform also writes one phase plane per microphone; a segment's features read the two planes of
+        #  microphone 0 for the magnitude rows and the C phase planes for the IPD rows instead of all 2 C planes)
+        "stft": n * C * 4 + C * 3 * F * TL * 4,
+        "features": nseg * ((2 + C) * F * T * 4 + T * Kp * 4),
         "scm": nseg * (planes_seg + masks_seg + (S + 1) * F * 49 * 8),
         "mvdr_solve": nseg * ((S + 1) * F * 49 * 8 + S * F * C * 16),
         "beamform": nseg * (planes_seg + S * F * C * 16 + S * F * T * 4 + S * F * T * 8),

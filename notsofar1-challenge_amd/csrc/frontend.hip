@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                     // (zero-padded frames: both phases 0, as css_phase_of(0, 0))
                     const float d = PH ? rm - imv : css_phase_of(rm, imv) - css_phase_of(r0, i0);
                     dd[i] = d;
-                    a[i] = cosf(d);
-                    bq[i] = sinf(d);
+                    sincosf(d, &bq[i], &a[i]);   // (one argument reduction for both; the same values as sinf / cosf)
                     s0 += a[i];
                     s1 += bq[i];
                     s2 += d;

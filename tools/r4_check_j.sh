@@ -1,0 +1,12 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_feature_options.py tests/test_hip_golden_r2.py tests/test_hip_lanes.py -m gpu -q --timeout 400 2>&1 | tail -6 ) > gpurun_out/r4j.txt
+( timeout 500 python bench.py --steps 20 --warmup 3 --no-long --no-cpu-baseline > gpurun_out/r4j_bench.json 2> gpurun_out/r4j_bench.err ); echo "bench rc=$?" >> gpurun_out/r4j.txt
+cat gpurun_out/r4j.txt
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r4j_bench.json").read().strip().splitlines()[-1])
+r=d["roofline"]; print(d["value"], d["ms_per_step"], r["frac"], "dev", d["device_resident"]["ms_per_step"])
+print("hbm", [(x["kernel"], x["us"], x["frac"]) for x in d["roofline_hbm"]])
+PY
