@@ -14,6 +14,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# torch is imported HERE, once, before any test runs: the first `import torch` on a fresh GPU box pages the wheel in and can
+# take minutes; inside a test it counts against that test's --timeout, and an import interrupted by the timeout leaves a
+# half-initialised module behind whose re-import crashes the interpreter (seen once: a segmentation fault in the NEXT test).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover  (the CPU-only oracle tests do not need it)
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
