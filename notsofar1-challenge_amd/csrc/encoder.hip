@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256 * NV * HV) void conv_module_kernel(const float*
     // launch on 256 CUs), so the block is made wide, not numerous.
     constexpr int D = 256 * NV, PAD = (TAPS - 1) / 2, ROWS = RUN + TAPS - 1, NW = 4 * NV * HV, JH = (RUN + HV - 1) / HV;
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [ROWS][D]
-    const int seg = blockIdx.x / runs_per_seg, run = blockIdx.x % runs_per_seg;
+    // (XCD-contiguous order: neighbouring runs of a segment read each other's frames as halo -- behind one L2 the second
+    //  reader hits; dealt round robin over the XCDs every run fetched its 32 halo frames from the fabric again)
+    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);
+    const int seg = item / runs_per_seg, run = item % runs_per_seg;
     const int t0 = run * RUN;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3];
@@ -420,7 +423,7 @@ template <int NJT, bool QKS, bool FRAG>
 __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
                                                          const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen,
-                                                         int split_out) {
+                                                         int split_out, int heads) {
     constexpr int DK = 64;
     // The position term lives in an LDS ring of three 32-offset tiles per query row (row stride 98 floats:
     // the skewed reads of 32 lanes land on addresses 3c + const (mod 32), i.e. 32 distinct banks).  A key tile
@@ -428,7 +431,13 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
     // the ring replaces the full [32][217] table (29 KB, 5 waves per CU) by 12.5 KB (register-limited 8 per CU).
     constexpr int LDR = 98;
     __shared__ __attribute__((aligned(16))) float lds[32 * LDR];
-    const int qt = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
+    // Block order (round 4): workgroup L runs on XCD L % 8, and the NJT query tiles of one (segment, head) read the SAME
+    // keys, values and position tiles.  Dealt round robin they sat in six different L2s, each of which fetched those
+    // operands again: 579 MB per launch of 120 segments against 183 MB algorithmic, 6.2 TB/s -- the launch was bound by
+    // the fabric (profiles/r04_pmc.md).  Every XCD now takes a contiguous range of the (segment, head, query tile) space,
+    // so the tiles of a (segment, head) run back to back behind one L2.
+    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);
+    const int qt = item % NJT, head = (item / NJT) % heads, seg = item / (NJT * heads);
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const int ld = 3 * D;
     const float* qb = qkv + (int64_t)seg * T * ld + head * DK;
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
     // tiles, 1 KiB contiguous per load.  Rows past T of the last tile were never written (zero or stale, finite): those
     // keys are masked and those query columns never stored.
     const float4* qkt = reinterpret_cast<const float4*>(qkf) +
-                        ((int64_t)(seg * (int)gridDim.y + head) * NJT) * (2 * 8 * 64) + lane;
+                        ((int64_t)(seg * heads + head) * NJT) * (2 * 8 * 64) + lane;
     if constexpr (FRAG) {
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) q[ch] = qkt[(qt * 2 + 0) * 512 + ch * 64];
@@ -784,13 +793,13 @@ void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int sp
 void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
                              int H, int maxlen, int qk_split, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    const dim3 grid(qtiles, H, nseg), block(64);
+    const dim3 grid((unsigned)qtiles * (unsigned)H * (unsigned)nseg), block(64);
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
 #define CSS_ATT_CASE(n)                                                                                                      \
     case n:                                                                                                                  \
-        if (qk_split && qk_frag) hipLaunchKernelGGL((relpos_attn_kernel<n, true, true>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);  \
-        else if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);  \
-        else hipLaunchKernelGGL((relpos_attn_kernel<n, false, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out);          \
+        if (qk_split && qk_frag) hipLaunchKernelGGL((relpos_attn_kernel<n, true, true>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);  \
+        else if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);  \
+        else hipLaunchKernelGGL((relpos_attn_kernel<n, false, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);          \
         break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)

@@ -108,6 +108,14 @@ void stft_build_tables(float* host);   // window | radix-4 twiddles | real-spect
 bool launch_stft_fft(const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, const float* tables, float* out,
                      int64_t row_ld, hipStream_t s, float* phase = nullptr);
 
+// XCD-aware work order: workgroup L of a 1-D grid runs on XCD L % 8 (round robin), and each XCD has its own L2.  Work items
+// that read the same operands should therefore be neighbours IN ONE XCD: every XCD takes a contiguous range of the n items,
+// consecutive workgroups of an XCD consecutive items of its range.  (A bijection of [0, n) for every n.)
+__device__ __forceinline__ int css_xcd_item(int L, int n) {
+    const int q = n >> 3, rem = n & 7, xcd = L & 7;
+    return xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
+}
+
 // Phase of a spectrum value as the reference reaches it.  An exactly real negative bin (DC / Nyquist have Im == +0 by
 // construction of the transform) goes through polar() -> angle() in the reference (conformer_wrapper.py:124,94), which
 // maps it to the float32 value just inside -pi; the side of the atan2 branch cut of the IPD feature depends on that

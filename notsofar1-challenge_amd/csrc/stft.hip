@@ -53,11 +53,6 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2
 // to rows that lie T_ld * 4 bytes apart (450 KB for a 30-min meeting: 1.6 TB/s there against 2.4 TB/s at 60 s, where the
 // planes never leave the Infinity Cache).  So every XCD takes a CONTIGUOUS range of the (channel, tile) space: neighbouring
 // tiles pass through one L2 back to back and leave as whole lines (and the hop-overlapped sample reads hit that L2 too).
-__device__ __forceinline__ int stft_xcd_tile(int L, int n_tiles) {
-    const int q = n_tiles >> 3, rem = n_tiles & 7, xcd = L & 7;
-    return xcd * q + (xcd < rem ? xcd : rem) + (L >> 3);
-}
-
 __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __restrict__ x, int64_t x_stride, int t_lo, int t_hi,
                                                                const float* __restrict__ tab, float* __restrict__ out,
                                                                int64_t row_ld, int wide, int tiles, float* __restrict__ phase) {
@@ -65,7 +60,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_fft_kernel(const float* __re
     float2* bufA = fft_lds;
     float2* twl = fft_lds + FFT_TB * FFT_FS;   // the 256 stage twiddles: one coalesced load instead of three dependent gathers per stage
     const int tid = threadIdx.x;
-    const int item = stft_xcd_tile((int)blockIdx.x, (int)gridDim.x);   // position in the (channel, tile) space
+    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);   // position in the (channel, tile) space
     const int c = item / tiles;
     const int t0 = (t_lo / FFT_TB + (item - c * tiles)) * FFT_TB;
     const float* xc = x + (int64_t)c * x_stride;
