@@ -183,17 +183,11 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                                                        int F, float* __restrict__ feat, int Kp,
                                                        const float* __restrict__ in_bias,
                                                        const float* __restrict__ in_scale, int64_t seg_lo, int T,
-                                                       int hop, int split_out, FeatOpts o, const float* __restrict__ PH,
-                                                       int nseg_launch) {
+                                                       int hop, int split_out, FeatOpts o, const float* __restrict__ PH) {
     constexpr int FEAT_LD = FEAT_TMAX + 1;
     __shared__ float tile[32 * FEAT_LD];
     // blockIdx.y = 0: the spectral rows (microphone 0); y >= 1: IPD pair y - 1 = phase[ml] - phase[mr]
-    // work order (kernels.hpp css_xcd_item): the 1 + pairs blocks of one (bin tile, segment) -- they all read microphone
-    // 0's rows -- then the next segment of the same bins (half of its frames are the same) are neighbours behind one L2
-    const int n_m = 1 + o.num_pairs, n_ft = (F + 31) / 32;
-    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);
-    const int m = item % n_m, segl = (item / n_m) % nseg_launch, f0 = (item / (n_m * nseg_launch)) * 32;
-    (void)n_ft;
+    const int f0 = blockIdx.x * 32, m = blockIdx.y, segl = blockIdx.z;
     const int ml = m ? o.pair_l[m - 1] : 0, mr = m ? o.pair_r[m - 1] : 0;
     const int64_t st = (seg_lo + segl) * (int64_t)hop;
     const int64_t tv64 = stft_frames - st;
@@ -330,13 +324,13 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
                      int split_out, const FeatOpts& opts, hipStream_t s, const float* PH) {
     (void)C;
-    const dim3 grid((unsigned)((F + 31) / 32) * (unsigned)(1 + opts.num_pairs) * (unsigned)nseg), block(256);
+    const dim3 grid((F + 31) / 32, 1 + opts.num_pairs, nseg), block(256);
     if (T <= 256)
         hipLaunchKernelGGL(features_kernel<256>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out, opts, PH, nseg);
+                           seg_lo, T, hop, split_out, opts, PH);
     else
         hipLaunchKernelGGL(features_kernel<512>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
-                           seg_lo, T, hop, split_out, opts, PH, nseg);
+                           seg_lo, T, hop, split_out, opts, PH);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -69,10 +69,7 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float scm_lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (wave-uniform for the compiler: the rows' buffer descriptors live in scalar registers)
     const int k = lane >> 4, l16 = lane & 15;
-    // work order (kernels.hpp css_xcd_item): consecutive segments of the same bins are neighbours behind one L2 -- half of
-    // a segment's frames are its neighbour's
-    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);
-    const int segl = item % a.nseg, f = (item / a.nseg) * SCM_WAVES + wave;
+    const int f = blockIdx.x * SCM_WAVES + wave, segl = blockIdx.y;
     const int64_t seg = a.seg_lo + segl;
     const int nm = a.S + 1;
     const int F = a.F, T = a.T;
@@ -242,7 +239,7 @@ bool launch_scm(const MvdrArgs& a, hipStream_t s) {
     // per wave: 18 rows of TS floats, 4 lists of TS uint16 (= 2 TS floats), 4 x 98 doubles; TS = 256 or 512
     const int TS = a.T <= 256 ? 256 : 512;
     const size_t per_wave = ((size_t)(14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2) * sizeof(float);
-    const dim3 grid((unsigned)((a.F + SCM_WAVES - 1) / SCM_WAVES) * (unsigned)a.nseg), block(64 * SCM_WAVES);
+    const dim3 grid((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), block(64 * SCM_WAVES);
     if (a.T <= 256) {
         hipLaunchKernelGGL(scm_kernel<4>, grid, block, per_wave * SCM_WAVES, s, a);
     } else {   // up to 8 s segments: 82 KB of LDS per block
@@ -393,8 +390,7 @@ void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s) {
 // Block = (bin, segment), threads run over time.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void beamform_kernel(MvdrArgs a) {
-    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);   // (segments of one bin side by side: see scm_kernel)
-    const int segl = item % a.nseg, f = item / a.nseg;
+    const int f = blockIdx.x, segl = blockIdx.y;
     const int64_t seg = a.seg_lo + segl;
     const int F = a.F, T = a.T, S = a.S;
     const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
@@ -432,7 +428,7 @@ __global__ __launch_bounds__(256) void beamform_kernel(MvdrArgs a) {
 }
 
 void launch_beamform(const MvdrArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(beamform_kernel, dim3((unsigned)a.F * (unsigned)a.nseg), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(beamform_kernel, dim3(a.F, a.nseg), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

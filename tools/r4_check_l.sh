@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_hip_lanes.py tests/test_feature_options.py tests/test_hip_realistic.py tests/test_hip_golden_r2.py tests/test_hip_long.py -m gpu -q --timeout 600 2>&1 | tail -6 ) > gpurun_out/r4l.txt
+( timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_hip_lanes.py tests/test_hip_linear_modes.py tests/test_hip_schedules.py -m gpu -q --timeout 600 2>&1 | tail -6 ) > gpurun_out/r4l.txt
 ( timeout 500 python bench.py --steps 20 --warmup 3 --no-long --no-cpu-baseline > gpurun_out/r4l_bench.json 2> gpurun_out/r4l_bench.err ); echo "bench rc=$?" >> gpurun_out/r4l.txt
 cat gpurun_out/r4l.txt
 python - <<PY
