@@ -205,7 +205,9 @@ enum css_tuning {
                                            * the copy stream, behind each session's upload, beside the previous pass's estimator */
     CSS_TUNE_GROUP_MVDR_ON_LANES = 7,     /* 1: its covariances / MVDR / stitching costs on the lanes' streams, joined; 0 (default):
                                            * on the tail stream with everything else behind the mask head                        */
-    CSS_TUNE_COUNT = 8
+    CSS_TUNE_GROUP_OUT_DMA = 8,           /* 1 (default): its waveforms are overlap-added into HBM and copied out by DMA; 0: the
+                                           * overlap-add kernel writes the page-locked output over PCIe itself                   */
+    CSS_TUNE_COUNT = 9
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

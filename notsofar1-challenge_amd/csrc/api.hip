@@ -137,7 +137,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 0, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 0, 0, 1};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -1908,7 +1908,18 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, 0, TL, ts); }
         if (j == G - 1) hipEventRecord(h->ev[5], ts);
         istft_gemm_on(h, 0, TL, ts);
-        wave_ola_on(h, 0, TL, 0, TL + 1, q.wav_mapped, q.cap, 0, ts);
+        if (h->tune[CSS_TUNE_GROUP_OUT_DMA]) {
+            // the PCIe leg as copies behind a 12 us kernel: written by the kernel itself the same samples keep 11 250
+            // workgroups resident for 0.21 ms per session, beside the next pass's estimator (profiles/r04_queue_group_ab.md)
+            const int64_t n_out = h->plan.n_out;
+            if ((rc = ensure(h, h->wav, (size_t)S * n_out * sizeof(float))) != CSS_OK) return rc;
+            wave_ola_on(h, 0, TL, 0, TL + 1, (float*)h->wav.p, n_out, 0, ts);
+            for (int sp = 0; sp < S; ++sp)
+                HIPCHK(h, hipMemcpyAsync(q.wav + (size_t)sp * q.cap, (const float*)h->wav.p + (size_t)sp * n_out,
+                                         (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, ts));
+        } else {
+            wave_ola_on(h, 0, TL, 0, TL + 1, q.wav_mapped, q.cap, 0, ts);
+        }
         h->perms_done = true;
     }
     hipEventRecord(h->ev[6], ts);
