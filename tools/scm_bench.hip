@@ -1,11 +1,13 @@
 // Stand-alone timing of css::launch_scm (and the other MVDR-stage kernels) on the 60 s meeting's shapes (tools only).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/scm_bench.hip notsofar1-challenge_amd/csrc/mvdr.hip -Inotsofar1-challenge_amd/csrc -o /tmp/scm_bench
+//   (build line: tools/scm_mfma.hip; it also holds the float64-MFMA form of the covariance kernel this compares)
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
 using namespace css;
+namespace css { bool launch_scm_mfma(const MvdrArgs& a, hipStream_t s); }
 int main() {
     const int C = 7, F = 257, T = 186, hop = 93, S = 3, nseg = 40;
     const int64_t TL = 3749, T_ld = 3752, mask_ld = (int64_t)nseg * T;
@@ -31,7 +33,32 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-12s %8.2f us\n", name, ms * 1000 / 20);
     };
+    // launch_scm is the product (vector-ALU) kernel, launch_scm_mfma the matrix-core experiment of tools/scm_mfma.hip
+    const size_t nscm = (size_t)nseg * (S + 1) * F * 49;
+    std::vector<double> ref(nscm), got(nscm);
+    launch_scm(a, st); hipStreamSynchronize(st);
+    hipMemcpy(ref.data(), scm, nscm * 8, hipMemcpyDeviceToHost);
+    hipMemset(scm, 0, nscm * 8);
+    launch_scm_mfma(a, st); hipStreamSynchronize(st);
+    hipMemcpy(got.data(), scm, nscm * 8, hipMemcpyDeviceToHost);
+    double worst = 0, scale = 0;
+    for (size_t i = 0; i < nscm; ++i) { scale = fmax(scale, fabs(ref[i])); }
+    for (size_t i = 0; i < nscm; ++i) { worst = fmax(worst, fabs(ref[i] - got[i])); }
+    {   // where the two differ: by packed index and by mask
+        int bad_i[49] = {0}, bad_k[4] = {0}; size_t nbad = 0;
+        for (size_t i = 0; i < nscm; ++i) if (fabs(ref[i] - got[i]) > 1e-9 * scale) { ++bad_i[i % 49]; ++bad_k[(i / 49 / F) % (S + 1)]; ++nbad; }
+        printf("differing entries %zu of %zu; by mask:", nbad, nscm);
+        for (int k = 0; k < 4; ++k) printf(" %d", bad_k[k]);
+        printf("\nby packed index:");
+        for (int i = 0; i < 49; ++i) printf(" %d", bad_i[i]);
+        printf("\nfirst matrix (seg 0, mask 0, bin 0): vector / matrix\n");
+        for (int i = 0; i < 49; ++i) printf("  [%2d] % .12g  % .12g\n", i, ref[i], got[i]);
+    }
+    printf("scm: max |vector - matrix| = %.3g (max |value| %.3g) err %s\n", worst, scale, hipGetErrorString(hipGetLastError()));
     timeit("scm", [&] { launch_scm(a, st); });
+    timeit("scm_mfma", [&] { launch_scm_mfma(a, st); });
+    timeit("scm", [&] { launch_scm(a, st); });
+    timeit("scm_mfma", [&] { launch_scm_mfma(a, st); });
     timeit("mvdr_solve", [&] { launch_mvdr_solve(a, st); });
     timeit("beamform", [&] { launch_beamform(a, st); });
     std::vector<double> out(49 * 4);
