@@ -355,6 +355,14 @@ int css_sync(css_handle_t h);
  * in_features, the pair indices with its microphones.  Single-channel models take the spectral options only. */
 int css_set_feature_options(css_handle_t h, const CssFeatureCfg* cfg);
 
+/* The analysis window of the handle's model: ExtractorCfg.window (conformer_wrapper.py:24), one of the two init_kernel
+ * builds (css_with_conformer/executor/feature.py:19-45): 'hann' (every shipped model; the state after css_create) or
+ * 'sqrt_hann' -- the square root of the float32 Hann window with the kernel divided by 0.5 sqrt(N N / hop) = 16.  The
+ * synthesis transform is not affected (the reference builds its iSTFT without `window`: feature.py:422-425). */
+#define CSS_WINDOW_HANN 0
+#define CSS_WINDOW_SQRT_HANN 1
+int css_set_analysis_window(css_handle_t h, int32_t window);
+
 /* Separator-protocol helpers operating on caller data (host pointers):
  * stft: pcm [n][C] -> X planes [C][2F][T] (T = stft_frames, tightly packed). */
 int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n_ch, float* x_planes, int64_t t_frames);

@@ -30,6 +30,7 @@ class CssError(RuntimeError):
 # status codes (include/css_mi355.h: css_status)
 CSS_OK, CSS_ERR_INVALID_ARG, CSS_ERR_HIP, CSS_ERR_ZERO_WEIGHT, CSS_ERR_MASK_FLOOR = 0, -1, -2, -3, -4
 CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW, CSS_ERR_RANGE = -5, -6, -7, -8, -9
+ANALYSIS_WINDOWS = {"hann": 0, "sqrt_hann": 1}   # CSS_WINDOW_* (css_set_analysis_window)
 
 # buffer ids (css_buffer)
 (BUF_X, BUF_FEATURES, BUF_MASKS, BUF_SCM, BUF_BFW, BUF_SEP, BUF_PIT_COST, BUF_PERMS, BUF_MASK_ST, BUF_ACTIVITY,
@@ -127,6 +128,7 @@ SIGNATURES = {
     "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "css_set_feature_options": (C.c_int, [_P, C.POINTER(CssFeatureCfg)]),
+    "css_set_analysis_window": (C.c_int, [_P, C.c_int32]),
     "css_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "css_istft_host": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     "css_handoff_logmel": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
@@ -410,6 +412,12 @@ class Handle:
         for i, (l, r) in enumerate(pairs[:16]):
             c.pair_l[i], c.pair_r[i] = int(l), int(r)
         check(self.h, self.lib.css_set_feature_options(self.h, C.byref(c)))
+
+    def set_analysis_window(self, window: str):
+        """ExtractorCfg.window: 'hann' (default) or 'sqrt_hann' (css_set_analysis_window; feature.py:19-45)"""
+        if window not in ANALYSIS_WINDOWS:
+            raise RuntimeError("Now only support sqrt hanning window or hann window")   # feature.py:24-25
+        check(self.h, self.lib.css_set_analysis_window(self.h, ANALYSIS_WINDOWS[window]))
 
     def set_range_fallback(self, enable: bool):
         check(self.h, self.lib.css_set_range_fallback(self.h, int(enable)))

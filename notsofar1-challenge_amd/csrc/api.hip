@@ -2230,6 +2230,19 @@ int css_set_feature_options(css_handle_t h, const CssFeatureCfg* c) {
     return CSS_OK;
 }
 
+int css_set_analysis_window(css_handle_t h, int32_t window) {
+    CSS_DRAIN(h);
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (window != CSS_WINDOW_HANN && window != CSS_WINDOW_SQRT_HANN)
+        return fail(h, CSS_ERR_INVALID_ARG, "the analysis window is 'hann' or 'sqrt_hann' (feature.py:24-25)");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<float> tab(stft_table_floats());
+    stft_build_tables(tab.data(), window);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->stft_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return CSS_OK;
+}
+
 int css_get_linear_mode(css_handle_t h) {
     if (!h) return CSS_ERR_INVALID_ARG;
     return h->split ? CSS_LINEAR_SPLIT_F16 : CSS_LINEAR_EXACT_F32;

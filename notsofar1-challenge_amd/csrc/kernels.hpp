@@ -99,7 +99,7 @@ void launch_relpos_attention(const float* qkv, const float* qk_frag, const float
 // stft.hip -- the analysis transform as an LDS-staged FFT (frame_len 512, hop 256, 257 bins)
 // ------------------------------------------------------------------------------------------------
 size_t stft_table_floats();
-void stft_build_tables(float* host);   // window | radix-4 twiddles | real-spectrum twiddles
+void stft_build_tables(float* host, int window = 0);   // window (0: hann, 1: sqrt_hann / 16) | radix-4 twiddles | real-spectrum twiddles
 // frames 0 .. nf-1 of C channels (channel c's first sample at x + c * x_stride, frame t at sample 256 t) -> planes
 // out[(c * 514 + r) * row_ld + t], r = f (Re) / 257 + f (Im).  false: the kernel's LDS could not be reserved.
 // phase != nullptr: also the PHASE planes phase[(c * 257 + f) * row_ld + t] = css_phase_of(Re, Im) -- the angle the IPD

@@ -26,8 +26,14 @@ constexpr int FFT_THREADS = 256;
 // tables: window[512] | tw256[256] (cos, -sin of 2 pi m / 256) | tw512[257] (cos, -sin of 2 pi k / 512)
 size_t stft_table_floats() { return FFT_N + 2 * FFT_H + 2 * (FFT_H + 1); }
 
-void stft_build_tables(float* t) {
-    for (int n = 0; n < FFT_N; ++n) t[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));   // torch.hann_window (periodic), float32
+// window 0: 'hann' (the shipped extractors); 1: 'sqrt_hann' -- feature.py:29-36: W = hann ** 0.5 on the float32 window and the
+// kernel divided by S = 0.5 sqrt(N N / hop) = 16 (init_kernel's normalize, which STFTBase never overrides: feature.py:63-66);
+// the power of two is folded into the window table (exact)
+void stft_build_tables(float* t, int window) {
+    for (int n = 0; n < FFT_N; ++n) {
+        const float hann = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / FFT_N));   // torch.hann_window (periodic), float32
+        t[n] = window == 1 ? std::sqrt(hann) / 16.0f : hann;
+    }
     float* t256 = t + FFT_N;
     for (int m = 0; m < FFT_H; ++m) {
         t256[2 * m] = (float)std::cos(2.0 * M_PI * m / FFT_H);

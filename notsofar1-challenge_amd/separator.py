@@ -80,14 +80,17 @@ def feature_options(e: ExtractorCfg) -> dict:
 def desc_from_cfg(cfg: ConformerCssCfg) -> ModelDesc:
     """ConformerCssCfg -> the C ABI's model descriptor.  The spectral and IPD options of ExtractorCfg
     (`log_spectrogram`, `mvn_spectrogram`, `ipd_index`, `ipd_mean_normalize`, `ipd_mean_normalize_version`, `ipd_cos`) are
-    all implemented (css_set_feature_options); rejected: another analysis window / frame size (the FFT kernel is the
-    512-point Hann transform) and `ang_index` -- the reference's own wrapper never passes the direction of arrival its
-    AngleFeature needs (conformer_wrapper.py:96-100 calls the executor without `doa`), so no model can use it there either."""
+    all implemented (css_set_feature_options), and so are both analysis windows init_kernel builds, 'hann' and 'sqrt_hann'
+    (css_set_analysis_window; feature.py:24-36); `round_pow_of_two` changes nothing at a power-of-two frame length
+    (feature.py:27).  Rejected: another frame size (the FFT kernel is the 512-point transform with hop 256) and
+    `ang_index` -- the reference's own wrapper never passes the direction of arrival its AngleFeature needs
+    (conformer_wrapper.py:96-100 calls the executor without `doa`), so no model can use it there either."""
     e, n = cfg.extractor_conf, cfg.nnet_conf
-    for name in ("ang_index", "window", "round_pow_of_two"):
-        if getattr(e, name) != getattr(_SUPPORTED_EXTRACTOR, name):
-            raise NotImplementedError(f"extractor_conf.{name}={getattr(e, name)!r} is not supported by the HIP "
-                                      f"front end (supported: {getattr(_SUPPORTED_EXTRACTOR, name)!r})")
+    if e.ang_index != _SUPPORTED_EXTRACTOR.ang_index:
+        raise NotImplementedError(f"extractor_conf.ang_index={e.ang_index!r} is not supported by the HIP front end "
+                                  f"(supported: {_SUPPORTED_EXTRACTOR.ang_index!r})")
+    if e.window not in _lib.ANALYSIS_WINDOWS:
+        raise RuntimeError("Now only support sqrt hanning window or hann window")   # feature.py:24-25
     if (e.frame_len, e.frame_hop) != (512, 256):
         raise NotImplementedError("the analysis transform is built for frame_len 512 / frame_hop 256")
     pairs = ipd_pairs(e.ipd_index)
@@ -177,6 +180,7 @@ class HipSeparator:
             self._handle = _lib.Handle(self.desc, self.blob, self._device, self._stream, self._max_batch)
             if self.cfg is not None and self.cfg.extractor_conf != _SUPPORTED_EXTRACTOR:
                 self._handle.set_feature_options(**feature_options(self.cfg.extractor_conf))
+                self._handle.set_analysis_window(self.cfg.extractor_conf.window)
         return self._handle
 
     def close(self):

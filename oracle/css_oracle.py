@@ -122,11 +122,17 @@ def _dft_angles(frame_len: int):
     return c, s
 
 
-def stft_kernel(frame_len: int = 512, dtype=np.float32) -> np.ndarray:
-    """Analysis kernel K[2F, frame_len] (rows 0..F-1 = cos*w, rows F.. = -sin*w).  feature.py:19-45
-    (window='hann' -> S = 1)."""
+def stft_kernel(frame_len: int = 512, dtype=np.float32, window: str = "hann", frame_hop: int = 256) -> np.ndarray:
+    """Analysis kernel K[2F, frame_len] (rows 0..F-1 = cos*w, rows F.. = -sin*w).  feature.py:19-45:
+    window='hann' -> S = 1; window='sqrt_hann' -> W = hann ** 0.5 (on the float32 window, feature.py:29-31) and
+    S = 0.5 sqrt(N N / hop) (init_kernel's `normalize` stays True: STFTBase does not pass its own, feature.py:63-66)."""
+    if window not in ("hann", "sqrt_hann"):
+        raise RuntimeError("Now only support sqrt hanning window or hann window")   # feature.py:24-25
     c, s = _dft_angles(frame_len)
-    w = hann_periodic(frame_len, np.float64)
+    if window == "hann":
+        w = hann_periodic(frame_len, np.float64)
+    else:
+        w = np.sqrt(hann_periodic(frame_len, np.float32)).astype(np.float64) / (0.5 * math.sqrt(frame_len * frame_len / frame_hop))
     k = np.concatenate([c * w, 0.0 - s * w], axis=0)
     return k.astype(dtype)
 
@@ -148,7 +154,7 @@ def num_frames(n_samples: int, frame_len: int = 512, frame_hop: int = 256) -> in
     return (n_samples - frame_len) // frame_hop + 1
 
 
-def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256) -> np.ndarray:
+def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256, window: str = "hann") -> np.ndarray:
     """x [N, C] (or [N]) -> complex X [F, T, C] (or [F, T]).
 
     ConformerCssWrapper.stft (conformer_wrapper.py:106-129): conv1d with the Hann-DFT kernel
@@ -159,7 +165,7 @@ def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int =
         x = x[:, None]
     n, c = x.shape
     t = num_frames(n, frame_len, frame_hop)
-    k = stft_kernel(frame_len, dtype)
+    k = stft_kernel(frame_len, dtype, window, frame_hop)
     nb = frame_len // 2 + 1
     cdtype = np.complex64 if dtype == np.float32 else np.complex128
     out = np.zeros((nb, t, c), dtype=cdtype)

@@ -99,8 +99,81 @@ def test_hip_features_and_masks_vs_oracle_and_reference(name, golden, mix60):
 
 def test_unsupported_extractor_options_are_rejected_loudly():
     S = pkg("separator")
-    for kw in (dict(ang_index="1,0;2,0"), dict(window="sqrt_hann"), dict(frame_len=400, frame_hop=160)):
+    for kw in (dict(ang_index="1,0;2,0"), dict(frame_len=400, frame_hop=160)):
         with pytest.raises(NotImplementedError):
             S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(**kw)))
     with pytest.raises(RuntimeError):
         S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(ipd_mean_normalize_version=4)))
+    with pytest.raises(RuntimeError):      # init_kernel's own error (feature.py:24-25)
+        S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(window="hamming")))
+    # both windows of init_kernel and the no-op round_pow_of_two are accepted
+    for kw in (dict(window="sqrt_hann"), dict(round_pow_of_two=False)):
+        assert S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(**kw))).frame_len == 512
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The second analysis window init_kernel builds (feature.py:19-45): ExtractorCfg(window='sqrt_hann'); fixture from the
+# reference (tests/golden/gen_golden_r4b.py).  round_pow_of_two=False is the same kernel at frame_len 512 (recorded there).
+# ---------------------------------------------------------------------------------------------------------------------
+def _window_setup(golden, mix60):
+    S, W = pkg("separator"), pkg("weights")
+    g = golden("window_r4.npz")
+    assert bool(g["round_pow_of_two_false_is_identical"])
+    e = S.ExtractorCfg(window="sqrt_hann", round_pow_of_two=False)
+    desc = W.ModelDesc(num_blocks=2)
+    st = W.apply_golden_recipe(W.portable_state_dict(desc, 5))
+    cfg = S.ConformerCssCfg(extractor_conf=e, nnet_conf=S.NnetCfg(in_features=desc.in_features, conformer_conf=S.ConformerCfg(
+        attention_dim=desc.attention_dim, attention_heads=desc.attention_heads, num_blocks=2, dropout_rate=0.0,
+        linear_units=desc.linear_units, kernel_size=desc.kernel_size)))
+    mix = mix60[:, int(g["offset"]):int(g["offset"]) + int(g["samples"])]
+    return g, st, desc, cfg, mix
+
+
+def test_oracle_sqrt_hann_window_vs_reference(golden, mix60):
+    g, st, desc, cfg, mix = _window_setup(golden, mix60)
+    x = O.stft(mix[0], window="sqrt_hann")                      # [F, 186, 7]
+    ref = g["sqrt_hann_stft"]
+    scale = float(np.abs(ref).max())
+    assert np.abs(x[::4, ::3] - ref).max() < 2e-6 * scale       # (the bar of the Hann transform)
+    # the kernel itself: sqrt of the float32 Hann window over S = 16; not the Hann kernel
+    k = O.stft_kernel(window="sqrt_hann")
+    assert np.allclose(k[0], np.sqrt(O.hann_periodic(512)) / 16.0, rtol=0, atol=1e-9)
+    assert np.abs(k - O.stft_kernel()).max() > 0.01
+    with pytest.raises(RuntimeError):
+        O.stft_kernel(window="hamming")
+    f = O.features(x)
+    d = np.abs(f[::8, ::3] - g["sqrt_hann_features"])
+    angle = np.arange(f.shape[0])[::8] >= 257
+    d[angle] = np.minimum(d[angle], 2 * np.pi - d[angle])
+    assert np.percentile(d, 99) < 2e-5 * max(float(np.abs(g["sqrt_hann_features"]).max()), 1.0) and d.max() < 2e-3 * 4
+    masks = O.conformer_forward(O.ConformerParams(st), f)
+    assert np.abs(np.moveaxis(masks[:3], 0, 2)[::8, ::4] - g["sqrt_hann_spk_masks"]).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_sqrt_hann_window_vs_oracle_and_reference(golden, mix60):
+    import torch
+    g, st, desc, cfg, mix = _window_setup(golden, mix60)
+    sep = pkg("separator").HipSeparator(st, cfg, device=0)
+    try:
+        X = sep.stft(torch.from_numpy(mix))                      # [1, F, 186, 7] complex64
+        x = X.numpy()[0]
+        xo = O.stft(mix[0], window="sqrt_hann")
+        rel_rms = lambda a, b: float(np.sqrt(np.mean(np.abs(a - b) ** 2) / np.mean(np.abs(b) ** 2)))
+        assert rel_rms(x, xo) < 1e-6                             # (the bars of the Hann transform, tests/test_hip_parity.py)
+        assert rel_rms(x[::4, ::3], g["sqrt_hann_stft"]) < 2e-6
+        assert np.abs(x.imag[0]).max() == 0 and np.abs(x.imag[256]).max() == 0
+        out = sep.separate(X)
+        spk = out["spk_masks"].numpy()[0]
+        om = O.conformer_forward(O.ConformerParams(st), O.features(xo))
+        assert np.abs(spk - np.moveaxis(om[:3], 0, 2)).max() < 1.5e-5
+        assert np.abs(spk[::8, ::4] - g["sqrt_hann_spk_masks"]).max() < 2e-5
+        # back to the Hann window on the same handle: the shipped transform again
+        sep.handle.set_analysis_window("hann")
+        xh = sep.stft(torch.from_numpy(mix)).numpy()[0]
+        assert rel_rms(xh, O.stft(mix[0])) < 1e-6
+        assert rel_rms(xh, xo) > 0.1
+        with pytest.raises(RuntimeError):
+            sep.handle.set_analysis_window("hamming")
+    finally:
+        sep.close()
