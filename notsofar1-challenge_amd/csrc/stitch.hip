@@ -19,6 +19,25 @@ __device__ __forceinline__ double wave_sum_dd(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// The same sum without LDS round trips (__shfl_xor compiles to ds_bpermute: six dependent ones per double and sum):
+// four DPP steps inside each row of 16 lanes, the four row totals through scalar registers.  Every lane gets the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_d(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return v + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_d<0x141>(v);   // row_half_mirror
+    v = dpp_add_d<0x140>(v);   // row_mirror
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * i), __builtin_amdgcn_readlane(lo, 16 * i));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Raw PIT cost of boundary b (segments b | b+1):  cost[a][c] = mean_{F, overlap} loss(L_a - R_c)
@@ -28,7 +47,9 @@ __device__ __forceinline__ double wave_sum_dd(double v) {
 // sequential dependence of css.py:266-285 is confined to the tiny scan below.
 //   input 0: masks   input 1: |separated spectrum|     loss 0: L1   loss 1: squared error
 // ------------------------------------------------------------------------------------------------
-constexpr int PIT_CH = 16;   // frequency chunks per boundary: 39 boundaries alone would occupy 39 of 256 CUs
+// frequency chunks per boundary: 39 boundaries alone would occupy 39 of 256 CUs; with 48 a thread takes two (bin, frame)
+// elements, all of whose loads are in flight at once (16 chunks: six dependent rounds of loads per thread)
+constexpr int PIT_CH = 48;
 
 // One block per (boundary, frequency chunk) -> partial[b][chunk][16]; a second kernel adds the chunks in a fixed
 // order, so the cost is the same bit pattern whatever boundary range or GPU computes it.
@@ -70,7 +91,7 @@ __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, i
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < SMAX * SMAX; ++i) {
-        const double v = wave_sum_dd(acc[i]);
+        const double v = wave_sum_dpp(acc[i]);
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
