@@ -93,11 +93,13 @@ typedef struct CssFeatureCfg {
 /* Run-time knobs.  Mirrors the arithmetic-relevant fields of CssCfg (css/css.py:24-48) after the
  * seconds->frames conversion of css/css.py:144-152, which the host shim performs with the same
  * Python float expressions. */
+#define CSS_MAX_SEGMENT_FRAMES 16384   /* 262 s: a sanity bound (one query's score rows must fit the LDS) */
 typedef struct CssRunCfg {
-    int32_t segment_frames;          /* 186  (css.py:147).  2 .. 512: PERMANENT LIMIT of this library -- the attention kernel
-                                      * keeps a query tile's scores over all keys in registers (16 key tiles), the
-                                      * feature / covariance kernels a segment's rows in LDS; segments beyond 8 s
-                                      * (the reference accepts any segment_size_sec) return CSS_ERR_INVALID_ARG       */
+    int32_t segment_frames;          /* 186  (css.py:147).  2 .. CSS_MAX_SEGMENT_FRAMES.  Up to 512 frames (8 s) the attention
+                                      * kernel keeps a query tile's scores over all keys in registers and the feature /
+                                      * covariance kernels a segment's rows in LDS; longer segments (the reference accepts
+                                      * any segment_size_sec) run on any-length forms of those three kernels -- the same
+                                      * results to the path's tolerances, several times slower per second of audio    */
     int32_t hop_frames;              /* 93   (css.py:148).  1 <= hop < segment_frames (css.py:276 needs an overlap)   */
     int32_t dilation_frames;         /* 24   (css.py:151)                                         */
     int32_t erosion_frames;          /* 12   (css.py:152)                                         */
@@ -372,7 +374,7 @@ int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int3
 /* ConformerCssWrapper.forward (conformer_wrapper.py:58-77: stft -> separate) for a batch of equally long clips, fused
  * on the device -- the validation forward of the reference's training loop (train.py:529 eval_model).
  * pcm_host [batch][n_samples][n_ch] -> masks_host [(S+1) F][batch * T'], T' = (n_samples - frame_len) / hop + 1
- * (2 <= T' <= 512), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
+ * (2 <= T' <= CSS_MAX_SEGMENT_FRAMES), clip b in columns [b T', (b+1) T'); mask k of bin f in row k F + f (speakers first). */
 int css_forward_host(css_handle_t h, const float* pcm_host, int32_t batch, int64_t n_samples, int32_t n_ch, float* masks_host);
 /* The validation loss of the reference's training loop for a batch of equally long clips (css/training/train.py:411-481
  * _calc_loss as train.py:529 eval_model calls it; no backward pass): forward as css_forward_host, |STFT| of microphone 0

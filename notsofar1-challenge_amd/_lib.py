@@ -31,6 +31,7 @@ class CssError(RuntimeError):
 CSS_OK, CSS_ERR_INVALID_ARG, CSS_ERR_HIP, CSS_ERR_ZERO_WEIGHT, CSS_ERR_MASK_FLOOR = 0, -1, -2, -3, -4
 CSS_ERR_SHAPE, CSS_ERR_STATE, CSS_ERR_NO_DEVICE, CSS_ERR_WEIGHT_WINDOW, CSS_ERR_RANGE = -5, -6, -7, -8, -9
 ANALYSIS_WINDOWS = {"hann": 0, "sqrt_hann": 1}   # CSS_WINDOW_* (css_set_analysis_window)
+MAX_SEGMENT_FRAMES = 16384                       # CSS_MAX_SEGMENT_FRAMES
 
 # buffer ids (css_buffer)
 (BUF_X, BUF_FEATURES, BUF_MASKS, BUF_SCM, BUF_BFW, BUF_SEP, BUF_PIT_COST, BUF_PERMS, BUF_MASK_ST, BUF_ACTIVITY,

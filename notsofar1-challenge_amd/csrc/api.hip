@@ -736,7 +736,8 @@ static int check_run_args(css_handle_t h, int64_t n_samples, int32_t n_ch, const
     if (!cfg->w_first || !cfg->w_mid || !cfg->w_last) return fail(h, CSS_ERR_INVALID_ARG, "segment weights missing");
     if (cfg->mask_floor > 1.0f || cfg->mask_floor < 0.f) return fail(h, CSS_ERR_MASK_FLOOR, "mask_floor_db must be <= 0");
     const int T = cfg->segment_frames, hop = cfg->hop_frames;
-    if (T < 2 || T > 512) return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, 512] (at most 8 s segments)");
+    if (T < 2 || T > CSS_MAX_SEGMENT_FRAMES)
+        return fail(h, CSS_ERR_INVALID_ARG, "segment_frames must be in [2, " + std::to_string(CSS_MAX_SEGMENT_FRAMES) + "]");
     if (cfg->stitching_loss < 0 || cfg->stitching_loss > 1 || cfg->stitching_input < 0 || cfg->stitching_input > 1)
         return fail(h, CSS_ERR_INVALID_ARG, "unexpected stitching_loss / stitching_input");
     if (hop <= 0 || hop >= T) return fail(h, CSS_ERR_INVALID_ARG, "hop_frames must satisfy 1 <= hop < T (at least one frame of overlap for the stitching cost, css.py:276)");
@@ -1014,13 +1015,22 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         ffn(l == 0, x, b.ffi_ln_w, b.ffi_ln_b, b.ffi_w1, b.ffi_b1, b.ffi_w2, b.ffi_b2);
         // self attention (conformer.py:65-92)
         { CSS_PROF(CSS_PROF_LAYERNORM, st); launch_layernorm(x, sp ? nullptr : u, sp ? u : nullptr, b.att_ln_w, b.att_ln_b, M, D, 0, st); }
-        // q, k and v leave the QKV GEMM as split operands for the MFMAs of the attention kernel (q and k in fragment order)
+        // q, k and v leave the QKV GEMM as split operands for the MFMAs of the attention kernel (q and k in fragment order);
+        // segments beyond 512 frames: as plain float32 rows for the any-length kernel (encoder.hip relpos_attn_long_kernel)
+        const bool long_seg = T > 512 || css_force_long_path();
         {
-            GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, 3 * D);
-            if (sp) { g.frag_out = qkf; g.frag_D = D; g.frag_T = T; g.frag_heads = d.attention_heads; g.frag_invT = 1.0f / T; }
+            GemmArgs g = lin(u, D, b.wqkv, b.bqkv, qkv, 3 * D, 3 * D, D, ACT_NONE, long_seg ? 0 : 3 * D);
+            if (sp && !long_seg) { g.frag_out = qkf; g.frag_D = D; g.frag_T = T; g.frag_heads = d.attention_heads; g.frag_invT = 1.0f / T; }
             gemm(h, g, st);
         }
-        { CSS_PROF(CSS_PROF_ATTENTION, st); launch_relpos_attention(qkv, sp ? qkf : nullptr, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st); }
+        {
+            CSS_PROF(CSS_PROF_ATTENTION, st);
+            if (long_seg) {
+                if (!launch_relpos_attention_long(qkv, W.pe_k, cb, nb, T, D, d.attention_heads, d.maxlen, sp, st)) return CSS_ERR_INVALID_ARG;
+            } else {
+                launch_relpos_attention(qkv, sp ? qkf : nullptr, (const float*)h->pe_frag[sp].p, cb, nb, T, D, d.attention_heads, d.maxlen, sp, sp, st);
+            }
+        }
         {
             GemmArgs g = lin(cb, D, b.wo, b.bo, x, D, D, D, ACT_NONE, 0);
             g.residual = x; g.ldr = D; g.alpha = 1.f;
@@ -1091,7 +1101,8 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
     const int L = h->d.num_blocks;
     const int sp = h->split ? 1 : 0;
     int rc;
-    if (h->pe_frag_T[sp] != io.T) {   // the attention kernel's position operands depend on the segment length only
+    const bool long_seg = io.T > 512 || css_force_long_path();   // (the any-length attention reads the position table itself)
+    if (!long_seg && h->pe_frag_T[sp] != io.T) {   // the attention kernel's position operands depend on the segment length only
         if ((rc = ensure(h, h->pe_frag[sp], (size_t)pe_fragment_tiles(io.T) * 2048 * sizeof(float))) != CSS_OK) return rc;
         launch_pe_fragments(sp ? h->wsplit + (h->w.pe_k - h->blob) : h->w.pe_k, (float*)h->pe_frag[sp].p, io.T, h->d.maxlen,
                             sp, h->stream);
@@ -2354,7 +2365,8 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
 int css_separate_host(css_handle_t h, const float* x_planes, int32_t batch, int32_t t_frames, float* masks) {
     CSS_DRAIN(h);
     if (!h || !x_planes || !masks || batch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
-    if (t_frames < 2 || t_frames > 512) return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, 512] frames");
+    if (t_frames < 2 || t_frames > CSS_MAX_SEGMENT_FRAMES)
+        return fail(h, CSS_ERR_INVALID_ARG, "segment length must be in [2, " + std::to_string(CSS_MAX_SEGMENT_FRAMES) + "] frames");
     HIPCHK(h, hipSetDevice(h->device));
     const int F = h->d.num_bins, C = h->d.num_mics, T = t_frames, nm = h->d.num_spks + h->d.num_nois;
     const int64_t TT = (int64_t)batch * T;
@@ -2387,7 +2399,8 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     if (n_ch != C) return fail(h, CSS_ERR_SHAPE, "the model expects " + std::to_string(C) + " channels");
     if (n_samples < N) return fail(h, CSS_ERR_INVALID_ARG, "clip shorter than one frame");
     const int64_t T64 = (n_samples - N) / hop + 1;
-    if (T64 < 2 || T64 > 512) return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2..512 frames");
+    if (T64 < 2 || T64 > CSS_MAX_SEGMENT_FRAMES)
+        return fail(h, CSS_ERR_INVALID_ARG, "clip length must give 2.." + std::to_string(CSS_MAX_SEGMENT_FRAMES) + " frames");
     const int T = (int)T64;
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t TT = (int64_t)batch * T;

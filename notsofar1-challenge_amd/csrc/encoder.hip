@@ -769,6 +769,156 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention for segments of ANY length (css/css.py:144-171 takes any segment_size_sec; relpos_attn_kernel keeps a
+// query tile's scores in registers and stops at 16 key tiles = 512 frames = 8 s).  Written for reach, not speed: float32
+// fused multiply-adds on the vector ALU in both arithmetic modes, one block of 256 threads per (segment, head, NQ queries),
+// everything that depends on T in a loop or in LDS:
+//   r[i][u] = q_i . pe[clamp(i0 - (T - 1) + u)]     u = 0 .. NQ + T - 2   (the Toeplitz form: B[i][j] = r[i][i + T - 1 - j])
+//   s[i][j] = (q_i . k_j + r[i][i + T - 1 - j]) / sqrt(d_k),  softmax over j in place,  ctx_i = sum_j p[i][j] v_j
+// A quad of lanes holds one key row (or one position row) in registers and walks the NQ queries in LDS; the position products
+// are added into the score rows where they belong; the host picks the largest NQ <= 16 whose q and s rows fit the LDS.  qkv: float32 rows [token][3 D] (the QKV GEMM writes them plain for this path),
+// pe: the float32 table [2 maxlen][64].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_attn_long_kernel(const float* __restrict__ qkv, const float* __restrict__ pe,
+                                                               float* __restrict__ ctx, int T, int D, int maxlen, int split_out,
+                                                               int heads, int nq) {
+    constexpr int DK = 64;
+    extern __shared__ __attribute__((aligned(16))) float att_lds[];
+    const int qtiles = (T + nq - 1) / nq;
+    const int item = blockIdx.x;
+    const int qt = item % qtiles, head = (item / qtiles) % heads, seg = item / (qtiles * heads);
+    const int i0 = qt * nq, nv = min(nq, T - i0);
+    float* qs = att_lds;                         // [nq][64]
+    float* ss = qs + nq * DK;                    // [nq][T]
+    const int tid = threadIdx.x;
+    const int64_t ld = 3 * (int64_t)D;
+    const float* base = qkv + (int64_t)seg * T * ld + head * DK;
+    for (int e = tid; e < nv * DK; e += 256) qs[e] = base[(int64_t)(i0 + e / DK) * ld + (e % DK)];
+    __syncthreads();
+    // Four lanes share a key (or position) row: lane `sub` of a quad holds features 16 m + 4 sub .. + 3, m = 0 .. 3, so a wave's
+    // load instruction covers 64 contiguous bytes of 16 rows.  (A row per lane -- 64 lanes x 256 bytes in flight per wave --
+    // thrashed the vector L1: every 16-byte piece fetched its 128-byte line again, 3.0 ms per layer on 10 s segments.)  The
+    // quad's partial products meet by two DPP steps; four queries run side by side because a block is one wave per SIMD and
+    // has nothing else to cover a chain of dependent multiply-adds.
+    const int sub = tid & 3, kq = tid >> 2;
+    auto quad_sum = [](float v) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+        return v;
+    };
+    auto load_row = [&](const float* rowp, float (&row)[16]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(rowp + 16 * m + 4 * sub);
+            row[4 * m] = v.x; row[4 * m + 1] = v.y; row[4 * m + 2] = v.z; row[4 * m + 3] = v.w;
+        }
+    };
+    // partial products of queries i .. i + 3 with the lane's 16 features, summed over the quad
+    auto dots4 = [&](int i, const float (&row)[16], float (&acc)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 q = *reinterpret_cast<const float4*>(qs + min(i + k, nv - 1) * DK + 16 * m + 4 * sub);
+                acc[k] = fmaf(q.x, row[4 * m], acc[k]); acc[k] = fmaf(q.y, row[4 * m + 1], acc[k]);
+                acc[k] = fmaf(q.z, row[4 * m + 2], acc[k]); acc[k] = fmaf(q.w, row[4 * m + 3], acc[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = quad_sum(acc[k]);
+    };
+    // key products: 64 keys per step
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        const int j = j0 + kq;
+        float row[16];
+        load_row(base + (int64_t)min(j, T - 1) * ld + D, row);
+        for (int i = 0; i < nv; i += 4) {
+            float acc[4];
+            dots4(i, row, acc);
+            // (lane `sub` of the quad stores query i + sub: every lane holds all four sums)
+            const float mine = sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3];
+            if (j < T && i + sub < nv) ss[(size_t)(i + sub) * T + j] = mine;
+        }
+    }
+    __syncthreads();
+    // position products, added where they belong -- query i0 + i and key j meet at offset (i0 + i) - j = i0 - (T - 1) + u,
+    // u = i + T - 1 - j: for a query, different offsets are different keys, so no two lanes touch one score
+    const int nu = nv + T - 1;
+    for (int u0 = 0; u0 < nu; u0 += 64) {
+        const int u = u0 + kq;
+        const int rel = max(-maxlen, min(i0 - (T - 1) + u, maxlen - 1)) + maxlen;     // conformer.py:24-29
+        float row[16];
+        load_row(pe + (int64_t)rel * DK, row);
+        for (int i = 0; i < nv; i += 4) {
+            float acc[4];
+            dots4(i, row, acc);
+            const float mine = sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3];
+            const int j = i + sub + T - 1 - u;
+            if (u < nu && i + sub < nv && j >= 0 && j < T) ss[(size_t)(i + sub) * T + j] = (ss[(size_t)(i + sub) * T + j] + mine) * 0.125f;
+        }
+    }
+    __syncthreads();
+    // softmax of each query row, in place (one wave per row)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < nv; i += 4) {
+        float* row = ss + (size_t)i * T;
+        float mx = -INFINITY;
+        for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < T; j += 64) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < T; j += 64) row[j] *= inv;
+    }
+    __syncthreads();
+    // context: thread = (feature d, query group); the value rows are read along d (coalesced), p[i][j] is an LDS broadcast
+    {
+        const int d = tid & 63, ig = tid >> 6;
+        constexpr int MAXQ = 4;                  // queries per thread: nq <= 16
+        float acc[MAXQ] = {0.f, 0.f, 0.f, 0.f};
+        const float* vb = base + 2 * D + d;
+#pragma unroll 8
+        for (int j = 0; j < T; ++j) {   // (unrolled: eight value rows on their way at a time)
+            const float v = vb[(int64_t)j * ld];
+#pragma unroll
+            for (int k = 0; k < MAXQ; ++k) {
+                const int i = ig + 4 * k;
+                if (i < nv) acc[k] = fmaf(ss[(size_t)i * T + j], v, acc[k]);
+            }
+        }
+        float* ob = ctx + ((int64_t)seg * T + i0) * D;
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int i = ig + 4 * k;
+            if (i >= nv) continue;
+            if (split_out) split_store(reinterpret_cast<_Float16*>(ob + (int64_t)i * D), head * DK + d, acc[k]);
+            else ob[(int64_t)i * D + head * DK + d] = acc[k];
+        }
+    }
+}
+
+bool launch_relpos_attention_long(const float* qkv, const float* pe, float* ctx, int nseg, int T, int D, int H, int maxlen,
+                                  int split_out, hipStream_t s) {
+    if (D != H * 64) return false;
+    // queries per block: up to 16, as many as leave room for three blocks per CU (a block is one wave per SIMD and its loops
+    // are chains; 20 s segments: 16 queries at one block per CU 6.0 ms per layer)
+    int nq = 16;
+    auto bytes = [&](int n) { return ((size_t)n * 64 + (size_t)n * T) * sizeof(float); };
+    while (nq > 1 && bytes(nq) > 52 * 1024) nq >>= 1;
+    if (bytes(nq) > 150 * 1024) return false;    // (one query per block still does not fit: segments beyond ~ 19 000 frames)
+    if (bytes(nq) > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attn_long_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(nq)) != hipSuccess)
+        return false;
+    const unsigned qtiles = (unsigned)((T + nq - 1) / nq);
+    hipLaunchKernelGGL(relpos_attn_long_kernel, dim3(qtiles * (unsigned)H * (unsigned)nseg), dim3(256), bytes(nq), s, qkv, pe, ctx, T, D,
+                       maxlen, split_out, H, nq);
+    return true;
+}
+
 // Position rows in the order the attention kernel's MFMA operands want them (see pe_tile there): tile m holds rows
 // 32 m - (T - 1) + c of the relative-position table (clamped to [-maxlen, maxlen - 1] as conformer.py:24 clamps them),
 // float4 index (8 m + ch) 64 + l = the 16 bytes lane l = c + 32 h reads for chunk ch of row c.  `pe` is the table as the

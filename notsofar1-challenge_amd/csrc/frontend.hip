@@ -2,10 +2,18 @@
 // overlap-add that finishes the inverse transform.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "split_f16.hpp"
 
 namespace css {
+
+bool css_force_long_path() {   // kernels.hpp
+    static const bool on = [] { const char* e = getenv("CSS_FORCE_LONG_PATH"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 
 // sum over the 64 lanes (every lane gets the total): DPP inside the rows of 16, row totals through scalar registers
 // (no ds_bpermute round trips; see wave_sum in encoder.hip)
@@ -320,12 +328,104 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same features for segments of ANY length (features_kernel holds a bin's T values in registers and a [32][T] tile in
+// LDS: T <= 512).  One wave per (bin, m, segment); the values of a frame are formed again in every pass instead of being
+// kept (statistics, [variance,] output), lanes run over time with the same strides and the sums are formed in the same
+// order as in features_kernel (measured on a 3 s session: the angle rows are the same bits, the magnitude rows differ by
+// one float32 ulp in half of the elements -- the compiler contracts the two kernels' mean / deviation arithmetic
+// differently).  Rows leave one element per lane (a 4-byte store every K_pad floats): written for reach, not for speed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void features_long_kernel(const float* __restrict__ X, int64_t T_ld, int64_t stft_frames,
+                                                           int F, float* __restrict__ feat, int Kp,
+                                                           const float* __restrict__ in_bias, const float* __restrict__ in_scale,
+                                                           int64_t seg_lo, int T, int hop, int split_out, FeatOpts o,
+                                                           const float* __restrict__ PH) {
+    const int f = blockIdx.x, m = blockIdx.y, segl = blockIdx.z;
+    const int ml = m ? o.pair_l[m - 1] : 0, mr = m ? o.pair_r[m - 1] : 0;
+    const int64_t st = (seg_lo + segl) * (int64_t)hop;
+    const int64_t tv64 = stft_frames - st;
+    const int tv = (int)(tv64 < 0 ? 0 : (tv64 > T ? T : tv64));
+    const int lane = threadIdx.x;
+    const float invT = 1.0f / (float)T;
+    const float* re0 = X + ((int64_t)mr * 2 * F + f) * T_ld + st;
+    const float* im0 = X + ((int64_t)mr * 2 * F + F + f) * T_ld + st;
+    const float* rem = X + ((int64_t)ml * 2 * F + f) * T_ld + st;
+    const float* imm = X + ((int64_t)ml * 2 * F + F + f) * T_ld + st;
+    const float* phl = PH ? PH + ((int64_t)ml * F + f) * T_ld + st : nullptr;
+    const float* phr = PH ? PH + ((int64_t)mr * F + f) * T_ld + st : nullptr;
+    // the values of frame t: m == 0: a = magnitude (clamped, optionally log); m >= 1: a = cos d, b = sin d, d = phase difference
+    auto eval = [&](int t, float& a, float& b, float& d) {
+        const bool ok = t < tv;   // zero-padded frames of the last segment: X = 0
+        if (m == 0) {
+            const float r0 = ok ? re0[t] : 0.f, i0 = ok ? im0[t] : 0.f;
+            a = fmaxf(sqrtf(r0 * r0 + i0 * i0), CSS_EPS32);
+            if (o.log_mag) a = logf(a);
+            b = 0.f; d = 0.f;
+        } else {
+            if (PH) d = (ok ? phl[t] : 0.f) - (ok ? phr[t] : 0.f);
+            else d = css_phase_of(ok ? rem[t] : 0.f, ok ? imm[t] : 0.f) - css_phase_of(ok ? re0[t] : 0.f, ok ? im0[t] : 0.f);
+            sincosf(d, &b, &a);
+        }
+    };
+    const int col = m * F + f;
+    const float bi = in_bias[col], sc = in_scale[col];
+    float* out = feat + (int64_t)segl * T * Kp;
+    auto put = [&](int t, float v) {
+        const float y = (v + bi) * sc;
+        if (split_out) split_store(reinterpret_cast<_Float16*>(out + (int64_t)t * Kp), col, y);
+        else out[(int64_t)t * Kp + col] = y;
+    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        float a, b, d;
+        eval(t, a, b, d);
+        s0 += a; s1 += b; s2 += d;
+    }
+    s0 = wave_sum_f(s0);
+    s1 = wave_sum_f(s1);
+    if (m == 0) {
+        float mean = 0.f, den = 1.f;
+        if (o.mvn) {                                                 // feature.py:503-507
+            mean = s0 * invT;
+            float q = 0.f;
+            for (int t = lane; t < T; t += 64) {
+                float a, b, d;
+                eval(t, a, b, d);
+                a -= mean;
+                q += a * a;
+            }
+            den = sqrtf(wave_sum_f(q) / (float)(T - 1)) + CSS_EPS32;
+        }
+        for (int t = lane; t < T; t += 64) {
+            float a, b, d;
+            eval(t, a, b, d);
+            put(t, o.mvn ? (a - mean) / den : a);
+        }
+    } else {
+        const float yrm = s0 * invT, yim = s1 * invT;
+        float shift = 0.f;
+        if (o.ipd_norm && o.ipd_version == 2) shift = atan2f(yim, yrm);
+        if (o.ipd_norm && o.ipd_version == 3) shift = wave_sum_f(s2) * invT;
+        for (int t = lane; t < T; t += 64) {
+            float a, b, d;
+            eval(t, a, b, d);
+            float v = (o.ipd_norm && o.ipd_version == 1) ? atan2f(b - yim, a - yrm) : d - shift;
+            if (o.ipd_cos) v = cosf(v);
+            put(t, v);
+        }
+    }
+}
+
 void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, int F, float* feat, int Kp,
                      const float* in_bias, const float* in_scale, int64_t seg_lo, int nseg, int T, int hop,
                      int split_out, const FeatOpts& opts, hipStream_t s, const float* PH) {
     (void)C;
     const dim3 grid((F + 31) / 32, 1 + opts.num_pairs, nseg), block(256);
-    if (T <= 256)
+    if (T > 512 || css_force_long_path())
+        hipLaunchKernelGGL(features_long_kernel, dim3(F, 1 + opts.num_pairs, nseg), dim3(64), 0, s, X, T_ld, stft_frames, F, feat, Kp,
+                           in_bias, in_scale, seg_lo, T, hop, split_out, opts, PH);
+    else if (T <= 256)
         hipLaunchKernelGGL(features_kernel<256>, grid, block, 0, s, X, T_ld, stft_frames, F, feat, Kp, in_bias, in_scale,
                            seg_lo, T, hop, split_out, opts, PH);
     else

@@ -94,6 +94,10 @@ void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int sp
 inline int64_t qk_fragment_floats(int64_t nseg, int T, int H) { return nseg * H * ((T + 31) / 32) * 2 * 8 * 64 * 4; }
 void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
                              int H, int maxlen, int qk_split, int split_out, hipStream_t s);
+// segments beyond 512 frames (encoder.hip relpos_attn_long_kernel): qkv = float32 rows [token][3 D], pe = the float32
+// table [2 maxlen][64]; false: the head width is not 64 or one query's rows do not fit the LDS
+bool launch_relpos_attention_long(const float* qkv, const float* pe, float* ctx, int nseg, int T, int D, int H, int maxlen,
+                                  int split_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // stft.hip -- the analysis transform as an LDS-staged FFT (frame_len 512, hop 256, 257 bins)
@@ -144,6 +148,11 @@ void launch_encode_pcm16(const float* wav, int S, int64_t n, unsigned int* peak_
                          hipStream_t s);
 // features for segments [seg_lo, seg_lo + nseg): X planes -> feat [nseg*T][Kp] (bias/scale folded); float32 rows
 // or split-f16 rows (split_f16.hpp; the padding columns are never written and must be zero)
+// Segments beyond 512 frames (8 s) take kernels written for any length (features_long_kernel, relpos_attn_long_kernel,
+// scm_long_kernel).  CSS_FORCE_LONG_PATH=1 in the environment sends EVERY segment length through them: the tests hold
+// them to the fixtures of the fast kernels that way.
+bool css_force_long_path();
+
 struct FeatOpts {   // CssFeatureCfg in kernel-argument form
     int log_mag, mvn, ipd_norm, ipd_version, ipd_cos, num_pairs;
     unsigned char pair_l[16], pair_r[16];

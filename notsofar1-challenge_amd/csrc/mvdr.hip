@@ -235,7 +235,81 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same covariances for segments of ANY length (scm_kernel holds a whole segment of the bin in a wave's LDS tile and
+// register pieces: T <= 512).  One block per (segment, bin); thread (k, e) owns entry e of mask k's packed matrix and
+// walks the frames in order, 128 at a time through LDS; the winners of a chunk are decided by its first 128 threads
+// (ties keep every tied mask, like mask == mask_max).  Written for reach, not for speed.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCM_LONG_CH = 128;
+
+__global__ __launch_bounds__(256) void scm_long_kernel(MvdrArgs a) {
+    __shared__ float xs[2 * NC][SCM_LONG_CH];
+    __shared__ double ws[4][SCM_LONG_CH];      // (m_k - 1e-10) where mask k wins the frame, else 0
+    const int f = blockIdx.x, segl = blockIdx.y;
+    const int64_t seg = a.seg_lo + segl;
+    const int nm = a.S + 1, F = a.F, T = a.T;
+    const int tv = valid_frames(a.stft_frames, seg, a.hop, T);
+    const int64_t st = seg * (int64_t)a.hop;
+    const uint8_t* ov = a.wta_override ? a.wta_override + (seg * F + f) * (int64_t)T : nullptr;
+    const int tid = threadIdx.x;
+    const int k = tid / NPACK, e = tid - k * NPACK;
+    // entry e: the diagonal (c, c), or (Re | Im) of (c, d), c < d, row by row
+    int c = e, d = e, im = 0;
+    if (e >= NC) {
+        int p = (e - NC) >> 1;
+        im = (e - NC) & 1;
+        c = 0;
+        for (int s_ = 0; s_ < NC - 2; ++s_) if (p >= NC - 1 - c) { p -= NC - 1 - c; ++c; }
+        d = c + 1 + p;
+    }
+    const bool owner = k < nm;   // 4 x 49 = 196 of the 256 threads own an entry
+    double acc = 0.0, plain = 0.0;
+    for (int t0 = 0; t0 < tv; t0 += SCM_LONG_CH) {
+        const int n = min(SCM_LONG_CH, tv - t0);
+        __syncthreads();   // the previous chunk has been read
+        for (int i = tid; i < 2 * NC * SCM_LONG_CH; i += 256) {
+            const int r = i / SCM_LONG_CH, t = i - r * SCM_LONG_CH;
+            xs[r][t] = t < n ? a.X[((int64_t)(r % NC) * 2 * F + (r / NC) * F + f) * a.T_ld + st + t0 + t] : 0.f;
+        }
+        if (tid < SCM_LONG_CH) {
+            const int t = tid;
+            float mv[4], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mv[j] = (t < n && j < nm) ? a.masks[((int64_t)j * F + f) * a.mask_ld + seg * (int64_t)T + t0 + t] : -INFINITY;
+                mx = fmaxf(mx, mv[j]);
+            }
+            const int ovv = (t < n && ov) ? ov[t0 + t] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool win = t < n && j < nm && (ov ? (ovv == j) : (mv[j] == mx));
+                ws[j][t] = win ? (double)mv[j] - 1e-10 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (owner) {
+            for (int t = 0; t < n; ++t) {
+                const double xrc = (double)xs[c][t], xic = (double)xs[NC + c][t];
+                const double xrd = (double)xs[d][t], xid = (double)xs[NC + d][t];
+                const double p = im ? xic * xrd - xrc * xid : xrc * xrd + xic * xid;      // x_c conj(x_d)
+                acc += ws[k][t] * p;
+                plain += p;
+            }
+        }
+    }
+    if (owner) {
+        double v = acc + 1e-10 * plain;
+        if (e < NC) v += 1e-15;  // Ri += 1e-15 * I   (mvdr_util.py:63-65)
+        a.scm[((seg * nm + k) * (int64_t)F + f) * NPACK + e] = v;
+    }
+}
+
 bool launch_scm(const MvdrArgs& a, hipStream_t s) {
+    if (a.T > 512 || css_force_long_path()) {
+        hipLaunchKernelGGL(scm_long_kernel, dim3(a.F, a.nseg), dim3(256), 0, s, a);
+        return true;
+    }
     // per wave: 18 rows of TS floats, 4 lists of TS uint16 (= 2 TS floats), 4 x 98 doubles; TS = 256 or 512
     const int TS = a.T <= 256 ? 256 : 512;
     const size_t per_wave = ((size_t)(14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2) * sizeof(float);

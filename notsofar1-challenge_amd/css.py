@@ -94,12 +94,13 @@ def make_run_cfg(cfg: CssCfg, fs: int, num_channels: int, frame_len: int = 512, 
     seg_samples = int(cfg.segment_size_sec * fs)
     segment_frames = (seg_samples - frame_len) // frame_hop + 1  # length of the dummy STFT, css.py:145-147
     hop_frames = int(segment_frames * cfg.hop_size_sec / cfg.segment_size_sec)
-    # what the kernels are built for: segments of 2..512 frames (up to 8 s) and any hop with at least one frame of overlap
-    # for the stitching cost (css.py:276 compares the overlapping frames of adjacent segments; hop == segment has none)
-    if not (2 <= segment_frames <= 512 and 0 < hop_frames < segment_frames):
+    # what the kernels take: segments of 2 frames and more (up to 512 frames = 8 s on the tuned kernels, beyond that on
+    # their any-length forms; the bound is a sanity limit of 262 s) and any hop with at least one frame of overlap for the
+    # stitching cost (css.py:276 compares the overlapping frames of adjacent segments; hop == segment has none)
+    if not (2 <= segment_frames <= _lib.MAX_SEGMENT_FRAMES and 0 < hop_frames < segment_frames):
         raise NotImplementedError(
             f"segment_size_sec={cfg.segment_size_sec} / hop_size_sec={cfg.hop_size_sec} give {segment_frames}-frame segments "
-            f"every {hop_frames} frames; the HIP path covers segments of 2..512 frames with 1 <= hop < segment")
+            f"every {hop_frames} frames; the HIP path covers segments of 2..{_lib.MAX_SEGMENT_FRAMES} frames with 1 <= hop < segment")
     m0_frames = int(segment_frames * cfg.seg_weight_m0_sec / cfg.segment_size_sec)
     m1_frames = int(segment_frames * cfg.seg_weight_m1_sec / cfg.segment_size_sec)
     dilation_frames = int(segment_frames * cfg.activity_dilation_sec / cfg.segment_size_sec)

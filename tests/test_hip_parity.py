@@ -376,11 +376,13 @@ def test_short_and_error_inputs(L, CSS, sep_mc):
     with pytest.raises(AssertionError):                                  # css.py:224 mask_floor_db <= 0
         CSS.separate_and_stitch(np.zeros((1, 64000, 7), np.float32), sep_mc, 16000, "cuda:0",
                                 CSS.CssCfg(mc_mask_floor_db=3.0))
-    # what is left outside: no overlap for the stitching cost (hop == segment) and segments beyond 512 frames (8 s)
+    # what is left outside: no overlap for the stitching cost (hop == segment) -- the reference asserts there itself
     with pytest.raises(NotImplementedError, match="1 <= hop < segment"):
         CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=3.0), 16000, 7)
+    # segments beyond 512 frames (8 s) run on the any-length kernels since round 4 (tests/test_hip_long_segments.py)
+    assert int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=9.0, hop_size_sec=4.5), 16000, 7).c.segment_frames) == 561
     with pytest.raises(NotImplementedError):
-        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=9.0, hop_size_sec=4.5), 16000, 7)   # 561-frame segments
+        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=300.0, hop_size_sec=150.0), 16000, 7)   # the sanity bound (262 s)
     # ... and what round 3 brought inside (fixtures from the reference: test_hip_golden_r2.py): hop < segment / 4, 311 frames
     assert int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=0.5), 16000, 7).c.hop_frames) == 31
     assert int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=5.0, hop_size_sec=2.5), 16000, 7).c.segment_frames) == 311
