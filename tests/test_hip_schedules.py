@@ -84,11 +84,11 @@ def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes):
 
 
 @pytest.mark.parametrize("seg,hop,seconds,max_batch", [(3.0, 0.5, 14.3, 64), (3.0, 0.5, 9.1, 5), (5.0, 2.5, 23.7, 64),
-                                                       (8.0, 1.0, 21.2, 3), (1.0, 0.1, 6.4, 16)])
+                                                       (8.0, 1.0, 21.2, 3), (1.0, 0.1, 6.4, 16), (9.5, 2.0, 33.1, 4)])
 def test_dense_and_long_segmentations_every_schedule(model, seg, hop, seconds, max_batch):
     """Segmentations beyond the shipped 3 s / 1.5 s -- more than four segments over a frame (the general overlap-add
-    loops), segments of more than 256 frames (the long-segment attention / feature / covariance kernels), and both at
-    once: the fused host -> host pipeline, the device-resident stage sequence and the sharded driver for 2, 3 and 5
+    loops), segments of more than 256 frames (the long-segment attention / feature / covariance kernels), of more than 512
+    (592: their any-length forms), and both at once: the fused host -> host pipeline, the device-resident stage sequence and the sharded driver for 2, 3 and 5
     virtual ranks (halo = ceil(T / hop) - 1 segments) give the same bits."""
     import torch
     L, CSS, PAR = pkg("_lib"), pkg("css"), pkg("parallel")
@@ -218,6 +218,36 @@ def test_queued_sessions_with_the_host_passes_ahead(mc_state):
             h.wait()
             for k, (got, (_, ref)) in enumerate(zip(outs, sessions)):
                 assert np.array_equal(got, ref), (presized, k, float(np.abs(got - ref).max()))
+    finally:
+        sep.close()
+
+
+
+def test_queued_long_segment_sessions_share_estimator_batches(mc_state):
+    """Sessions cut into 10 s segments (624 frames: the any-length kernels) queued back to back share estimator batches
+    like any others: each, bit for bit, its own synchronous css_run."""
+    L, CSS = pkg("_lib"), pkg("css")
+    st, desc = mc_state
+    cfg = CSS.make_run_cfg(CSS.CssCfg(show_progressbar=False, activity_th=0.3, segment_size_sec=10.0, hop_size_sec=5.0), 16000, 7)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=24)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([41.0, 27.0, 60.0, 22.3]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=900 + k)
+            pcm = L.pinned_copy(np.ascontiguousarray(mix[0, :mix.shape[1] - 13 * k]))
+            sessions.append((pcm, h.run(pcm, cfg).copy()))
+        assert int(h.get_plan().segment_frames if hasattr(h.get_plan(), "segment_frames") else 624) == 624
+        for rounds in range(2):
+            outs = []
+            for pcm, ref in sessions:
+                out = L.pinned_empty(ref.shape, np.float32)
+                out[:] = np.nan
+                outs.append(h.run_enqueue(pcm, cfg, out))
+            h.wait()
+            for k, (got, (_, ref)) in enumerate(zip(outs, sessions)):
+                assert np.isfinite(ref).all() and float(np.abs(ref).max()) > 0
+                assert np.array_equal(got, ref), (rounds, k, float(np.abs(got - ref).max()))
     finally:
         sep.close()
 
