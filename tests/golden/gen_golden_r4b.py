@@ -3,11 +3,14 @@
 in the build container (rules as in gen_golden.py: the reference is imported in place, nothing of it is copied; only
 seeds and output tensors are written).
 
-    python tests/golden/gen_golden_r4b.py       # writes window_r4.npz
+    python tests/golden/gen_golden_r4b.py       # writes window_r4.npz, segs_long_r4.npz
 
   window_r4.npz   ExtractorCfg(window='sqrt_hann') -- and round_pow_of_two=False, which changes nothing at frame_len 512
                   -- on the 3 s clip of feature_opts_r3.npz: the wrapper's complex STFT (decimated), the reference
-                  FeatureExtractor's features (decimated) and the speaker masks of a seeded 2-block model."""
+                  FeatureExtractor's features (decimated) and the speaker masks of a seeded 2-block model.
+  segs_long_r4.npz   the reference's separate_and_stitch with 10 s segments every 5 s (624 frames: beyond the 512 the tuned
+                  kernels hold; css.py:144-171 takes any segment_size_sec) on a 27 s input, v1.0-MC model with the golden
+                  weights.  Same keys as the seg* entries of segs_r3.npz (gen_golden_r3.py)."""
 from __future__ import annotations
 
 import os
@@ -53,6 +56,28 @@ def main():
     assert same
     out["round_pow_of_two_false_is_identical"] = same
     np.savez_compressed(os.path.join(HERE, "window_r4.npz"), **out)
+
+    # ------------------------------------------------------------------ segments beyond 512 frames through the reference
+    import gen_golden_r2 as G2
+    RC = G.RC
+    desc = W.ModelDesc.mc_v1()
+    cal = np.load(os.path.join(HERE, "calib_mc.npz"))
+    st = W.apply_golden_recipe(W.portable_state_dict(desc, int(cal["weight_seed"])), head_bias=cal["head_bias"])
+    model = G.build_reference_model(desc, st)
+    # (the clip starts at frame 1375 of the recording: of the offsets searched -- every 25 frames -- the one whose four full
+    # segments keep all of their 960 000 inter-channel angles furthest from the atan2 branch cut, 3.6e-6: DESIGN.md hazard 7)
+    mix_s = mix60[:, 352000:352000 + 27 * 16000 + 300]
+    lo = {"seg_offset": 352000, "seg_samples": mix_s.shape[1]}
+    seg, hop = 10.0, 5.0
+    name = f"seg{int(seg)}{int(hop)}"
+    w3, s3, t3, _ = G.run_reference(model, mix_s, RC.CssCfg(show_progressbar=False, activity_th=0.3, segment_size_sec=seg, hop_size_sec=hop))
+    lo.update(G2.outputs(name, w3, s3, t3.pit))
+    lo[f"{name}_wta_index"] = G2.pack2(G2.wta_of(t3.masks))
+    lo[f"{name}_wta_shape"] = np.array(G2.wta_of(t3.masks).shape)
+    lo[f"{name}_segment_frames"] = int(s3["segment_frames"])
+    lo[f"{name}_masks_spk_seg0"] = t3.masks[0]["spk_masks"][0, ::8, ::4]
+    print(name, "segments", len(t3.masks), "frames", int(s3["segment_frames"]), "perms", sorted({tuple(p) for _, p in t3.pit}))
+    np.savez_compressed(os.path.join(HERE, "segs_long_r4.npz"), **lo)
 
 
 if __name__ == "__main__":

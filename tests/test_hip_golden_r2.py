@@ -63,11 +63,12 @@ def test_csscfg_branches_vs_reference(L, sep_mc, mix60, golden, name):
         assert rel_rms(ww[k][:3], g[p + "_wav_windows"][k][:3]) < 1e-4, (name, k)
 
 
-# (3 s, 0.5 s): six segments over every frame; (5 s, 2.5 s): 311-frame segments -- round-3 fixtures (gen_golden_r3.py)
-@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0), (3.0, 0.5), (5.0, 2.5)])
+# (3 s, 0.5 s): six segments over every frame; (5 s, 2.5 s): 311-frame segments -- round-3 fixtures (gen_golden_r3.py);
+# (10 s, 5 s): 624-frame segments, beyond what the tuned kernels hold -- round 4 (gen_golden_r4b.py)
+@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0), (3.0, 0.5), (5.0, 2.5), (10.0, 5.0)])
 def test_other_segmentations_vs_reference(L, sep_mc, mix60, golden, seg_hop):
     CSS = pkg("css")
-    g = golden("segs_r3.npz" if seg_hop in ((3.0, 0.5), (5.0, 2.5)) else "variants_mc.npz")
+    g = golden("segs_long_r4.npz" if seg_hop == (10.0, 5.0) else "segs_r3.npz" if seg_hop in ((3.0, 0.5), (5.0, 2.5)) else "variants_mc.npz")
     name = f"seg{int(seg_hop[0])}{int(seg_hop[1])}"
     mix = np.ascontiguousarray(mix60[0, int(g["seg_offset"]):int(g["seg_offset"]) + int(g["seg_samples"])])
     cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False, segment_size_sec=seg_hop[0], hop_size_sec=seg_hop[1])

@@ -76,10 +76,11 @@ def test_csscfg_branches_vs_reference(opt_run, name):
         assert rel_rms(ww[0][:3], g["opt_default_wav_windows"][0][:3]) > 1e-2   # leave these permutations as they are)
 
 
-# (3 s, 0.5 s): six segments over every frame; (5 s, 2.5 s): 311-frame segments -- round-3 fixtures (gen_golden_r3.py)
-@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0), (3.0, 0.5), (5.0, 2.5)])
+# (3 s, 0.5 s): six segments over every frame; (5 s, 2.5 s): 311-frame segments -- round-3 fixtures (gen_golden_r3.py);
+# (10 s, 5 s): 624-frame segments, beyond what the tuned kernels hold -- round 4 (gen_golden_r4b.py)
+@pytest.mark.parametrize("seg_hop", [(3.0, 2.0), (4.0, 2.0), (2.0, 1.0), (3.0, 0.5), (5.0, 2.5), (10.0, 5.0)])
 def test_other_segmentations_vs_reference(mc_state, mix60, golden, seg_hop):
-    g = golden("segs_r3.npz" if seg_hop in ((3.0, 0.5), (5.0, 2.5)) else "variants_mc.npz")
+    g = golden("segs_long_r4.npz" if seg_hop == (10.0, 5.0) else "segs_r3.npz" if seg_hop in ((3.0, 0.5), (5.0, 2.5)) else "variants_mc.npz")
     name = f"seg{int(seg_hop[0])}{int(seg_hop[1])}"
     mix = mix60[:, int(g["seg_offset"]):int(g["seg_offset"]) + int(g["seg_samples"])]
     params = O.ConformerParams(mc_state[0])
