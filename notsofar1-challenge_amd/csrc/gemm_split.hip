@@ -74,7 +74,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_split_kernel(GemmArgs g, int
     const int per_batch = tiles_m * tiles_n;
     const int bz = tile / per_batch;
     const int t2 = tile - bz * per_batch;
-    const int tn = t2 % tiles_n, tm = t2 / tiles_n;
+    // (m_fastest: the row tiles of one COLUMN panel are neighbours -- the launch whose B operand is the large one, the mask
+    // head: weights are A, the tokens B)
+    const int tn = g.m_fastest ? t2 / tiles_m : t2 % tiles_n, tm = g.m_fastest ? t2 % tiles_m : t2 / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const float* __restrict__ A = g.A + (int64_t)bz * g.strideA;

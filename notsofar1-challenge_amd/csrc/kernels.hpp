@@ -48,6 +48,9 @@ struct GemmArgs {
     // (split_f16.hpp: nothing is clamped); checked here, in the consumer, because a ReLU downstream would launder a NaN
     unsigned int* range_flag;
     int layout;            // LDS-staged kernels (gemm.hip, gemm_split.hip): 0 = choose, else 8 / 4 (128-row tiles, 8 / 4 waves) / 64
+    // LDS-staged kernels: an XCD's consecutive tiles walk the ROW tiles of one column panel (they share the B panel) instead
+    // of the column tiles of one row panel: for launches whose B operand is the large one.  Same tiles, same bits.
+    int m_fastest;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
