@@ -97,6 +97,7 @@ struct css_ctx : SessState {
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
     float* dft_tiled = nullptr;  // ... and in the tile-major layout of the weights-direct GEMM (whole-meeting synthesis)
+    float* head_tiled = nullptr; // the mask head's weights in that layout (rows rounded up to 32; wsplit keeps the row-major image)
     DevBuf pe_frag[2];           // relative-position rows in attention-operand order for segment length pe_frag_T
     int pe_frag_T[2] = {0, 0};   // ([0] from the float32 table, [1] from the split-f16 one; encoder.hip pe_fragments_kernel)
     float* stft_tab = nullptr;   // window and twiddles of the analysis FFT (stft.hip)
@@ -532,6 +533,11 @@ int make_split_weights(css_ctx* h) {
     }
     launch_split_convert(h->w.head_w, D, h->wsplit + (h->w.head_w - h->blob), (int64_t)d.num_bins * (d.num_spks + d.num_nois), D,
                          D, h->stream);
+    {
+        const int nout = d.num_bins * (d.num_spks + d.num_nois);
+        HIPCHK(h, hipMalloc((void**)&h->head_tiled, (size_t)((nout + 31) / 32 * 32) * D * sizeof(float)));
+        launch_split_convert_tiled(h->w.head_w, D, h->head_tiled, nout, D, h->stream);
+    }
     // the synthesis transform matrix, row-major split
     HIPCHK(h, hipMalloc((void**)&h->dft_split, (size_t)d.frame_len * h->KIp * sizeof(float)));
     launch_split_convert(h->dft_inv_t, h->KIp, h->dft_split, d.frame_len, h->KIp, h->KIp, h->stream);
@@ -708,6 +714,7 @@ int css_destroy(css_handle_t h) {
     if (h->wsplit) hipFree(h->wsplit);
     if (h->dft_split) hipFree(h->dft_split);
     if (h->dft_tiled) hipFree(h->dft_tiled);
+    if (h->head_tiled) hipFree(h->head_tiled);
     for (auto& b : h->pe_frag)
         if (b.p) hipFree(b.p);
     if (h->stft_tab) hipFree(h->stft_tab);
@@ -1071,17 +1078,30 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     // masks[(k*F + f)][segment*T + t] = sigmoid(head_w[k*F + f] . x[token] + head_b[k*F + f])
     GemmArgs g{};
     const int nout = F * (d.num_spks + d.num_nois);
-    g.A = WS(W.head_w); g.lda = D; g.strideA = 0;
-    g.B = sp ? u : x; g.ldb = D; g.strideB = 0;
-    g.C = io.masks + s0 * T; g.ldc = io.mask_ld; g.strideC = 0;
-    g.M = nout; g.N = M; g.K = D; g.batch = 1;
-    g.bias = W.head_b; g.bias_along_m = 1; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
-    g.split_in = sp;
-    g.range_flag = sp ? h->range_flag_dev : nullptr;
-    // (the tokens are the large operand here: 17 row tiles of weights against hundreds of token panels; walked row panel by
-    // row panel every XCD streamed all tokens twice -- 376 MB fetched per launch of 120 segments against 48 MB of operands;
-    // kernel trace, A/B on one box: 107.8 -> 101.0 us at 60 segments per lane, 161.7 -> 137.6 us at 120)
-    g.m_fastest = 1;
+    if (sp) {
+        // split mode: tokens x weights on the weights-direct kernel like every Linear layer, the result written transposed
+        // (kernel trace, A/B on one box: 87 us per 60 segments against 101 us for the LDS-staged kernel with the weights as
+        // its A operand; the step itself did not move measurably, 4.903 vs 4.907 ms)
+        g.A = u; g.lda = D; g.strideA = 0;
+        g.B = h->head_tiled; g.ldb = D; g.strideB = 0; g.b_tiled = 1;
+        g.C = io.masks + s0 * T; g.ldc = io.mask_ld; g.strideC = 0; g.c_transposed = 1;
+        g.M = M; g.N = nout; g.K = D; g.batch = 1;
+        g.bias = W.head_b; g.bias_along_m = 0; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
+        g.split_in = 1; g.concurrent = concurrent ? 1 : 0;
+        g.range_flag = h->range_flag_dev;
+    } else {
+        g.A = WS(W.head_w); g.lda = D; g.strideA = 0;
+        g.B = sp ? u : x; g.ldb = D; g.strideB = 0;
+        g.C = io.masks + s0 * T; g.ldc = io.mask_ld; g.strideC = 0;
+        g.M = nout; g.N = M; g.K = D; g.batch = 1;
+        g.bias = W.head_b; g.bias_along_m = 1; g.act = ACT_SIGMOID; g.residual = nullptr; g.alpha = 1.f;
+        g.split_in = sp;
+        g.range_flag = sp ? h->range_flag_dev : nullptr;
+        // (the tokens are the large operand here: 17 row tiles of weights against hundreds of token panels; walked row panel by
+        // row panel every XCD streamed all tokens twice -- 376 MB fetched per launch of 120 segments against 48 MB of operands;
+        // kernel trace, A/B on one box: 107.8 -> 101.0 us at 60 segments per lane, 161.7 -> 137.6 us at 120)
+        g.m_fastest = 1;
+    }
     gemm(h, g, st);
     if (!lane) h->last_batch_tokens = M;
     return CSS_OK;

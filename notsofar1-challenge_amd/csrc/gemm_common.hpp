@@ -202,6 +202,27 @@ __device__ __forceinline__ void emit_tile_pre_wide(const f32x16& acc, const Tile
     }
 }
 
+// The finished tile written TRANSPOSED: C^T[n][m] at Ct + n * ldct + m (the mask head: rows of the product are tokens, the
+// masks want time as their fastest axis).  Through the wave-private patch like the wide epilogue; a store instruction is two
+// output rows (columns n of the tile) of 32 consecutive m: 128-byte runs.  Column bias and activation only.
+__device__ __forceinline__ void emit_tile_pre_tr(const f32x16& acc, float bn, int mb0, int h, int c, int nb, int M, int N,
+                                                 float* __restrict__ Ct, int64_t ldct, int act, float* __restrict__ patch) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + bn;
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+        patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_LD + c] = v;
+    }
+    const int m = mb0 + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int nl = 2 * i + h, n = nb + nl;
+        const float v = patch[c * LDS_LD + nl];
+        if (m < M && n < N) Ct[(int64_t)n * ldct + m] = v;
+    }
+}
+
 // Epilogue of a 32 x 32 tile of the attention's q / k projections (bias only) in the ATTENTION kernel's operand order
 // (encoder.hip): the tile is one 32-k group `grp` of one head; token m = segment * T + j lands in row tile j / 32, lane
 // (j % 32) + 32 h', chunk 4 grp + 2 sub + part (part 0 = hi halves, 1 = lo halves of k = 32 grp + 16 sub + 8 h' .. + 7).

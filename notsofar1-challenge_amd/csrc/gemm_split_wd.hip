@@ -39,7 +39,9 @@ constexpr int WD_BM = 128;
 // waves per SIMD nothing else would hide those instructions.
 // BUF: operand loads as buffer loads (resource descriptor in SGPRs + 32-bit lane offset + scalar slab offset) instead of
 // 64-bit-per-lane global loads: half the address registers through the issue path, no 64-bit pointer arithmetic per slab
-template <int BM, int WMV, bool BUF = false>
+// TR: the result is written transposed (GemmArgs::c_transposed; its own instantiation, so that the Linear layers' kernel
+// is the code it was)
+template <int BM, int WMV, bool BUF = false, bool TR = false>
 __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 ? 2 : 3) void gemm_split_wd_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int THREADS = WMV * 256;
     constexpr int TM = BM / 32 / WMV;           // 32-row tiles per wave
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(WMV * 256, (BM / WMV) >= 96 ? 1 : (BM / WMV) >= 64 
     if constexpr (t < TM) {                                                                                 \
         acc##t += cor##t * SPLIT_LO_INV;                                                                    \
         if (g.range_flag) range_check(acc##t, g.range_flag);                                                \
-        if (fragq) emit_tile_frag(acc##t, pre##t.bn, mtile + 32 * t, h, c, M, g.frag_out, g.frag_T, g.frag_invT, g.frag_heads, \
+        if constexpr (TR) emit_tile_pre_tr(acc##t, pre##t.bn, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, patch);   \
+        else if (fragq) emit_tile_frag(acc##t, pre##t.bn, mtile + 32 * t, h, c, M, g.frag_out, g.frag_T, g.frag_invT, g.frag_heads, \
                                   (ntile % g.frag_D) >> 6, ntile / g.frag_D, (ntile >> 5) & 1, patch);          \
         else if (wide) emit_tile_pre_wide(acc##t, pre##t, mtile + 32 * t, h, c, ntile, M, N, C, ldc, act, res != nullptr, alpha, so, \
                                      g.nt_store, patch);                                                    \
@@ -292,6 +295,11 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     // cannot address -- an activation or weight extent of 2 GiB and more, i.e. M * lda beyond 2^29 floats)
     const int64_t a_bytes = (int64_t)g.M * g.lda * (int64_t)sizeof(float), w_bytes = (int64_t)((g.N + 31) / 32 * 32) * g.K * (int64_t)sizeof(float);
     if (a_bytes >= (int64_t)1 << 31 || w_bytes >= (int64_t)1 << 31) pick = 65;
+    if (g.c_transposed) {   // (column bias + activation only; operands within the 32-bit buffer offsets: the caller's business)
+        const int tm64 = (g.M + 63) / 64;
+        hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
+        return;
+    }
     if (pick == 32) {
         const int tm32 = (g.M + 31) / 32;
         hipLaunchKernelGGL((gemm_split_wd_kernel<32, 1, true>), dim3(tm32 * tiles_n), dim3(256), 0, s, g, tm32, tiles_n);

@@ -51,6 +51,9 @@ struct GemmArgs {
     // LDS-staged kernels: an XCD's consecutive tiles walk the ROW tiles of one column panel (they share the B panel) instead
     // of the column tiles of one row panel: for launches whose B operand is the large one.  Same tiles, same bits.
     int m_fastest;
+    // weights-direct kernel: the result leaves transposed, C^T[n][m] at C + n * ldc + m (column bias and activation only;
+    // no residual, no split output)
+    int c_transposed;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
