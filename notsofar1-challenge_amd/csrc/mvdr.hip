@@ -64,7 +64,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 constexpr int SCM_WAVES = 2;   // bins per block
 
-template <int NI>   // 64-frame pieces of a segment: 4 (T <= 256) or 8 (T <= 512)
+template <int NI, int TS_ = NI * 64>   // 64-frame pieces of a segment: 4 (T <= 256) or 8 (T <= 512); TS_: the tile's row length
 __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float scm_lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (wave-uniform for the compiler: the rows' buffer descriptors live in scalar registers)
@@ -78,11 +78,14 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
     const int64_t st = seg * (int64_t)a.hop;
     // wave-private tile: x[14][TS] (rows c: Re, 7 + c: Im), m[4][TS], TS = NI * 64 (whole 64-frame pieces, so that a piece is
     // stored without a lane mask), then the four frame lists (uint16) and 4 x 98 doubles
-    constexpr int TS = NI * 64;
-    float* xs = scm_lds + (size_t)wave * ((14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2);
+    // (TS_ = 192 for the shipped 3 s segments, with the group totals laid over the tile -- dead by then: 15.4 KB per wave, ten
+    // waves per CU instead of eight.  The launch is 10 280 waves: 5.02 rounds of 2 048 slots are six rounds, 4.02 of 2 560 five.)
+    constexpr int TS = TS_;
+    constexpr bool TOT_OVER_TILE = TS_ < NI * 64;
+    float* xs = scm_lds + (size_t)wave * ((14 + 4) * TS + 2 * TS + (TOT_OVER_TILE ? 0 : 4 * 2 * NPACK * 2));
     float* ms = xs + 14 * TS;
     unsigned short* lists = reinterpret_cast<unsigned short*>(ms + 4 * TS);    // [4][TS]
-    double* tot = reinterpret_cast<double*>(ms + 4 * TS + 2 * TS);             // [4][2 * NPACK] group totals (8-byte aligned)
+    double* tot = reinterpret_cast<double*>(TOT_OVER_TILE ? xs : ms + 4 * TS + 2 * TS);   // [4][2 * NPACK] group totals (8-byte aligned)
     // ---- the bin's rows, contiguous along time: every load of the 18 rows is in flight before the first LDS store
     // (row by row, a wave waited out 18 memory round trips).  Buffer loads: a row is a buffer of `tv` floats (0 for a mask
     // row the model does not have), frames past it read as zero by the hardware's bounds check -- no lane mask, no branch
@@ -314,7 +317,9 @@ bool launch_scm(const MvdrArgs& a, hipStream_t s) {
     const int TS = a.T <= 256 ? 256 : 512;
     const size_t per_wave = ((size_t)(14 + 4) * TS + 2 * TS + 4 * 2 * NPACK * 2) * sizeof(float);
     const dim3 grid((a.F + SCM_WAVES - 1) / SCM_WAVES, a.nseg), block(64 * SCM_WAVES);
-    if (a.T <= 256) {
+    if (a.T <= 192) {   // (A/B on one box: 90.2 -> 74.5 us per 40 segments)
+        hipLaunchKernelGGL((scm_kernel<4, 192>), grid, block, (size_t)(20 * 192) * sizeof(float) * SCM_WAVES, s, a);
+    } else if (a.T <= 256) {
         hipLaunchKernelGGL(scm_kernel<4>, grid, block, per_wave * SCM_WAVES, s, a);
     } else {   // up to 8 s segments: 82 KB of LDS per block
         // (the attribute is per device: set on every launch -- a host-side table lookup -- not behind a process-wide flag
