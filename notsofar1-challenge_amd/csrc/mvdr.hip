@@ -4,6 +4,9 @@
 // The 7x7 spatial covariance matrices are accumulated and solved in float64 (the reference does
 // this in complex64, which leaves it ~2e-5 from the exact answer; float64 keeps our
 // own distance from the exact answer negligible, so the distance to the reference is the reference's).
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace css {
@@ -507,7 +510,10 @@ __global__ __launch_bounds__(256) void beamform_kernel(MvdrArgs a) {
 }
 
 void launch_beamform(const MvdrArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(beamform_kernel, dim3(a.F, a.nseg), dim3(256), 0, s, a);
+    // as many waves as the segment has 64-frame pieces (3 s segments: 186 frames on 192 threads instead of 256; ten blocks
+    // per CU instead of eight -- 40 x 257 blocks are 4.02 rounds of 2 560 slots instead of 5.02 of 2 048: 50.3 -> 47.3 us)
+    const int threads = std::min(256, (a.T + 63) / 64 * 64);
+    hipLaunchKernelGGL(beamform_kernel, dim3(a.F, a.nseg), dim3(threads), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
