@@ -48,8 +48,12 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 //   input 0: masks   input 1: |separated spectrum|     loss 0: L1   loss 1: squared error
 // ------------------------------------------------------------------------------------------------
 // frequency chunks per boundary: 39 boundaries alone would occupy 39 of 256 CUs; with 48 a thread takes two (bin, frame)
-// elements, all of whose loads are in flight at once (16 chunks: six dependent rounds of loads per thread)
-constexpr int PIT_CH = 48;
+// elements, all of whose loads are in flight at once (16 chunks: six dependent rounds of loads per thread).  A long
+// meeting has boundaries enough (1 208 in 30 min: 58 k blocks of 48 chunks took 383 us against 305 us with 16), so the
+// count follows the MEETING's number of boundaries -- not the range a call or a rank computes: the chunk sums are added in
+// a fixed order and a cost must be the same bit pattern wherever it is computed.
+constexpr int PIT_CH = 48;   // the most (scratch layout)
+__host__ __device__ inline int pit_chunks(int64_t num_segments) { return num_segments - 1 < 128 ? PIT_CH : 16; }
 
 // One block per (boundary, frequency chunk) -> partial[b][chunk][16]; a second kernel adds the chunks in a fixed
 // order, so the cost is the same bit pattern whatever boundary range or GPU computes it.
@@ -57,9 +61,9 @@ __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, i
                                                        double* __restrict__ partial) {
     __shared__ double red[4][SMAX * SMAX];
     const int64_t b = b_lo + blockIdx.x;
-    const int ch = blockIdx.y;
+    const int ch = blockIdx.y, nch = (int)gridDim.y;
     const int S = a.S, F = a.F, T = a.T, ov = a.T - a.hop;
-    const int f_lo = (int)((int64_t)F * ch / PIT_CH), f_hi = (int)((int64_t)F * (ch + 1) / PIT_CH);
+    const int f_lo = (int)((int64_t)F * ch / nch), f_hi = (int)((int64_t)F * (ch + 1) / nch);
     double acc[SMAX * SMAX];
 #pragma unroll
     for (int i = 0; i < SMAX * SMAX; ++i) acc[i] = 0.0;
@@ -102,14 +106,14 @@ __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, i
 }
 
 __global__ __launch_bounds__(64) void pit_cost_final_kernel(const double* __restrict__ partial, int S, int F, int ov,
-                                                            int64_t b_lo, int64_t b_hi, double* __restrict__ costs) {
+                                                            int64_t b_lo, int64_t b_hi, double* __restrict__ costs, int nch) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int ss = S * S;
     if (i >= (b_hi - b_lo) * ss) return;
     const int64_t b = b_lo + i / ss;
     const int e = (int)(i % ss), q = (e / S) * SMAX + e % S;
     double v = 0.0;
-    for (int ch = 0; ch < PIT_CH; ++ch) v += partial[(b * PIT_CH + ch) * (SMAX * SMAX) + q];
+    for (int ch = 0; ch < nch; ++ch) v += partial[(b * PIT_CH + ch) * (SMAX * SMAX) + q];
     costs[b * ss + e] = v / ((double)F * ov);
 }
 
@@ -118,10 +122,11 @@ size_t pit_cost_scratch_bytes(int64_t n_boundaries) { return (size_t)std::max<in
 void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* scratch, double* costs,
                       hipStream_t s) {
     if (b_hi <= b_lo) return;
-    hipLaunchKernelGGL(pit_cost_kernel, dim3((unsigned)(b_hi - b_lo), PIT_CH), dim3(256), 0, s, a, loss, input, b_lo, scratch);
+    const int nch = pit_chunks(a.num_segments);
+    hipLaunchKernelGGL(pit_cost_kernel, dim3((unsigned)(b_hi - b_lo), nch), dim3(256), 0, s, a, loss, input, b_lo, scratch);
     const int64_t n = (b_hi - b_lo) * a.S * a.S;
     hipLaunchKernelGGL(pit_cost_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, scratch, a.S, a.F, a.T - a.hop, b_lo,
-                       b_hi, costs);
+                       b_hi, costs, nch);
 }
 
 // ------------------------------------------------------------------------------------------------
