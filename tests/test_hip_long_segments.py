@@ -92,6 +92,41 @@ def test_long_clip_lengths_vs_oracle(L, mix60, frames):
         sep.close()
 
 
+def test_single_channel_long_segments_vs_oracle(L, CSS, mix60):
+    """The single-channel model (no IPD rows, no MVDR: the masked reference microphone, css.py:204) with 10 s segments: a
+    2-block SC model, masks of every segment against the oracle, decisions exact, waveforms <= 1e-4 on the HIP masks."""
+    import dataclasses
+    w = pkg("weights")
+    desc = dataclasses.replace(w.ModelDesc.sc_v1(), num_blocks=2)
+    st = w.apply_golden_recipe(w.portable_state_dict(desc, 29))
+    params = O.ConformerParams(st)
+    mix = np.ascontiguousarray(mix60[:, 4000:4000 + 26 * 16000 + 50, :1])
+    kw = dict(segment_size_sec=10.0, hop_size_sec=5.0, activity_th=0.3)
+    cfg, ocfg = CSS.CssCfg(show_progressbar=False, **kw), O.OracleCssCfg(**kw)
+    sep = pkg("separator").HipSeparator(st, None, device=0)
+    try:
+        wavs, side = CSS.separate_and_stitch(mix, sep, 16000, "cuda:0", cfg)
+        h = sep.handle
+        nseg, Ts = int(h.get_plan().num_segments), 624
+        assert side["segment_frames"] == Ts and nseg >= 4
+        m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, Ts)
+        X = O.stft(mix[0, :, 0])                                     # [F, T_long] (one channel)
+        for i in range(nseg):
+            seg = np.zeros((F, Ts), np.complex64)
+            part = X[:, i * 312:i * 312 + Ts]
+            seg[:, :part.shape[1]] = part
+            om = O.conformer_forward(params, O.features(seg))
+            assert np.abs(m[:, :, i] - om).max() < 5e-5, i
+        hip_masks = [(np.moveaxis(m[:S, :, i], 0, 2), np.moveaxis(m[S:, :, i], 0, 2)) for i in range(nseg)]
+        ow, oside = O.separate_and_stitch(mix, params, 16000, ocfg, separate_fn=lambda i, seg: hip_masks[i])
+        assert np.array_equal(h.read(L.BUF_PERMS), np.array(oside["perms"]))
+        assert np.array_equal(side["activity_final"].numpy(), oside["activity_final"])
+        for k in range(S):
+            assert rel_rms(wavs[k], ow[k]) < 1e-4, k
+    finally:
+        sep.close()
+
+
 def test_thousand_frame_segment_on_the_hip_features(L, CSS, mix60):
     """1000-frame segments (16 s) through a staged session: the feature rows against the oracle's (angles modulo 2 pi; at
     most a couple of the 1.5 million angles may sit on the other side of the atan2 cut, DESIGN.md hazard 7), and the masks
