@@ -40,6 +40,22 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.CssTimings) == 10 * 4 + 8 + 8 + 2 * 4
 
 
+def test_header_constants_agree_with_the_binding(L):
+    """The header's macros the Python side mirrors: the segment-length bound and the analysis windows; and the seconds ->
+    frames conversion on either side of the tuned kernels' 512 frames (css.py:144-152)."""
+    text = open(os.path.join(ROOT, "include", "css_mi355.h")).read()
+    macro = lambda name: int(re.search(rf"#define\s+{name}\s+(\d+)", text).group(1))
+    assert macro("CSS_MAX_SEGMENT_FRAMES") == L.MAX_SEGMENT_FRAMES
+    assert {"hann": macro("CSS_WINDOW_HANN"), "sqrt_hann": macro("CSS_WINDOW_SQRT_HANN")} == L.ANALYSIS_WINDOWS
+    CSS = pkg("css")
+    frames = lambda seg, hop: int(CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=seg, hop_size_sec=hop), 16000, 7).c.segment_frames)
+    assert (frames(3.0, 1.5), frames(8.0, 4.0), frames(9.0, 4.5), frames(10.0, 5.0), frames(60.0, 30.0)) == (186, 499, 561, 624, 3749)
+    with pytest.raises(NotImplementedError):
+        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=300.0, hop_size_sec=150.0), 16000, 7)      # beyond the 262 s sanity bound
+    with pytest.raises(NotImplementedError, match="1 <= hop < segment"):
+        CSS.make_run_cfg(CSS.CssCfg(segment_size_sec=3.0, hop_size_sec=3.0), 16000, 7)
+
+
 def test_blob_size_agrees_with_packer(L):
     w = pkg("weights")
     for desc in (w.ModelDesc.mc_v1(), w.ModelDesc.sc_v1(), w.ModelDesc(num_blocks=2)):
