@@ -203,8 +203,9 @@ enum css_tuning {
     CSS_TUNE_MVDR_ON_LANES = 3, /* 1 (default): covariances / MVDR / stitching costs at the end of each lane's chain; 0: after  */
     CSS_TUNE_PIPELINE_DEVICE = 4, /* 1: css_run_device also takes the unit pipeline; 0 (default): the plain stage sequence    */
     CSS_TUNE_GROUP_LANES = 5,   /* lanes of a batch shared by queued sessions (css_run_enqueue), 1..4, default 2               */
-    CSS_TUNE_GROUP_TRANSFORM_ON_MAIN = 6, /* 1: such a pass's analysis transforms as a prefix of the main stream; 0 (default): on
-                                           * the copy stream, behind each session's upload, beside the previous pass's estimator */
+    CSS_TUNE_GROUP_TRANSFORM_ON_MAIN = 6, /* 1 (default): such a pass's analysis transforms as a prefix of the main stream; 0: on
+                                           * the copy stream, behind each session's upload, beside the previous pass's estimator
+                                           * (1 % slower in interleaved A/B: what the copy stream runs competes with the estimator) */
     CSS_TUNE_GROUP_MVDR_ON_LANES = 7,     /* 1: its covariances / MVDR / stitching costs on the lanes' streams, joined; 0 (default):
                                            * on the tail stream with everything else behind the mask head                        */
     CSS_TUNE_GROUP_OUT_DMA = 8,           /* 1 (default): its waveforms are overlap-added into HBM and copied out by DMA; 0: the

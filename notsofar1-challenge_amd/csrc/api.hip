@@ -139,7 +139,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 0, 0, 1};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
