@@ -210,7 +210,10 @@ enum css_tuning {
                                            * on the tail stream with everything else behind the mask head                        */
     CSS_TUNE_GROUP_OUT_DMA = 8,           /* 1 (default): its waveforms are overlap-added into HBM and copied out by DMA; 0: the
                                            * overlap-add kernel writes the page-locked output over PCIe itself                   */
-    CSS_TUNE_COUNT = 9
+    CSS_TUNE_F32_GEMM = 9,                /* CSS_LINEAR_EXACT_F32 products: 0 (default): gemm_f32.hip, four independent blocks per CU and
+                                           * tile heights balanced over the CUs; 1: the round-4 kernel (gemm.hip); 2..5: gemm_f32.hip with
+                                           * every tile 32 / 64 / 96 / 128 rows.  Same bits whichever                               */
+    CSS_TUNE_COUNT = 10
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

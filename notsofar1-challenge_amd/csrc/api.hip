@@ -139,7 +139,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1, 0};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -159,7 +159,26 @@ struct css_ctx : SessState {
     int last_piped = -1;      // overlap mode of the last queued pass (-1: nothing queued): a queue never mixes modes un-drained
     // css_run_enqueue's arguments since the last css_wait: a queued pass that left the split-f16 range is repeated from
     // them on the exact float32 kernels (the caller keeps pcm_host valid and wav_host untouched until css_wait anyway)
-    struct QueuedPass { const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; float* wav; int64_t cap; };
+    struct QueuedPass {
+        const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; float* wav; int64_t cap;
+        std::vector<float> w;   // the three stitching windows of cfg, copied at css_run_enqueue (the caller may free its own)
+        QueuedPass(const float* pcm_, int64_t n_, int32_t n_ch_, const CssRunCfg& c, float* wav_, int64_t cap_)
+            : pcm(pcm_), n(n_), n_ch(n_ch_), cfg(c), wav(wav_), cap(cap_) {
+            const size_t T = (size_t)std::max(c.segment_frames, 0);
+            w.resize(3 * T);
+            if (T && c.w_first && c.w_mid && c.w_last) {
+                std::memcpy(w.data(), c.w_first, T * sizeof(float));
+                std::memcpy(w.data() + T, c.w_mid, T * sizeof(float));
+                std::memcpy(w.data() + 2 * T, c.w_last, T * sizeof(float));
+            }
+        }
+        CssRunCfg own_cfg() const {   // cfg with its window pointers at this entry's copies
+            CssRunCfg c = cfg;
+            const size_t T = w.size() / 3;
+            c.w_first = w.data(); c.w_mid = w.data() + T; c.w_last = w.data() + 2 * T;
+            return c;
+        }
+    };
     std::vector<QueuedPass> queue_log;
     // css_run_enqueue: sessions accepted and not yet on the streams -- they wait for company: sessions of one segment
     // length are merged into ONE estimator batch (run_group) as long as their segments fit max_batch_segments
@@ -438,6 +457,13 @@ struct Prof {
 void gemm(css_ctx* h, const GemmArgs& g, hipStream_t st) {
     CSS_PROF(CSS_PROF_LINEAR, st);
     if (h->profile_gemm) h->gemm_flops += 2.0 * g.M * (double)g.N * g.K * g.batch;
+    if (!g.split_in && !g.layout && h->tune[CSS_TUNE_F32_GEMM]) {   // (A/B and tests: which exact float32 kernel; same bits)
+        GemmArgs q = g;
+        const int t = h->tune[CSS_TUNE_F32_GEMM];
+        q.layout = t == 1 ? 2 : 10 + std::min(t - 1, 4);
+        launch_gemm(q, st);
+        return;
+    }
     launch_gemm(g, st);
 }
 
@@ -1868,7 +1894,10 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     for (auto& e : h->pass_end)
         if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (h->pass_no >= CSS_QUEUE_LEAD) HIPCHK(h, hipEventSynchronize(h->pass_end[(h->pass_no - CSS_QUEUE_LEAD) & 3]));
-    {   // whatever the handle's stream holds from before the queue (weights, an earlier synchronous pass) comes first
+    if (!h->queued) {
+        // whatever the handle's stream holds from BEFORE the queue (weights, an earlier synchronous pass) comes first.  Only
+        // the first pass of a queue waits for it: a later pass's uploads are ordered by pcm_free / level_free / tail_end, and
+        // a wait on the main stream here would put them behind the previous pass's estimator instead of beside it
         hipEvent_t opened = pool_event(h);
         HIPCHK(h, hipEventRecord(opened, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, opened, 0));
@@ -1990,11 +2019,24 @@ static int flush_pending(css_handle_t h) {
     std::vector<css_ctx::Pending> grp;
     grp.swap(h->pending);
     h->pending_segments = 0;
+    int rc;
     if (grp.size() == 1) {
         RunIo io; io.pcm_host = grp[0].pcm; io.wav_host = grp[0].wav; io.cap = grp[0].cap; io.enqueue_only = true;
-        return run_once(h, grp[0].n, grp[0].n_ch, &grp[0].cfg, io);
+        rc = run_once(h, grp[0].n, grp[0].n_ch, &grp[0].cfg, io);
+    } else {
+        rc = run_group(h, grp);
     }
-    return run_group(h, grp);
+    if (rc != CSS_OK) {
+        // sessions css_run_enqueue had accepted are dropped with this error: take them out of the repeat log (they are its
+        // last grp.size() entries -- nothing is logged between an acceptance and its flush) and name them
+        const size_t drop = std::min(grp.size(), h->queue_log.size());
+        const size_t first = h->queue_log.size() - drop;
+        h->queue_log.resize(first, css_ctx::QueuedPass(nullptr, 0, 0, CssRunCfg{}, nullptr, 0));
+        const std::string why = h->err;
+        return fail(h, rc, "queued session(s) " + std::to_string(first) + " .. " + std::to_string(first + drop - 1) +
+                               " (counted from the last css_wait) were accepted and could not be started; they are dropped: " + why);
+    }
+    return CSS_OK;
 }
 
 // The pass, and -- when an operand left the split-f16 range (a split GEMM saw a non-finite accumulator) -- the same pass
@@ -2043,7 +2085,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
         RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
         rc = run_once(h, n_samples, n_ch, cfg, io);
-        if (rc == CSS_OK) h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
+        if (rc == CSS_OK) h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
         return rc;
     }
     const int T = cfg->segment_frames;
@@ -2068,7 +2110,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
         }
     }
     h->pending_segments += pl.num_segments;
-    h->queue_log.push_back({pcm_host, n_samples, n_ch, *cfg, wav_host, cap});
+    h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
     // no session of this length would still fit, or the group is full: off it goes -- nothing waits for a css_wait that
     // could already run
     if (h->pending_segments + pl.num_segments > h->max_batch || (int)h->pending.size() >= h->group_limit) return flush_pending(h);
@@ -2088,7 +2130,7 @@ int css_wait(css_handle_t h) {
         const int rc_flush = flush_pending(h);
         if (rc_flush != CSS_OK) { h->queue_log.clear(); return rc_flush; }
     }
-    if (!h->queued) return CSS_OK;
+    if (!h->queued) { h->queue_log.clear(); return CSS_OK; }
     HIPCHK(h, hipSetDevice(h->device));
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2118,7 +2160,8 @@ int css_wait(css_handle_t h) {
         for (; repeated < log.size() && rc == CSS_OK; ++repeated) {
             const css_ctx::QueuedPass& q = log[repeated];
             RunIo io; io.pcm_host = q.pcm; io.wav_host = q.wav; io.cap = q.cap;
-            rc = run_once(h, q.n, q.n_ch, &q.cfg, io);
+            const CssRunCfg own = q.own_cfg();
+            rc = run_once(h, q.n, q.n_ch, &own, io);
         }
         const std::string why = h->err;
         const int rc2 = css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16);
@@ -2674,7 +2717,9 @@ static int buffer_info(css_ctx* h, int which, DevBuf** buf, int64_t dims[4], int
         case CSS_BUF_X: *buf = &h->X; dims[0] = h->n_ch; dims[1] = 2 * F; dims[2] = h->T_ld; break;
         case CSS_BUF_FEATURES: *buf = &h->feat; dims[0] = h->last_batch_tokens; dims[1] = h->Kp; break;
         case CSS_BUF_MASKS:   // (a session of a queued group holds its masks as columns of the group's buffer: not readable)
-            if (h->masks_v != (float*)h->masks.p || h->mask_ld_v != nseg * T) return CSS_ERR_STATE;
+            if (h->masks_v != (float*)h->masks.p || h->mask_ld_v != nseg * T)
+                return fail(h, CSS_ERR_STATE, "the masks of a session that shared a queued estimator batch are columns of the group's "
+                                              "buffer: not addressable as CSS_BUF_MASKS (css_write_buffer re-homes them)");
             *buf = &h->masks; dims[0] = (int64_t)(S + 1) * F; dims[1] = nseg * T; break;
         case CSS_BUF_SCM: *buf = &h->scm; dims[0] = nseg; dims[1] = S + 1; dims[2] = F; dims[3] = 49; *elem = 8; break;
         case CSS_BUF_BFW: *buf = &h->bfw; dims[0] = nseg; dims[1] = S; dims[2] = F; dims[3] = 14; *elem = 8; break;
@@ -2700,7 +2745,8 @@ int css_buffer_dims(css_handle_t h, int which, int64_t dims[4], int32_t* elem_by
     int rc = check_session(h);
     if (rc) return rc;
     DevBuf* b;
-    if (!dims || !elem_bytes || buffer_info(h, which, &b, dims, elem_bytes) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    if (!dims || !elem_bytes) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if ((rc = buffer_info(h, which, &b, dims, elem_bytes)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
     return CSS_OK;
 }
 
@@ -2711,7 +2757,8 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes) {
     DevBuf* b;
     int64_t dims[4];
     int32_t el;
-    if (!host || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    if (!host) return fail(h, CSS_ERR_INVALID_ARG, "null host pointer");
+    if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
     const int64_t need = dims[0] * dims[1] * dims[2] * dims[3] * el;
     if (nbytes != need || !b->p) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2751,7 +2798,12 @@ int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes
     DevBuf* b;
     int64_t dims[4];
     int32_t el;
-    if (!host || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    if (which == CSS_BUF_MASKS) {   // written masks are the session's own [(S+1) F][nseg T] matrix (also after a grouped pass)
+        h->masks_v = (float*)h->masks.p;
+        h->mask_ld_v = h->plan.num_segments * h->cfg.segment_frames;
+    }
+    if (!host) return fail(h, CSS_ERR_INVALID_ARG, "null host pointer");
+    if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
     const int64_t need = dims[0] * dims[1] * dims[2] * dims[3] * el;
     if (nbytes != need) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2772,7 +2824,8 @@ int css_buffer_devptr(css_handle_t h, int which, void** out) {
     DevBuf* b;
     int64_t dims[4];
     int32_t el;
-    if (!out || buffer_info(h, which, &b, dims, &el) != CSS_OK) return fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    if (!out) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
     *out = b->p;
     return CSS_OK;
 }

@@ -173,7 +173,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
     if (g.split_in) return g.b_tiled ? launch_gemm_split_wd(g, s) : launch_gemm_split(g, s);
-    const int forced = g.layout;
+    int forced = g.layout;
+    if (forced == 0 || forced == 1 || (forced >= 11 && forced <= 14)) {
+        if (launch_gemm_f32(g, s, forced >= 11 ? forced - 10 : 0)) return;
+        forced = 0;   // (an operand of 2 GiB and more: the kernel below addresses with 64-bit pointers)
+    }
+    if (forced == 2) forced = 0;   // layout 2: this file's kernel with its own choice of tile (the round-4 default; A/B, tests)
     const int tiles_n = (g.N + BN - 1) / BN;
     const int blocks128 = ((g.M + 127) / 128) * tiles_n * g.batch;
     int layout = forced ? forced : (blocks128 < 1000 ? 8 : 4);

@@ -1,0 +1,293 @@
+// Exact float32 MFMA GEMM for gfx950, second form (round 5):  C[m][n] = epilogue( sum_k A[m][k] * B[n][k] ).
+//
+// Same arithmetic as gemm.hip (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain; the same K permutation inside each
+// group of 8 k), so every output is bit for bit what gemm_kernel writes -- what changes is how the matrix pipe is fed:
+//
+//   * FOUR independent 4-wave blocks per CU instead of one 8-wave block.  The round-4 kernel needs 169 registers, i.e.
+//     two waves per SIMD, both from ONE block: they run the same 32 MFMAs between the same barriers, and the pipe idles
+//     while both store the next slab, meet and wait for their first operand reads (a slab takes 2 680 cycles for 2 048 of
+//     MFMA issue with one wave per SIMD, tools/gemm_f32_bench.hip).  Here a wave owns 32 COLUMNS of the block's tile and all
+//     of its rows (TM row tiles of 32: at most 64 accumulator registers), the slab is 16 deep and double buffered
+//     (2 x (128 + 128) rows x 20 floats = 40 960 B: exactly a quarter of the CU's 160 KB), and the kernel stays
+//     under 128 registers -- four waves per SIMD from four blocks that fill each other's bubbles.
+//   * PERSISTENT blocks over a balanced cut of the work.  The launch is 1 024 blocks (4 x 256 CUs); the output is
+//     counted in UNITS of 32 rows x 128 columns, the units of a launch are a line (batch entry, column panel, row unit --
+//     row unit fastest), every "virtual CU" takes an equal contiguous piece of that line and each of its four blocks a
+//     quarter of the piece, walked in tiles of 1..4 units.  A block's time is proportional to its units, so every CU is
+//     busy for ceil(units / 256) unit times whatever M is: M = 22 320 x N = 512 is 2 792 units = 10.9 per CU, where 700
+//     tiles of 128 rows leave a quarter of the CUs with 12 units and the rest with 8.
+//   * The four blocks of a CU are kept OUT OF PHASE: their first tiles have different heights, so their tile ends --
+//     the epilogue's residual reads and result writes, the next tile's cold first slab -- fall into the other blocks'
+//     K loops instead of all CUs leaving the matrix pipe idle together (one round of equal tiles: 25 us of a 116 us
+//     launch was prologue + epilogue, fitted over K).
+//   * Operands arrive by buffer loads (rows past M / N read zeros: no clamped row pointers, one offset register per
+//     operand); the epilogue requests a tile's residual values one 32 x 32 tile ahead (the first under the last slab's
+//     MFMAs) and writes 16-byte row pieces after a turn through a wave-private LDS patch.
+#include <algorithm>
+
+#include "gemm_common.hpp"
+
+namespace css {
+
+namespace {
+
+constexpr int F_BK = 16;                     // slab depth
+constexpr int F_LD = 20;                     // LDS row stride in floats: 5 * row mod 16 is a bijection -> conflict-free ds_read_b128
+constexpr int F_BUF = (128 + BN) * F_LD;     // floats per slab buffer (A region sized for the tallest tile)
+constexpr int F_PATCH_LD = 36;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float epi_value(float acc, float bn, float bm, int act, bool has_res, float rv, float alpha) {
+    float v = acc + bn + bm;
+    if (act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == ACT_SIGMOID) v = sigmoidf_(v);
+    if (has_res) v = rv + alpha * v;
+    return v;
+}
+
+template <int TM>
+__device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restrict__ A, const float* __restrict__ B,
+                                         float* __restrict__ C, const int m0, const int n0, float* __restrict__ lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int M = g.M, N = g.N;
+    constexpr int BM = 32 * TM;
+    constexpr int NPA = (BM + 63) / 64;      // staging passes over the A tile (64 rows x 16 floats per pass)
+    // ---- staging: thread -> (row srow + 64 i, floats sk .. sk + 3) of the slab
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((int64_t)M * g.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)((int64_t)N * g.ldb * 4), 0x00020000);
+    const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
+    const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
+    const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
+#ifndef F32_DMA
+#define F32_DMA 0   // 1: global -> LDS by the DMA path (buffer_load ... lds), unpadded 64-byte LDS rows with an XOR swizzle
+#endif
+#if F32_DMA
+    // LDS row r (16 floats = four 16-byte slots) holds its k segment s in slot s ^ ((r >> 2) & 3): the 16 lanes of a
+    // ds_read_b128 group then hit 16 distinct bank quads.  The DMA writes lane l's 16 bytes at base + 16 l, so lane l
+    // (row l >> 2 of its wave's 16 rows, slot l & 3) FETCHES segment (l & 3) ^ ((row >> 2) & 3).
+    constexpr int D_BUF = (128 + BN) * 16;
+    const int dseg = ((tid & 3) ^ ((tid >> 4) & 3)) * 4;
+    const int dvoA = (int)(((int64_t)(m0 + srow) * g.lda + dseg) * 4), dvoB = (int)(((int64_t)(n0 + srow) * g.ldb + dseg) * 4);
+    const bool a1_wave = (BM % 64 == 0) || w < (BM % 64) / 16;   // (wave-uniform: a wave covers 16 rows of a pass)
+    typedef __attribute__((address_space(3))) void lds_void;
+#define F32_GLOAD(k0, buf)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                            \
+        if (i + 1 < NPA || a1_wave)                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(lds + (buf) * D_BUF + (i * 64 + 16 * w) * 16), 16, dvoA, (k0) * 4 + i * passA, 0, 0); \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(lds + (buf) * D_BUF + (128 + i * 64 + 16 * w) * 16), 16, dvoB, (k0) * 4 + i * passB, 0, 0);
+#define F32_LSTORE(buf) __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's pieces of the next slab have landed */
+#else
+    f32x4 ra[NPA], rb[2];
+#define F32_GLOAD(k0, buf)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                            \
+        if (i + 1 < NPA || a1_on) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (k0) * 4 + i * passA, 0)); \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voB, (k0) * 4 + i * passB, 0));
+#define F32_LSTORE(buf)                                                                                          \
+    {                                                                                                            \
+        float* as_ = lds + (buf) * F_BUF + srow * F_LD + sk;                                                     \
+        _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                        \
+            if (i + 1 < NPA || a1_on) *reinterpret_cast<f32x4*>(as_ + i * 64 * F_LD) = ra[i];                    \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(as_ + (128 + i * 64) * F_LD) = rb[i]; \
+    }
+#endif
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i] = f32x16{0};
+    const int nk = g.K / F_BK;
+    F32_GLOAD(0, 0)
+    F32_LSTORE(0)
+    __syncthreads();
+#if F32_DMA
+    constexpr int S_BUF = D_BUF, S_LD = 16;
+    const int sw4 = ((c >> 2) & 3) * 4;
+    const int aoff = c * 16, boff = (128 + 32 * w + c) * 16;
+#define F32_SLOT(ch) (((8 * (ch) + 4 * h)) ^ sw4)
+#else
+    constexpr int S_BUF = F_BUF, S_LD = F_LD;
+    const int aoff = c * F_LD + 4 * h, boff = (128 + 32 * w + c) * F_LD + 4 * h;
+#define F32_SLOT(ch) (8 * (ch))
+#endif
+    // epilogue operands: lane -> rows (lane >> 3) + 8 j of each 32 x 32 tile, columns n .. n + 3
+    const float* __restrict__ bias = g.bias;
+    const float* __restrict__ res = g.residual;
+    const int act = g.act;
+    const bool bias_m = bias && g.bias_along_m, bias_n = bias && !g.bias_along_m, has_res = res != nullptr;
+    const int64_t ldc = g.ldc, ldr = g.ldr;
+    const float alpha = g.alpha;
+    const bool wide = (ldc % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (!has_res || ((ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0)));
+    f32x4 rv[2][4];   // residual pieces of the tile being written and of the next one
+    // (lane_ is `lane` behind a compiler barrier at the call sites below: the 64-bit row addresses of the epilogue must
+    // not be formed before the K loop and carried through it -- the loop has no registers to spare)
+    auto prefetch = [&](int i, int slot, int lane_) {
+        const int n_ = n0 + 32 * w + (lane_ & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 32 * i + (lane_ >> 3) + 8 * j;
+            const int mc = m < M ? m : M - 1;
+            rv[slot][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_res && n_ < N) {
+                if (wide) {
+                    rv[slot][j] = *reinterpret_cast<const f32x4*>(res + (int64_t)mc * ldr + n_);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[slot][j][e] = res[(int64_t)mc * ldr + (n_ + e < N ? n_ + e : N - 1)];
+                }
+            }
+        }
+    };
+#ifndef F32_ABLATE
+#define F32_ABLATE 0   // tools: timing probes (wrong results): 1 no slab barrier, 2 no global loads / LDS stores, 4 no LDS operand reads; 8 (right results): accumulators in AGPRs
+#endif
+    f32x4 abl_a = {1.f, 2.f, 3.f, (float)lane}, abl_b = {0.5f, 0.25f, (float)w, 1.f};
+#define F32_COMPUTE(buf)                                                                                         \
+    {                                                                                                            \
+        const float* as = lds + (buf) * S_BUF + aoff;                                                            \
+        const float* bs = lds + (buf) * S_BUF + boff;                                                            \
+        _Pragma("unroll") for (int ch = 0; ch < 2; ++ch) {                                                       \
+            f32x4 b = abl_b;                                                                                     \
+            if (!(F32_ABLATE & 4)) b = *reinterpret_cast<const f32x4*>(bs + F32_SLOT(ch));                       \
+            f32x4 a[TM];                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
+                a[i] = abl_a;                                                                                    \
+                if (!(F32_ABLATE & 4)) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * S_LD + F32_SLOT(ch)); \
+            }                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
+                    if (F32_ABLATE & 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i][e]), "v"(b[e])); \
+                    else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[e], acc[i], 0, 0, 0);          \
+                }                                                                                                \
+            }                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+        }                                                                                                        \
+    }
+    // slabs 0 .. nk - 2: the next slab travels global -> registers under this slab's MFMAs, then registers -> LDS
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        if (!(F32_ABLATE & 2)) { F32_GLOAD((kt + 1) * F_BK, (kt + 1) & 1) }
+        __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the loads below the MFMAs, next to their LDS stores)
+        F32_COMPUTE(kt & 1)
+        if (!(F32_ABLATE & 2)) { F32_LSTORE((kt + 1) & 1) }
+        if (!(F32_ABLATE & 1)) __syncthreads();
+    }
+    // the last slab: the first tile's epilogue operands travel under its MFMAs
+    {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        prefetch(0, 0, lane_);
+    }
+    F32_COMPUTE((nk - 1) & 1)
+    __syncthreads();
+#undef F32_COMPUTE
+#undef F32_SLOT
+#undef F32_GLOAD
+#undef F32_LSTORE
+
+    // ---- epilogue: every 32 x 32 tile takes a turn through the wave's LDS patch and leaves as 16-byte row pieces
+    // (the slab buffers are free: the loop ended with a barrier)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    float* patch = lds + w * (32 * F_PATCH_LD);
+    const int col4 = (lane_e & 7) * 4, n = n0 + 32 * w + col4, erow = lane_e >> 3;
+    const bool col_ok = n < N;
+    float bn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias_n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bn[e] = bias[n + e < N ? n + e : N - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * F_PATCH_LD + c] = acc[i][r];
+        // (a wave's own LDS writes and reads are in order: no barrier)
+        if (i + 1 < TM) prefetch(i + 1, (i + 1) & 1, lane_e);   // (the registers of acc[i] are free now)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = erow + 8 * j, m = m0 + 32 * i + row;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * F_PATCH_LD + col4);
+            if (m >= M || !col_ok) continue;
+            float* dst = C + (int64_t)m * ldc + n;
+            const float bm = bias_m ? bias[m] : 0.f;   // (the mask head only: one launch per batch)
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = epi_value(v[e], bn[e], bm, act, has_res, rv[i & 1][j][e], alpha);
+            if (wide) {
+                *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) dst[e] = o[e];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// The work of a launch as a line of units (32 rows x 128 columns): index = (batch entry * tiles_n + column panel) * u + row
+// unit.  Virtual CU v of `ncu` takes [v U / ncu, (v + 1) U / ncu), its block j of four a quarter of that.
+struct F32Plan { int u, tiles_n, ncu, max_tm; int64_t U; unsigned long long* dbg; };   // dbg (tools): block 0 records shader / wall clocks
+
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * F_BUF];
+    const int b = blockIdx.x, v = b % p.ncu, j = b / p.ncu;
+    const int64_t lo = p.U * v / p.ncu, hi = p.U * (v + 1) / p.ncu;
+    int64_t pos = lo + (hi - lo) * j / 4;
+    const int64_t end = lo + (hi - lo) * (j + 1) / 4;
+    // first tile: 1 + (b + j) % 4 units -- neighbours in the grid AND blocks one stride apart differ, whichever of them the
+    // dispatcher puts on one CU; afterwards the tallest tile that fits
+    int want = std::min(1 + (b + j) % 4, p.max_tm);
+    bool first = true;
+    if (p.dbg && threadIdx.x == 0) {   // (tools: a census of the blocks -- where and when each ran)
+        p.dbg[4 * b + 0] = wall_clock64();
+        p.dbg[4 * b + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID | HW_ID
+        p.dbg[4 * b + 3] = __builtin_readcyclecounter();
+    }
+    while (pos < end) {
+        const int64_t panel = pos / p.u;
+        const int r = (int)(pos - panel * p.u);
+        const int tm = (int)std::min<int64_t>(std::min<int64_t>(want, end - pos), p.u - r);
+        const int bz = (int)(panel / p.tiles_n), tn = (int)(panel - (int64_t)bz * p.tiles_n);
+        const float* A = g.A + (int64_t)bz * g.strideA;
+        const float* B = g.B + (int64_t)bz * g.strideB;
+        float* C = g.C + (int64_t)bz * g.strideC;
+        if (!first) __syncthreads();   // the previous tile's epilogue patches lie over the slab buffers
+        first = false;
+        switch (tm) {
+            case 1: f32_tile<1>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            case 2: f32_tile<2>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            case 3: f32_tile<3>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            default: f32_tile<4>(g, A, B, C, 32 * r, tn * BN, lds); break;
+        }
+        pos += tm;
+        want = p.max_tm;
+    }
+    if (p.dbg && threadIdx.x == 0) { p.dbg[4 * b + 1] = wall_clock64(); p.dbg[4 * b + 3] = __builtin_readcyclecounter() - p.dbg[4 * b + 3]; }
+}
+
+// false: an operand the 32-bit buffer offsets cannot address, or a K that is not a multiple of 16 (use gemm_kernel)
+bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
+    if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return true;
+    if (g.K % F_BK) return false;
+    const int64_t lim = (int64_t)1 << 31;
+    if (((int64_t)g.M + 128) * g.lda * 4 >= lim || ((int64_t)g.N + 128) * g.ldb * 4 >= lim) return false;
+    constexpr int NCU = 256;
+    F32Plan p;
+    p.u = (g.M + 31) / 32;
+    p.tiles_n = (g.N + BN - 1) / BN;
+    p.ncu = NCU;
+    p.max_tm = (forced_tm >= 1 && forced_tm <= 4) ? forced_tm : 4;
+    p.U = (int64_t)p.u * p.tiles_n * g.batch;
+    p.dbg = g.narrow_epilogue == 77 ? reinterpret_cast<unsigned long long*>(g.range_flag) : nullptr;   // (tools/gemm_f32_bench.hip)
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(4 * NCU), dim3(256), 0, s, g, p);
+    return true;
+}
+
+}  // namespace css

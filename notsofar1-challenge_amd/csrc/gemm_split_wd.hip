@@ -295,9 +295,12 @@ void launch_gemm_split_wd(const GemmArgs& g_in, hipStream_t s) {
     // cannot address -- an activation or weight extent of 2 GiB and more, i.e. M * lda beyond 2^29 floats)
     const int64_t a_bytes = (int64_t)g.M * g.lda * (int64_t)sizeof(float), w_bytes = (int64_t)((g.N + 31) / 32 * 32) * g.K * (int64_t)sizeof(float);
     if (a_bytes >= (int64_t)1 << 31 || w_bytes >= (int64_t)1 << 31) pick = 65;
-    if (g.c_transposed) {   // (column bias + activation only; operands within the 32-bit buffer offsets: the caller's business)
+    if (g.c_transposed) {   // (column bias + activation only)
         const int tm64 = (g.M + 63) / 64;
-        hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
+        if (pick == 65)   // an operand beyond the 32-bit buffer offsets (>= 2 GiB): the 64-bit global-load form, same bits
+            hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, false, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_split_wd_kernel<64, 1, true, true>), dim3(tm64 * tiles_n), dim3(256), 0, s, g, tm64, tiles_n);
         return;
     }
     if (pick == 32) {

@@ -47,7 +47,9 @@ struct GemmArgs {
     // split kernels: *range_flag |= 1 when a finished accumulator is not finite -- an operand left the split-f16 range
     // (split_f16.hpp: nothing is clamped); checked here, in the consumer, because a ReLU downstream would launder a NaN
     unsigned int* range_flag;
-    int layout;            // LDS-staged kernels (gemm.hip, gemm_split.hip): 0 = choose, else 8 / 4 (128-row tiles, 8 / 4 waves) / 64
+    int layout;            // LDS-staged kernels (gemm.hip, gemm_split.hip): 0 = choose, else 8 / 4 (128-row tiles, 8 / 4 waves) / 64;
+                           // exact float32 only: 1 = gemm_f32.hip with its balanced plan (what 0 chooses), 11 .. 14 = gemm_f32.hip with
+                           // every tile 32 / 64 / 96 / 128 rows, 2 = gemm.hip's kernel with its own choice among 8 / 4 / 64
     // LDS-staged kernels: an XCD's consecutive tiles walk the ROW tiles of one column panel (they share the B panel) instead
     // of the column tiles of one row panel: for launches whose B operand is the large one.  Same tiles, same bits.
     int m_fastest;
@@ -56,6 +58,10 @@ struct GemmArgs {
     int c_transposed;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.split_in
+// gemm_f32.hip: the exact float32 product on four independent 4-wave blocks per CU with balanced tile heights (same bits as
+// gemm.hip's kernel); forced_tm = 1..4: every tile 32 * forced_tm rows, 0: the balanced plan.  false: not launched (an
+// operand beyond the 32-bit buffer offsets, K % 16): the caller takes gemm.hip's kernel
+bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm);
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
 void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s);  // gemm_split_wd.hip (g.b_tiled)
 // float32 W [N][K] (row stride ld_src, K % 32 == 0) -> tile-major split-f16 weights, (N rounded up to 32) * K floats

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 KERNELS = {0: ("split-f16, weights direct", (0, 32, 64, 96, 4, 128, 65)),   # 65: the 64-row tile on 64-bit global loads (operands of 2 GiB and more)
            1: ("split-f16, LDS staged", (0, 8, 4, 64)),
-           2: ("exact float32", (0, 8, 4, 64))}
+           2: ("exact float32", (0, 2, 8, 4, 64, 11, 12, 13, 14))}   # 0: gemm_f32.hip (persistent, balanced); 2 / 8 / 4 / 64: gemm.hip; 11..14: gemm_f32.hip, tiles of at most 32..128 rows
 
 
 @pytest.fixture(scope="module")

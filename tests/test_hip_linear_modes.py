@@ -122,3 +122,27 @@ def test_e2e_waveform_vs_reference_exact_mode(L, sep, mix60, golden):
         assert flips <= 1e-5 * g["wta_index"].size + 3
     finally:
         h.set_linear_mode("split_f16")
+
+
+def test_exact_mode_is_bit_identical_on_either_float32_gemm(L, sep, mix_stage):
+    """Round 5's exact float32 GEMM (gemm_f32.hip: four independent blocks per CU, persistent, balanced tile heights) must
+    leave every bit of the exact mode where round 4's kernel (gemm.hip) put it: masks, hidden states and waveforms of a
+    whole pass, for the balanced plan and for every forced tile height (css_set_tuning CSS_TUNE_F32_GEMM)."""
+    CSS = pkg("css")
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    h = sep.handle
+    h.set_linear_mode("exact_f32")
+    try:
+        ref = None
+        for tune in (1, 0, 2, 3, 4, 5):   # 1: gemm.hip; 0: gemm_f32.hip; 2..5: gemm_f32.hip, tiles of at most 32 .. 128 rows
+            h.set_tuning("f32_gemm", tune)
+            wav = h.run(mix_stage[0], run_cfg)
+            got = (_masks(h, L, h.get_plan().num_segments).copy(), h.read(L.BUF_HIDDEN).copy(), wav.copy())
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    assert np.array_equal(a, b), tune
+    finally:
+        h.set_tuning("f32_gemm", 0)
+        h.set_linear_mode("split_f16")
