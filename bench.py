@@ -87,6 +87,19 @@ def gpu_clocks():
         return None
 
 
+def sclk_mhz():
+    """the shader clock rocm-smi reports right now (MHz; None when unavailable) -- printed next to every roofline fraction:
+    the matrix peaks assume 2.4 GHz, the sustained clock under the MFMA kernels is lower"""
+    import re
+    c = gpu_clocks() or {}
+    for k, v in c.items():
+        if "sclk" in k.lower():
+            m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+            if m:
+                return int(m.group(1))
+    return None
+
+
 def gemm_roofline(t, mode, ks_ref=None):
     # `achieved` counts ALGORITHMIC flops (2*M*N*K of the float32 products the network defines).
     achieved = t["gemm_flops"] / (t["gemm_ms"] * 1e-3) / 1e12 if t["gemm_ms"] > 0 else 0.0
@@ -100,7 +113,7 @@ def gemm_roofline(t, mode, ks_ref=None):
                  "vs_f32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
     else:
         peak = PEAK_FP32_MATRIX_TFLOPS
-        kernel = "css::gemm_kernel (v_mfma_f32_32x32x2_f32, 128x128x32 tiles)"
+        kernel = "css::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; persistent, four 4-wave blocks per CU, tiles of 32..128 x 128 x 16)"
         extra = {}
     out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 1),
            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
@@ -143,21 +156,25 @@ def cpu_baseline(mix, state, seconds, cfg_kwargs, threads=16):
                                       f"{threads} threads, {dt:.1f} s wall"}
 
 
-def hbm_kernel_bytes(plan, desc, T, hop, n):
-    """ALGORITHMIC bytes per pass of the memory-bound kernel families (compulsory traffic with the path's
-    materialisation points kept; DESIGN.md section 3 states each formula)."""
+def hbm_kernel_bytes(plan, desc, T, hop, n, own_planes=False):
+    """ALGORITHMIC bytes per pass of the memory-bound kernel families: SURVEY.md 8(d)'s compulsory traffic -- what the
+    reference's own stages hand to each other (PCM, spectra, features, masks, covariances, beamformer weights, separated
+    spectra, waveforms), each read and written once.  own_planes=True: the bytes THIS implementation moves where it
+    differs (round 4: the analysis transform also writes one phase plane per microphone, and a segment's features read the
+    two planes of microphone 0 plus the C phase planes instead of all 2 C planes) -- listed beside, never as the roofline's
+    numerator."""
     C, F, S = desc.num_mics, desc.num_bins, desc.num_spks
     nseg, TL = int(plan.num_segments), int(plan.mix_frames)
     Kp = (desc.in_features + 31) // 32 * 32
     KIp = (2 * F + 31) // 32 * 32
     planes_seg = C * 2 * F * T * 4
     masks_seg = (S + 1) * F * T * 4
+    if own_planes:
+        return {"stft": n * C * 4 + C * 3 * F * TL * 4, "features": nseg * ((2 + C) * F * T * 4 + T * Kp * 4)}
     return {
         "deinterleave": 2 * n * C * 4,
-        # (round 4: the transform also writes one phase plane per microphone; a segment's features read the two planes of
-        #  microphone 0 for the magnitude rows and the C phase planes for the IPD rows instead of all 2 C planes)
-        "stft": n * C * 4 + C * 3 * F * TL * 4,
-        "features": nseg * ((2 + C) * F * T * 4 + T * Kp * 4),
+        "stft": n * C * 4 + C * 2 * F * TL * 4,
+        "features": nseg * (planes_seg + T * Kp * 4),
         "scm": nseg * (planes_seg + masks_seg + (S + 1) * F * 49 * 8),
         "mvdr_solve": nseg * ((S + 1) * F * 49 * 8 + S * F * C * 16),
         "beamform": nseg * (planes_seg + S * F * C * 16 + S * F * T * 4 + S * F * T * 8),
@@ -343,8 +360,10 @@ def main():
         h.sync()
         return 1e3 * (time.perf_counter() - t0) / steps
 
-    dtype_of = {"split_f16": "f32 (Linear layers: f32 products as 3 f16 MFMAs on split operands, f32 accumulate; MVDR f64)",
-                "exact_f32": "f32 (MVDR covariance/solve f64)"}
+    dtype_of = {"split_f16": "split-f16x3 (f32 values carried as two f16 numbers: 22-bit operands, three v_mfma_f32_32x32x16_f16 per product, f32 "
+                             "accumulate -- operands NARROWER than the reference's f32; MVDR covariance / solve f64)",
+                "exact_f32": "f32 (float32 operands on v_mfma_f32_32x32x2_f32 in every Linear layer, attention product and transform: the "
+                             "reference's own operand precision; MVDR covariance / solve f64)"}
     result = {"metric": "CSS real-time-factor (sep. audio sec/wall sec) on 7-ch 16 kHz", "unit": "x real-time (audio s / wall s)",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
               "data": "synthetic"}
@@ -567,13 +586,13 @@ def main():
         result.setdefault("tuning", {})[name] = int(val)
     pcm_pin = L.pinned_copy(np.ascontiguousarray(mix[0]))
     out_pin = L.pinned_empty((S, int(plan.n_out)), np.float32)
-    torch.cuda.synchronize()
-
-    # ---- headline: a queue of K sessions, each host -> host (css_run_enqueue ... css_wait): exactly K steps after W warm-up
-    # steps, synchronised on both sides.  Every session is uploaded, separated and downloaded inside the timed region; what
-    # the queue adds over K synchronous calls is that a session's PCIe legs run under its neighbours' kernels.
     out_pin2 = L.pinned_empty((S, int(plan.n_out)), np.float32)
     outs = (out_pin, out_pin2)
+    pcm_dev = torch.from_numpy(np.ascontiguousarray(mix[0])).to(dev)
+    wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    group_limit = args.queue_group if args.queue_group else 8
+    sessions_per_batch = max(1, min(group_limit, args.max_batch // int(plan.num_segments), args.steps))
 
     def queued(k_steps):
         for k in range(k_steps):
@@ -588,54 +607,6 @@ def main():
         h.sync(); torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    group_limit = args.queue_group if args.queue_group else 8
-    sessions_per_batch = max(1, min(group_limit, args.max_batch // int(plan.num_segments), args.steps))
-    h.run(pcm_pin, run_cfg, out=out_pin)   # initialisation, not a step: the handle allocates its device buffers on first use
-    queued(args.warmup)
-    # K steps of 5 ms are a 0.1 s region: the timed region (exactly K steps each time) is repeated until >= 1 s has been
-    # timed in total, `value` is the MEDIAN region and every region is listed (`runs_ms`), so that the headline does not
-    # hang on one box's jitter
-    runs = [timed_region()]
-    while sum(runs) < args.min_seconds and len(runs) < 200:   # (one sustained region of back-to-back queues for the driver's busy sampler)
-        runs.append(timed_region())
-    elapsed = float(np.median(runs))
-    assert np.isfinite(out_pin).all() and (args.steps < 2 or np.array_equal(out_pin, out_pin2))
-    result["runs_ms"] = {"per_step_ms_of_each_timed_region": [round(1e3 * r / args.steps, 3) for r in runs],
-                         "regions": len(runs), "steps_per_region": args.steps, "value_is": "median region", "timed_seconds_in_total": round(sum(runs), 3),
-                         "min": round(1e3 * min(runs) / args.steps, 3), "max": round(1e3 * max(runs) / args.steps, 3)}
-    result.update({
-        "value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "scaling": "strong", "dtype": dtype_of[h.linear_mode()],
-        "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({plan.num_segments} segments of 3 s / 1.5 s "
-                               f"hop), Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR; a queue of sessions, each host PCM -> "
-                               f"host waveforms (css_run_enqueue / css_wait, page-locked buffers, every session's two PCIe "
-                               f"legs inside the timed region, overlapped with its neighbours' kernels)",
-                   "segments": int(plan.num_segments), "sharding": "single GPU",
-                   "sessions_per_estimator_batch": sessions_per_batch,
-                   "estimator_batching": f"queued sessions share mask-estimator batches: {sessions_per_batch} sessions = "
-                                         f"{sessions_per_batch * int(plan.num_segments)} segments = M {sessions_per_batch * int(plan.num_segments) * T} rows per "
-                                         f"Linear-layer launch (max_batch_segments {args.max_batch}); everything else per session; "
-                                         f"each session's result is bit for bit its css_run result"},
-    })
-    # ---- the same K sessions as K synchronous calls (css_run returns when the waveforms are in host memory)
-    for _ in range(args.warmup):
-        h.run(pcm_pin, run_cfg, out=out_pin)
-    h.sync(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h.run(pcm_pin, run_cfg, out=out_pin)
-    h.sync(); torch.cuda.synchronize()
-    ms_sync = 1e3 * (time.perf_counter() - t0) / args.steps
-    result["synchronous_call"] = {"ms_per_step": round(ms_sync, 3), "value": round(seconds / (ms_sync * 1e-3), 2),
-                                  "note": "css_run: one session per call, host -> host, the call's own latency (nothing to overlap with)"}
-    stage = h.timings()
-    result["stage_ms"] = {k: round(v, 3) for k, v in stage.items()
-                          if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total", "host_enqueue", "host_total")}
-
-    # ---- the same pass with input and output resident in HBM (what the PCIe legs cost), and from pageable memory
-    pcm_dev = torch.from_numpy(np.ascontiguousarray(mix[0])).to(dev)
-    wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
-
     def timed(fn, steps=args.steps, warmup=2):
         for _ in range(warmup):
             fn()
@@ -649,19 +620,8 @@ def main():
     def rec(ms, note):
         return {"ms_per_step": round(ms, 3), "value": round(seconds / (ms * 1e-3), 2), "note": note}
 
-    ms_dev = timed(lambda: h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out))
-    result["device_resident"] = rec(ms_dev, "css_run_device: PCM and waveforms in HBM (no PCIe leg)")
-    result["host_vs_device_resident"] = round((1e3 * elapsed / args.steps) / ms_dev, 4)
-    result["synchronous_vs_device_resident"] = round(ms_sync / ms_dev, 4)
-    pageable = np.ascontiguousarray(mix[0])
-    result["pageable_host"] = rec(timed(lambda: h.run(pageable, run_cfg), steps=5, warmup=1),
-                                  "css_run from/to ordinary (pageable) host memory: the driver's staged copies")
-    planes = [np.ascontiguousarray(np.clip(np.rint(mix[0, :, c] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)) for c in range(7)]
-    result["pcm16_edges"] = rec(timed(lambda: h.run_pcm16(planes, run_cfg), steps=5, warmup=1),
-                                "css_run_pcm16: 7 int16 planes in host memory -> 3 peak-normalised PCM16 streams in host memory")
-
-    # ---- roofline of the dominant kernel (the Linear-layer GEMM): live HIP-event timing of every launch, one lane
     def profiled_pass():
+        """one session alone under the per-launch profile (device-resident, one lane)"""
         h.set_profile(True)
         h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
         h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out)
@@ -673,36 +633,24 @@ def main():
         """the headline's own schedule under the per-launch profile: k queued sessions = one estimator batch"""
         h.wait()
         h.set_profile(True)
-        for k in range(k_sessions):
-            h.run_enqueue(pcm_pin, run_cfg, outs[k % 2])
-        h.wait()
-        for k in range(k_sessions):
-            h.run_enqueue(pcm_pin, run_cfg, outs[k % 2])
-        h.wait()
+        for _ in range(2):
+            for k in range(k_sessions):
+                h.run_enqueue(pcm_pin, run_cfg, outs[k % 2])
+            h.wait()
         t, ks = h.timings(), h.kernel_stats()
         h.set_profile(False)
         return t, ks
 
-    t, ks = profiled_pass()
-    roof_single = gemm_roofline(t, h.linear_mode(), ks)
-    if sessions_per_batch > 1:
-        tq, ksq = profiled_queue(sessions_per_batch)
-        roof = gemm_roofline(tq, h.linear_mode(), ksq)
-        roof["sessions_per_launch"] = sessions_per_batch
-        roof["rows_per_launch"] = sessions_per_batch * int(plan.num_segments) * T
-        result["roofline_single_session"] = roof_single
-        result["kernel_family_ms_per_session_in_a_shared_batch"] = {k: round(v[0] / sessions_per_batch, 4) for k, v in ksq.items()
-                                                                    if k != "event_pair_overhead"}
-    else:
-        roof = roof_single
-    # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes from
-    # the committed PMC passes of the same command (profiles/README.md), when present
-    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
-        tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic.json")
-        if os.path.exists(tj):
+    def attach_traffic(roof, mode):
+        # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the figure comes from
+        # the committed PMC passes of the same command (profiles/README.md), when present
+        suffix = "" if mode == "split_f16" else "_exact_f32"
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            tj = os.path.join(ROOT, "profiles", f"{tag}_gemm_traffic{suffix}.json")
+            if not os.path.exists(tj):
+                continue
             with open(tj) as f:
                 tr = json.load(f)
-            # the counters of the launches the profile above timed (same rows per launch), when the file has them per shape
             key = f"M{roof.get('rows_per_launch', int(plan.num_segments) * T)}"
             pick = tr.get(key, tr)
             if "traffic_bytes_per_launch" in pick:
@@ -710,30 +658,111 @@ def main():
                 if "algorithmic_bytes_per_launch" in pick:
                     roof["algorithmic_bytes_per_launch"] = round(pick["algorithmic_bytes_per_launch"])
                     roof["traffic_over_algorithmic"] = round(pick["traffic_bytes_per_launch"] / pick["algorithmic_bytes_per_launch"], 3)
-                roof["traffic_source"] = (f"profiles/{tag}_gemm_traffic.json [{key if key in tr else 'launch mix of that round'}] (rocprofv3 --pmc "
-                                          f"FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)")
+                roof["traffic_source"] = (f"profiles/{tag}_gemm_traffic{suffix}.json [{key if key in tr else 'launch mix of that round'}] (rocprofv3 "
+                                          f"--pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)")
             break
-    result["roofline"] = roof
-    # ---- the memory-bound kernel families of the same profiled pass: algorithmic bytes / live HIP-event time
-    def hbm_table(alg, ks):
-        return [{"kernel": k, "bytes": int(alg[k]), "us": round(1e3 * ks[k][0], 2), "launches": ks[k][1],
-                 "GBps": round(alg[k] / (ks[k][0] * 1e-3) / 1e9, 1),
-                 "frac": round(alg[k] / (ks[k][0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-                for k in alg if k in ks and ks[k][0] > 0]
+        return roof
 
-    result["roofline_hbm"] = hbm_table(hbm_kernel_bytes(plan, desc, T, hop, n), ks)
-    result["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks.items() if k != "event_pair_overhead"}
+    def headline(mode, min_seconds):
+        """The metric in one arithmetic mode: K queued sessions, each host -> host (css_run_enqueue ... css_wait), exactly K
+        steps per timed region, regions repeated until `min_seconds` have been timed, the MEDIAN region is the value; the
+        same sessions as synchronous calls and device-resident; the dominant kernel's roofline on the headline's own
+        schedule (the shared estimator batch) and on one session alone."""
+        h.set_linear_mode(mode)
+        h.run(pcm_pin, run_cfg, out=out_pin)   # initialisation, not a step: the handle sizes its device buffers on first use
+        queued(args.warmup)
+        runs = [timed_region()]
+        while sum(runs) < min_seconds and len(runs) < 200:
+            runs.append(timed_region())
+        elapsed = float(np.median(runs))
+        assert np.isfinite(out_pin).all() and (args.steps < 2 or np.array_equal(out_pin, out_pin2))
+        out = {"value": round(seconds * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "dtype": dtype_of[mode],
+               "runs_ms": {"per_step_ms_of_each_timed_region": [round(1e3 * r / args.steps, 3) for r in runs], "regions": len(runs),
+                           "steps_per_region": args.steps, "value_is": "median region", "timed_seconds_in_total": round(sum(runs), 3),
+                           "min": round(1e3 * min(runs) / args.steps, 3), "max": round(1e3 * max(runs) / args.steps, 3)}}
+        # the same K sessions as K synchronous calls (css_run returns when the waveforms are in host memory)
+        ms_sync = timed(lambda: h.run(pcm_pin, run_cfg, out=out_pin), warmup=args.warmup)
+        out["synchronous_call"] = rec(ms_sync, "css_run: one session per call, host -> host, the call's own latency (nothing to overlap with)")
+        stage = h.timings()
+        out["stage_ms"] = {k: round(v, 3) for k, v in stage.items()
+                           if k in ("upload", "stft", "masknet", "mvdr", "stitch", "istft", "download", "total", "host_enqueue", "host_total")}
+        ms_dev = timed(lambda: h.run_device(pcm_dev.data_ptr(), n, 7, run_cfg, wav_dev.data_ptr(), plan.n_out))
+        out["device_resident"] = rec(ms_dev, "css_run_device: PCM and waveforms in HBM (no PCIe leg)")
+        out["host_vs_device_resident"] = round(out["ms_per_step"] / ms_dev, 4)
+        out["synchronous_vs_device_resident"] = round(ms_sync / ms_dev, 4)
+        t1, ks1 = profiled_pass()
+        roof_single = gemm_roofline(t1, mode, ks1)
+        if sessions_per_batch > 1:
+            tq, ksq = profiled_queue(sessions_per_batch)
+            roof = gemm_roofline(tq, mode, ksq)
+            roof["sessions_per_launch"] = sessions_per_batch
+            roof["rows_per_launch"] = sessions_per_batch * int(plan.num_segments) * T
+            out["roofline_single_session"] = roof_single
+            out["kernel_family_ms_per_session_in_a_shared_batch"] = {k: round(v[0] / sessions_per_batch, 4) for k, v in ksq.items()
+                                                                     if k != "event_pair_overhead"}
+        else:
+            roof = roof_single
+        roof["sclk_mhz_after_the_profiled_passes"] = sclk_mhz()
+        out["roofline"] = attach_traffic(roof, mode)
+        out["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks1.items() if k != "event_pair_overhead"}
+        out["_ks_single"] = ks1
+        return out
 
-    # ---- the strictly-float32 arithmetic mode, same workload, same timing rules
-    h.set_linear_mode("exact_f32")
-    ms_x = fused_host_to_host(h, pcm_pin, out_pin, max(args.steps // 2, 5), 2)
-    tx, _ = profiled_pass()
-    result["exact_f32"] = {**rec(ms_x, "css_set_linear_mode(CSS_LINEAR_EXACT_F32): every Linear layer on the exact float32 MFMA chain; host -> host"),
-                           "dtype": dtype_of["exact_f32"], "roofline": gemm_roofline(tx, "exact_f32", ks)}
-    # (for a strict reader: the figure at the reference's own arithmetic, no digging)
-    result["value_exact_f32"] = result["exact_f32"]["value"]
-    result["roofline_exact_f32"] = result["exact_f32"]["roofline"]
-    h.set_linear_mode("split_f16")
+    # ---- the headline: the reference's own arithmetic (float32 operands on the float32 matrix instruction) ...
+    head = headline("exact_f32", args.min_seconds)
+    ks_single = head.pop("_ks_single")
+    result.update(head)
+    result.update({
+        "scaling": "strong",
+        "config": {"workload": f"synthetic 7-ch 16 kHz {seconds:g} s meeting ({plan.num_segments} segments of 3 s / 1.5 s "
+                               f"hop), Conformer-CSS v1.0-MC (18 blocks, D=512) + MVDR; a queue of sessions, each host PCM -> "
+                               f"host waveforms (css_run_enqueue / css_wait, page-locked buffers, every session's two PCIe "
+                               f"legs inside the timed region, overlapped with its neighbours' kernels)",
+                   "segments": int(plan.num_segments), "sharding": "single GPU", "arithmetic": "CSS_LINEAR_EXACT_F32",
+                   "sessions_per_estimator_batch": sessions_per_batch,
+                   "estimator_batching": f"queued sessions share mask-estimator batches: {sessions_per_batch} sessions = "
+                                         f"{sessions_per_batch * int(plan.num_segments)} segments = M {sessions_per_batch * int(plan.num_segments) * T} rows per "
+                                         f"Linear-layer launch (max_batch_segments {args.max_batch}); everything else per session; "
+                                         f"each session's result is bit for bit its css_run result"},
+        "value_is": "CSS_LINEAR_EXACT_F32 (float32 operands, v_mfma_f32_32x32x2_f32): the reference's operand precision.  The "
+                    "library's DEFAULT mode is the faster split-f16 one (22-bit operands): `split_f16` / `value_split_f16` below",
+    })
+    # ---- the memory-bound kernel families of the profiled single-session pass: algorithmic bytes / live HIP-event time
+    def hbm_table(alg, ks, own=None):
+        rows = []
+        for k in alg:
+            if k not in ks or ks[k][0] <= 0:
+                continue
+            row = {"kernel": k, "bytes": int(alg[k]), "us": round(1e3 * ks[k][0], 2), "launches": ks[k][1],
+                   "GBps": round(alg[k] / (ks[k][0] * 1e-3) / 1e9, 1),
+                   "frac": round(alg[k] / (ks[k][0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            if own and k in own:
+                row["bytes_this_implementation_moves"] = int(own[k])
+            rows.append(row)
+        return rows
+
+    result["roofline_hbm"] = hbm_table(hbm_kernel_bytes(plan, desc, T, hop, n), ks_single, hbm_kernel_bytes(plan, desc, T, hop, n, True))
+    result["roofline_hbm_bytes_are"] = ("SURVEY.md 8(d)'s compulsory bytes: operands the reference's own stages exchange (PCM, spectra, masks, "
+                                        "features, covariances, weights, separated spectra, waveforms); planes the implementation adds for "
+                                        "itself (the analysis transform's phase planes) are NOT counted")
+    pageable = np.ascontiguousarray(mix[0])
+    result["pageable_host"] = rec(timed(lambda: h.run(pageable, run_cfg), steps=5, warmup=1),
+                                  "css_run from/to ordinary (pageable) host memory: the driver's staged copies")
+    planes = [np.ascontiguousarray(np.clip(np.rint(mix[0, :, c] * 0.05 * 32768.0), -32768, 32767).astype(np.int16)) for c in range(7)]
+    result["pcm16_edges"] = rec(timed(lambda: h.run_pcm16(planes, run_cfg), steps=5, warmup=1),
+                                "css_run_pcm16: 7 int16 planes in host memory -> 3 peak-normalised PCM16 streams in host memory")
+
+    # ---- ... and the library's default, faster mode: same workload, same timing rules, its own roofline
+    fast = headline("split_f16", min(args.min_seconds, 3.0))
+    fast.pop("_ks_single")
+    result["split_f16"] = fast
+    result["value_split_f16"] = fast["value"]
+    result["dtype_split_f16"] = fast["dtype"]
+    result["roofline_split_f16"] = fast["roofline"]
+    # (the keys earlier rounds' records used for the float32 figure)
+    result["value_exact_f32"] = result["value"]
+    result["roofline_exact_f32"] = result["roofline"]
 
     # ---- BASELINE.json configs[3] on this one GPU: the fixed 30-min meeting every N > 1 line runs
     if not args.no_long:
@@ -748,31 +777,38 @@ def main():
         pcm_dev = torch.from_numpy(np.ascontiguousarray(long_mix[0])).to(dev)
         wav_dev = torch.empty((S, int(plan_long.n_out)), dtype=torch.float32, device=dev)
         del long_mix
-        h.set_profile(True)
-        for _ in range(2):
-            h.run_device(pcm_dev.data_ptr(), n_long, 7, run_cfg, wav_dev.data_ptr(), int(plan_long.n_out))
-        t_l, ks_l = h.timings(), h.kernel_stats()
-        h.set_profile(False)
-        result["roofline_hbm_1800s"] = hbm_table(hbm_kernel_bytes(plan_long, desc, T, hop, n_long), ks_l)
-        result["roofline_1800s"] = gemm_roofline(t_l, h.linear_mode(), ks_l)
-        del pcm_dev, wav_dev
         out_long = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
-        ms_long = fused_host_to_host(h, pcm_long, out_long, 3, 1)
-        assert np.isfinite(out_long[:, ::4096]).all()
-        result["meeting_1800s"] = {**rec(ms_long, "the strong-scaling workload of the N > 1 lines on ONE GPU, host -> host, one synchronous css_run per meeting"),
-                                   "value": round(args.long_seconds / (ms_long * 1e-3), 2),
-                                   "segments": int(plan_long.num_segments), "seconds": args.long_seconds}
         out_long2 = L.pinned_empty((S, int(plan_long.n_out)), np.float32)
-        h.run_enqueue(pcm_long, run_cfg, out_long2); h.wait()
-        h.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(4):
-            h.run_enqueue(pcm_long, run_cfg, (out_long, out_long2)[k % 2])
-        h.wait(); torch.cuda.synchronize()
-        ms_q = 1e3 * (time.perf_counter() - t0) / 4
-        result["meeting_1800s"]["queued"] = {"ms_per_step": round(ms_q, 3), "value": round(args.long_seconds / (ms_q * 1e-3), 2),
-                                             "note": "four such meetings queued (css_run_enqueue / css_wait)"}
-        del pcm_long, out_long, out_long2
+        for mode in ("exact_f32", "split_f16"):
+            h.set_linear_mode(mode)
+            h.set_profile(True)
+            for _ in range(2):
+                h.run_device(pcm_dev.data_ptr(), n_long, 7, run_cfg, wav_dev.data_ptr(), int(plan_long.n_out))
+            t_l, ks_l = h.timings(), h.kernel_stats()
+            h.set_profile(False)
+            ms_long = fused_host_to_host(h, pcm_long, out_long, 3, 1)
+            assert np.isfinite(out_long[:, ::4096]).all()
+            m1800 = {**rec(ms_long, "the strong-scaling workload of the N > 1 lines on ONE GPU, host -> host, one synchronous css_run per meeting"),
+                     "value": round(args.long_seconds / (ms_long * 1e-3), 2), "dtype": dtype_of[mode],
+                     "segments": int(plan_long.num_segments), "seconds": args.long_seconds,
+                     "roofline": gemm_roofline(t_l, mode, ks_l)}
+            h.run_enqueue(pcm_long, run_cfg, out_long2); h.wait()
+            h.sync(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(4):
+                h.run_enqueue(pcm_long, run_cfg, (out_long, out_long2)[k % 2])
+            h.wait(); torch.cuda.synchronize()
+            ms_q = 1e3 * (time.perf_counter() - t0) / 4
+            m1800["queued"] = {"ms_per_step": round(ms_q, 3), "value": round(args.long_seconds / (ms_q * 1e-3), 2),
+                               "note": "four such meetings queued (css_run_enqueue / css_wait)"}
+            if mode == "exact_f32":
+                result["meeting_1800s"] = m1800
+                result["roofline_1800s"] = m1800["roofline"]
+                result["roofline_hbm_1800s"] = hbm_table(hbm_kernel_bytes(plan_long, desc, T, hop, n_long), ks_l,
+                                                         hbm_kernel_bytes(plan_long, desc, T, hop, n_long, True))
+            else:
+                result["split_f16"]["meeting_1800s"] = m1800
+        del pcm_dev, wav_dev, pcm_long, out_long, out_long2
 
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(mix, state, min(args.cpu_baseline_seconds, seconds), {"activity_th": 0.3})
