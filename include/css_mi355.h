@@ -153,7 +153,9 @@ typedef enum css_buffer {
     CSS_BUF_Y = 12,         /* float  [S][T_long][KI_pad]                                           */
     CSS_BUF_WAV = 13,       /* float  [S][n_out]                                                    */
     CSS_BUF_HIDDEN = 14,    /* float  [batch tokens][D]  encoder output of the last batch           */
-    CSS_BUF_WTA_OVERRIDE = 15,/* uint8 [segments][F][T_seg]  (write-only) injected WTA decisions     */
+    CSS_BUF_WTA_OVERRIDE = 15,/* uint8 [segments][F][T_seg]  (write-only) injected WTA decisions: 0..3 = the one winning mask;
+                               * 16 + bits = the SET of winners (bit j: mask j wins) -- mvdr_util.py:53-54 keeps every mask that
+                               * equals the maximum, and a trained model's saturated masks tie exactly                        */
     CSS_BUF_LEVEL = 16      /* float  [1]  max |sample| of the PCM laid out so far in this session: sets the power-of-two
                                gain of the split-f16 synthesis operand; ranks of a sharded meeting exchange its maximum */
 } css_buffer;
@@ -413,6 +415,26 @@ int css_read_buffer(css_handle_t h, int which, void* host, int64_t nbytes);
 int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes);
 /* Device address of a buffer (for zero-copy wrapping, e.g. by torch for the RCCL all-gather). */
 int css_buffer_devptr(css_handle_t h, int which, void** out);
+
+/* ---- the exchanges of the sharded path without Python ------------------------------------------------
+ * parallel.py shards a long meeting by sliding-window segment over the GPUs of a node and stitches with three all-gathers
+ * (raw PIT costs, thresholded activity, seam blocks / waveform shards; css.py:110-338 itself has no collective -- it is the
+ * single-process loop these replace).  Python reaches them through torch.distributed; a host in another language uses
+ * these: one RCCL communicator per handle, created from a unique id the caller distributes over its own channel (what
+ * ncclGetUniqueId / ncclCommInitRank expect), every collective enqueued on the handle's stream behind its kernels.
+ * librccl.so is loaded on first use (dlopen): the library itself carries no link-time dependency on it, and every entry
+ * point returns CSS_ERR_STATE with a message when it cannot be loaded. */
+#define CSS_COMM_ID_BYTES 128
+int css_comm_unique_id(void* id_out);   /* rank 0: CSS_COMM_ID_BYTES bytes to hand to every rank */
+int css_comm_init(css_handle_t h, const void* id, int32_t nranks, int32_t rank);
+int css_comm_destroy(css_handle_t h);
+/* nranks / rank / HIP device / RCCL version code of the handle's communicator (any pointer may be NULL) */
+int css_comm_info(css_handle_t h, int32_t* nranks, int32_t* rank, int32_t* device, int32_t* rccl_version);
+/* recv_dev [nranks][bytes_per_rank] <- every rank's send_dev [bytes_per_rank]; device pointers; on the handle's stream */
+int css_comm_all_gather(css_handle_t h, const void* send_dev, void* recv_dev, int64_t bytes_per_rank);
+/* (The pieces themselves -- which rows of CSS_BUF_PIT_COST / CSS_BUF_ACTIVITY a rank owns, the seam block of its shard -- are
+ * parallel.py's plan; a host in another language addresses them through css_buffer_devptr.  parallel.HipShardBackend takes this
+ * route with comm="cabi": the same driver, RCCL reached through these entry points instead of torch.distributed.) */
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,11 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), _P, C.c_int32, C.POINTER(C.c_int32)]),
     "css_validation_loss_host": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, _P, _P, _P, C.POINTER(C.c_float)]),
+    "css_comm_unique_id": (C.c_int, [_P]),
+    "css_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "css_comm_destroy": (C.c_int, [_P]),
+    "css_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "css_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64]),
     "css_buffer_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "css_read_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "css_write_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -221,6 +226,18 @@ class RunCfg:
                            int(bool(normalize_segment_power)), float(mask_floor), float(activity_th),
                            self._w[0].ctypes.data_as(_FP), self._w[1].ctypes.data_as(_FP),
                            self._w[2].ctypes.data_as(_FP))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI: rank 0 calls it and hands the 128 bytes to every rank (over its own channel)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().css_comm_unique_id(buf)
+    if rc != 0:
+        raise CssError(rc, "css_comm_unique_id failed (is librccl.so loadable?)")
+    return buf.raw
 
 
 def plan(desc, run_cfg: RunCfg, n_samples: int) -> CssPlan:
@@ -444,6 +461,24 @@ class Handle:
         check(self.h, self.lib.css_linear_host(self.h, _np_ptr(x), _np_ptr(w), _np_ptr(b) if b is not None else None,
                                                m, n, k, int(kernel), int(layout), _np_ptr(y)))
         return y
+
+    # ---- RCCL through the C ABI (css_comm_*): what a host in another language would call
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        check(self.h, self.lib.css_comm_init(self.h, buf, int(nranks), int(rank)))
+
+    def comm_destroy(self):
+        check(self.h, self.lib.css_comm_destroy(self.h))
+
+    def comm_info(self):
+        n, r, d, v = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.h, self.lib.css_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d), C.byref(v)))
+        return {"nranks": n.value, "rank": r.value, "device": d.value, "rccl_version_code": v.value}
+
+    def comm_all_gather(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int):
+        """device pointers; enqueued on the handle's stream"""
+        check(self.h, self.lib.css_comm_all_gather(self.h, C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr)), int(bytes_per_rank)))
 
     def linear_mode(self):
         m = self.lib.css_get_linear_mode(self.h)

@@ -11,6 +11,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <mutex>
+
 #include "kernels.hpp"
 #include "lsap.hpp"
 
@@ -53,6 +56,7 @@ inline int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
 // X holds the planes [C][2F][T_ld] (Re | Im) and, behind them, the phase planes [C][F][T_ld] the analysis transform writes
 // with them (kernels.hpp launch_stft_fft): one allocation, so that whatever swaps or re-sizes X takes the phases along
 constexpr int X_ROWS_PER_BIN = 3;
+struct ncclUniqueId_bytes { char internal[CSS_COMM_ID_BYTES]; };   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -186,6 +190,8 @@ struct css_ctx : SessState {
                      float* wav_mapped; int64_t nseg; };
     std::vector<Pending> pending;
     int64_t pending_segments = 0;
+    void* comm = nullptr;          // ncclComm_t of css_comm_init (RCCL, loaded lazily)
+    int comm_ranks = 0, comm_rank = -1;
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
     std::vector<PendingUpload> uploads;
     std::vector<hipEvent_t> ev_pool;   // untimed events of the pipeline (uploads landed, planes ready, ranges finished)
@@ -710,6 +716,7 @@ int css_destroy(css_handle_t h) {
     if (!h) return CSS_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm) css_comm_destroy(h);
     DevBuf* bufs[] = {&h->pcm_in, &h->pcm_cm, &h->X, &h->feat, &h->hx, &h->hu, &h->ht, &h->qkv, &h->qkf, &h->ctxb, &h->masks,
                       &h->scm, &h->bfw, &h->sep, &h->costs, &h->perms, &h->mask_st, &h->activity, &h->act_b,
                       &h->act_tmp, &h->act_final, &h->Y, &h->G, &h->wav, &h->wta, &h->pnorm, &h->segw, &h->stage, &h->pit_part,
@@ -2828,6 +2835,101 @@ int css_buffer_devptr(css_handle_t h, int which, void** out) {
     if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
     *out = b->p;
     return CSS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// RCCL without Python (css_mi355.h "the exchanges of the sharded path").  librccl.so is loaded on first use: the entry
+// points are looked up by name, so that this library loads (and everything else works) on a box without RCCL.
+extern "C++" {
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, ncclUniqueId_bytes, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.why.empty()) r.why = std::string("librccl.so lacks ") + n; return p; };
+        r.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+        r.CommInitRank = (int (*)(void**, int, ncclUniqueId_bytes, int))sym("ncclCommInitRank");
+        r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
+        r.GetVersion = (int (*)(int*))sym("ncclGetVersion");
+        r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return r;
+}
+int rccl_fail(css_ctx* h, const char* what, int code) {
+    Rccl& r = rccl();
+    return fail(h, CSS_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+}  // namespace
+}  // extern "C++"
+
+int css_comm_unique_id(void* id_out) {
+    if (!id_out) return CSS_ERR_INVALID_ARG;
+    Rccl& r = rccl();
+    if (!r.why.empty()) return CSS_ERR_STATE;
+    ncclUniqueId_bytes id{};
+    if (r.GetUniqueId(&id) != 0) return CSS_ERR_HIP;
+    std::memcpy(id_out, &id, CSS_COMM_ID_BYTES);
+    return CSS_OK;
+}
+
+int css_comm_init(css_handle_t h, const void* id, int32_t nranks, int32_t rank) {
+    CSS_DRAIN(h);
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, CSS_ERR_INVALID_ARG, "bad communicator arguments");
+    if (h->comm) return fail(h, CSS_ERR_STATE, "the handle already has a communicator (css_comm_destroy first)");
+    Rccl& r = rccl();
+    if (!r.why.empty()) return fail(h, CSS_ERR_STATE, r.why);
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId_bytes uid;
+    std::memcpy(&uid, id, CSS_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = r.CommInitRank(&comm, nranks, uid, rank);
+    if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
+    h->comm = comm; h->comm_ranks = nranks; h->comm_rank = rank;
+    return CSS_OK;
+}
+
+int css_comm_destroy(css_handle_t h) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (!h->comm) return CSS_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    const int rc = rccl().CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_ranks = 0; h->comm_rank = -1;
+    return rc == 0 ? (int)CSS_OK : rccl_fail(h, "ncclCommDestroy", rc);
+}
+
+int css_comm_info(css_handle_t h, int32_t* nranks, int32_t* rank, int32_t* device, int32_t* rccl_version) {
+    if (!h) return CSS_ERR_INVALID_ARG;
+    if (!h->comm) return fail(h, CSS_ERR_STATE, "no communicator: css_comm_init first");
+    if (nranks) *nranks = h->comm_ranks;
+    if (rank) *rank = h->comm_rank;
+    if (device) *device = h->device;
+    if (rccl_version) { int v = 0; rccl().GetVersion(&v); *rccl_version = v; }
+    return CSS_OK;
+}
+
+int css_comm_all_gather(css_handle_t h, const void* send_dev, void* recv_dev, int64_t bytes_per_rank) {
+    if (!h || !send_dev || !recv_dev || bytes_per_rank < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad all-gather arguments");
+    if (!h->comm) return fail(h, CSS_ERR_STATE, "no communicator: css_comm_init first");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = rccl().AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, /* ncclInt8 */ 0, h->comm, h->stream);
+    return rc == 0 ? (int)CSS_OK : rccl_fail(h, "ncclAllGather", rc);
 }
 
 }  // extern "C"

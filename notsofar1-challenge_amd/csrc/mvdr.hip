@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * SCM_WAVES) void scm_kernel(MvdrArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // ties keep every tied mask, like mask == mask_max in the reference
-            const bool win = ok && j < nm && (ov ? (ovv == j) : (mv[j] == mx));
+            const bool win = ok && j < nm && (ov ? (ovv >= 16 ? ((ovv >> j) & 1) != 0 : ovv == j) : (mv[j] == mx));
             const unsigned long long b = __ballot(win);
             if (win) lists[j * TS + cnt[j] + __popcll(b & lt)] = (unsigned short)(t | (seen ? 0 : 0x8000));
             cnt[j] += __popcll(b);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void scm_long_kernel(MvdrArgs a) {
             const int ovv = (t < n && ov) ? ov[t0 + t] : -1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool win = t < n && j < nm && (ov ? (ovv == j) : (mv[j] == mx));
+                const bool win = t < n && j < nm && (ov ? (ovv >= 16 ? ((ovv >> j) & 1) != 0 : ovv == j) : (mv[j] == mx));
                 ws[j][t] = win ? (double)mv[j] - 1e-10 : 0.0;
             }
         }

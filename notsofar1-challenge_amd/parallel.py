@@ -129,8 +129,10 @@ class HipShardBackend:
     """Stage calls of one rank on its GPU (the C ABI's css_stage_* entry points), plus torch views of the two device
     buffers the exchanges read and write.  Everything is enqueued on the handle's own HIP stream."""
 
-    def __init__(self, handle, torch_device, comm_device=None, torch_stream=None):
-        """`comm_device`: where the process group exchanges tensors -- the GPU itself for "nccl" (RCCL over
+    def __init__(self, handle, torch_device, comm_device=None, torch_stream=None, cabi_comm=False):
+        """`cabi_comm`: the all-gathers go through the C ABI (css_comm_all_gather on the handle's communicator, which the
+        caller has initialised with handle.comm_init) instead of torch.distributed -- the route of a non-Python host.
+        `comm_device`: where the process group exchanges tensors -- the GPU itself for "nccl" (RCCL over
         xGMI, the default), torch.device("cpu") for "gloo" (functional testing of the multi-process path).
         `torch_stream`: the torch.cuda.Stream the handle was created on (css_create's `stream` argument) -- the
         preferred arrangement for long-lived processes: torch owns the stream, so its caching allocators (device and
@@ -148,6 +150,7 @@ class HipShardBackend:
             self.stream = torch.cuda.ExternalStream(handle.stream_ptr(), device=torch_device)
         self._scratch = {}
         self._keep = None
+        self.cabi_comm = handle if cabi_comm else None
 
     def on_stream(self):
         return self.torch.cuda.stream(self.stream)
@@ -382,9 +385,16 @@ class ShardedSession:
             return out
 
 
-def _all_gather(dist, send, world, comm_dev):
-    """[...] on every rank -> [world, ...]; through host memory when the process group lives there (gloo)"""
+def _all_gather(dist, send, world, comm_dev, cabi=None):
+    """[...] on every rank -> [world, ...]; through host memory when the process group lives there (gloo).
+    cabi: a _lib.Handle with a communicator (css_comm_init): the transfer goes through the C ABI's css_comm_all_gather --
+    RCCL on the handle's stream, no torch.distributed on the data path (what a host in another language would call)"""
     import torch
+    if cabi is not None:
+        src = send.contiguous()
+        recv = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        cabi.comm_all_gather(src.data_ptr(), recv.data_ptr(), src.numel() * src.element_size())
+        return recv
     src = send if send.device == comm_dev else send.to(comm_dev)
     recv = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
     if dist.get_backend() == "nccl":
@@ -421,6 +431,7 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
     assert gather in ("all", "range"), gather
     ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world, segment_groups)
     comm_dev = getattr(backend, "comm_dev", None)
+    cabi = getattr(backend, "cabi_comm", None)   # HipShardBackend(cabi_comm=True): the handle, its RCCL communicator initialised
     mark = trace if trace is not None else (lambda label: None)
 
     def finish(result):
@@ -453,12 +464,12 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
         costs = ss.segments_and_costs()
         mark("segments")
         if world > 1:
-            costs = _all_gather(dist, costs, world, comm_dev if comm_dev is not None else costs.device)
+            costs = _all_gather(dist, costs, world, comm_dev if comm_dev is not None else costs.device, cabi)
         mark("exchange_costs")
         act = ss.masks_and_activity(costs)
         mark("scan_stitch_masks")
         if world > 1:
-            act = _all_gather(dist, act, world, comm_dev if comm_dev is not None else act.device)
+            act = _all_gather(dist, act, world, comm_dev if comm_dev is not None else act.device, cabi)
         mark("exchange_activity")
         shard = ss.gate_and_istft(act)
         mark("gate_istft")
@@ -466,7 +477,7 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
             seams = None
             if world > 1:
                 seam = ss.seam_piece(shard)
-                seams = _all_gather(dist, seam, world, comm_dev if comm_dev is not None else seam.device)
+                seams = _all_gather(dist, seam, world, comm_dev if comm_dev is not None else seam.device, cabi)
             own, rng = ss.finish_range(shard, seams), ss.own_range()
             if out is not None:
                 out[:, :rng[1] - rng[0]].copy_(own)
@@ -480,7 +491,7 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
                 res = out
             mark("exchange_waveforms")
             return finish(res)
-        shards = _all_gather(dist, shard, world, comm_dev if comm_dev is not None else shard.device)
+        shards = _all_gather(dist, shard, world, comm_dev if comm_dev is not None else shard.device, cabi)
         res = ss.join_shards(shards, out)
         mark("exchange_waveforms")
         return finish(res)

@@ -226,6 +226,34 @@ def apply_golden_recipe(state: Dict[str, np.ndarray], head_bias: np.ndarray = No
     return st
 
 
+TRAINED_LIKE_FF_BLOCK = 9
+
+
+def apply_trained_like_recipe(state: Dict[str, np.ndarray], attn_gain: float = 4.0, head_gain: float = 8.0,
+                              ff_gain: float = 256.0) -> Dict[str, np.ndarray]:
+    """A state dict that behaves like a TRAINED mask estimator where seeded weights never go (tests/golden/gen_golden_r5.py,
+    VERDICT r4 item 5): every block's query and key projections x attn_gain (attention logits x attn_gain^2: peaky rows
+    instead of near-uniform ones), the mask head x head_gain on top of the golden recipe (saturated sigmoids: masks at
+    exactly 0 / 1, exact winner-take-all ties), and the first feed-forward module of block TRAINED_LIKE_FF_BLOCK with its
+    hidden activations x ff_gain (up-projection x ff_gain, down-projection / ff_gain -- a power of two, so the module's
+    output is unchanged while its hidden operand sits ~1e3, towards the split-f16 range)."""
+    st = dict(state)
+    l = 0
+    while PREFIX + f"conformer.encoders.{l}.self_attn.linear_q.weight" in st:
+        for nm in ("q", "k"):
+            for part in ("weight", "bias"):
+                k = PREFIX + f"conformer.encoders.{l}.self_attn.linear_{nm}.{part}"
+                st[k] = (np.asarray(st[k], np.float32) * np.float32(attn_gain)).astype(np.float32)
+        l += 1
+    st[PREFIX + "linear.weight"] = (np.asarray(st[PREFIX + "linear.weight"], np.float32) * np.float32(head_gain)).astype(np.float32)
+    st[PREFIX + "linear.bias"] = (np.asarray(st[PREFIX + "linear.bias"], np.float32) * np.float32(head_gain)).astype(np.float32)
+    p = PREFIX + f"conformer.encoders.{min(TRAINED_LIKE_FF_BLOCK, l - 1)}.feed_forward_in.net."
+    st[p + "0.weight"] = (np.asarray(st[p + "0.weight"], np.float32) * np.float32(ff_gain)).astype(np.float32)
+    st[p + "0.bias"] = (np.asarray(st[p + "0.bias"], np.float32) * np.float32(ff_gain)).astype(np.float32)
+    st[p + "3.weight"] = (np.asarray(st[p + "3.weight"], np.float32) / np.float32(ff_gain)).astype(np.float32)
+    return st
+
+
 # ----------------------------------------------------------------------------------------------
 # blob packing (layout: include/css_mi355.h, "Weight blob")
 # ----------------------------------------------------------------------------------------------

@@ -251,3 +251,37 @@ def test_rccl_takes_the_exchange_tensors():
                 assert tuple(got.shape) == (1,) + tuple(t.shape) and torch.equal(got[0], t)
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_communicator_takes_the_exchange_tensors(mc_state):
+    """The same three pieces through the C ABI's own RCCL entry points (css_comm_unique_id / css_comm_init /
+    css_comm_all_gather: no torch.distributed on the data path -- what a host in another language calls), in a one-rank
+    communicator on the handle's stream, and through parallel._all_gather's `cabi` route."""
+    import torch
+    L, PAR = pkg("_lib"), pkg("parallel")
+    dev = torch.device("cuda", 0)
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0)
+    try:
+        h = sep.handle
+        uid = L.comm_unique_id()
+        assert len(uid) == L.COMM_ID_BYTES and any(uid)
+        with pytest.raises(L.CssError):
+            h.comm_info()                                  # no communicator yet: CSS_ERR_STATE, loudly
+        h.comm_init(uid, 1, 0)
+        info = h.comm_info()
+        assert info["nranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["rccl_version_code"] > 20000, info
+        with pytest.raises(L.CssError):
+            h.comm_init(uid, 1, 0)                         # one communicator per handle
+        be = PAR.HipShardBackend(h, dev, cabi_comm=True)
+        with be.on_stream():
+            for t in (torch.arange(18, dtype=torch.float64, device=dev).reshape(2, 9),
+                      (torch.arange(300, device=dev) % 2).to(torch.uint8).reshape(3, 100),
+                      torch.linspace(-1, 1, 3 * 1024, device=dev).reshape(3, 1024)):
+                got = PAR._all_gather(None, t, 1, dev, cabi=be.cabi_comm)
+                h.sync()
+                assert tuple(got.shape) == (1,) + tuple(t.shape) and torch.equal(got[0], t)
+        be.close()
+        h.comm_destroy()
+        h.comm_destroy()                                   # idempotent
+    finally:
+        sep.close()
