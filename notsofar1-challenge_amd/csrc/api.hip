@@ -105,6 +105,9 @@ struct css_ctx : SessState {
     DevBuf pe_frag[2];           // relative-position rows in attention-operand order for segment length pe_frag_T
     int pe_frag_T[2] = {0, 0};   // ([0] from the float32 table, [1] from the split-f16 one; encoder.hip pe_fragments_kernel)
     float* stft_tab = nullptr;   // window and twiddles of the analysis FFT (stft.hip)
+    bool fft512 = true;          // frame_len 512 / hop 256 / 257 bins: the FFT kernel and the pipelined schedules; else the generic forms
+    float* dft_fwd = nullptr;    // generic analysis: [2F][Lp] = (cos | -sin)(2 pi f n / N) * window[n], n < frame_len (zero beyond)
+    int Lp = 0, ovl = 2;         // frame_len rounded up to 32; frames over an output sample = ceil(frame_len / hop)
     float* dft_inv_t = nullptr;  // [frame_len][KIp]
 
     // shared by the sessions of a handle: upload staging, the estimator's activations, the mask buffer, small tables
@@ -286,8 +289,12 @@ int64_t bind_weights(const CssModelDesc& d, const float* base, Weights* w) {
 
 const char* validate_desc(const CssModelDesc& d) {
     if (d.num_mics != 1 && d.num_mics != 7) return "num_mics must be 1 or 7";
-    if (d.frame_len != 2 * d.frame_hop || d.frame_len % 64) return "frame_len must equal 2*frame_hop and be a multiple of 64";
-    if (d.num_bins != d.frame_len / 2 + 1) return "num_bins must be frame_len/2 + 1";
+    // init_kernel (feature.py:19-45): N FFT points (frame_len rounded up to a power of two, or frame_len itself), N/2 + 1 bins, a
+    // window of frame_len samples, any hop.  frame_len 512 / hop 256 takes the FFT kernel and every pipelined schedule; other
+    // sizes take the DFT-matrix product and the plain stage sequence
+    if (d.num_bins < 2 || d.frame_len < 32 || d.frame_len > 2 * (d.num_bins - 1) || d.frame_len % 4)
+        return "frame_len must be a multiple of 4, at least 32 and at most the FFT size 2 * (num_bins - 1)";
+    if (d.frame_hop < 4 || d.frame_hop > d.frame_len || d.frame_hop % 4) return "frame_hop must be a multiple of 4 in [4, frame_len]";
     // magnitude block + one block per IPD pair (ipd_index; the shipped models: one pair per extra microphone -> 1799 / 257)
     if (d.num_bins <= 0 || d.in_features % d.num_bins || d.in_features / d.num_bins < 1 ||
         d.in_features / d.num_bins > 1 + CSS_MAX_IPD_PAIRS || (d.num_mics == 1 && d.in_features != d.num_bins))
@@ -618,6 +625,47 @@ int64_t css_blob_num_floats(const CssModelDesc* desc) {
     return bind_weights(*desc, nullptr, nullptr);
 }
 
+// The analysis kernel of any frame size as a matrix (feature.py:19-45): rows f < F: cos(2 pi f n / NF) w[n], rows F + f:
+// -sin(2 pi f n / NF) w[n], n < frame_len, zero up to Lp.  The sines of DC and Nyquist are exact zeros (hazard 2).
+static int upload_analysis_matrix(css_ctx* h, int window) {
+    const int L = h->d.frame_len, F = h->d.num_bins, NF = 2 * (F - 1), Lp = h->Lp;
+    std::vector<float> m((size_t)2 * F * Lp, 0.f);
+    const double S = window == CSS_WINDOW_SQRT_HANN ? 0.5 * std::sqrt((double)NF * NF / h->d.frame_hop) : 1.0;
+    for (int n = 0; n < L; ++n) {
+        const double wn = 0.5 - 0.5 * cos(2.0 * M_PI * n / L);
+        const double w = window == CSS_WINDOW_SQRT_HANN ? (double)(float)std::sqrt((float)wn) / S : wn;
+        for (int f = 0; f < F; ++f) {
+            double c, s_;
+            exact_cs((int64_t)f * n, NF, &c, &s_);
+            m[(size_t)f * Lp + n] = (float)(c * w);
+            m[(size_t)(F + f) * Lp + n] = (float)(0.0 - s_ * w);
+        }
+    }
+    return hipMemcpy(h->dft_fwd, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? (int)CSS_OK : (int)CSS_ERR_HIP;
+}
+
+// Frames [t_lo, t_hi) of C channels (channel c's samples at x + c x_stride, zero or finite up to 32 floats past the last
+// frame) -> planes out[(c 2F + r) row_ld + t].  frame_len 512 / hop 256: the LDS-staged FFT (+ the phase planes when asked);
+// any other size: DFT matrix x overlapping frames on the exact float32 GEMM -- the frames ARE the rows of the B operand,
+// row stride = hop -- and no phase planes (*phase_done = false: the feature kernel forms the angles itself).
+static bool analysis_transform(css_ctx* h, const float* x, int64_t x_stride, int C, int64_t t_lo, int64_t t_hi, float* out,
+                               int64_t row_ld, hipStream_t st, float* phase, bool* phase_done) {
+    if (phase_done) *phase_done = false;
+    if (t_hi <= t_lo) return true;
+    if (h->fft512) {
+        if (phase_done) *phase_done = phase != nullptr;
+        return launch_stft_fft(x, x_stride, C, t_lo, t_hi, h->stft_tab, out, row_ld, st, phase);
+    }
+    const int F = h->d.num_bins;
+    GemmArgs g{};
+    g.A = h->dft_fwd; g.lda = h->Lp; g.strideA = 0;
+    g.B = x + t_lo * h->d.frame_hop; g.ldb = h->d.frame_hop; g.strideB = x_stride;
+    g.C = out + t_lo; g.ldc = row_ld; g.strideC = (int64_t)2 * F * row_ld;
+    g.M = 2 * F; g.N = (int)(t_hi - t_lo); g.K = h->Lp; g.batch = C; g.alpha = 1.f;
+    launch_gemm(g, st);
+    return true;
+}
+
 int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_floats, int device, void* stream,
                int32_t max_batch_segments, css_handle_t* out) {
     if (!desc || !blob_host || !out) return fail(nullptr, CSS_ERR_INVALID_ARG, "null argument");
@@ -681,17 +729,20 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     bind_weights(*desc, h->blob, &h->w);
     // transforms (feature.py:19-45): analysis = Hann-windowed 512-point FFT (stft.hip); synthesis = a GEMM with the
     // matrix sqrt-Hann * DFT / 16 (its output rows overlap-add, and its input is the stitched spectra in GEMM row format)
-    const int N = desc->frame_len, F = desc->num_bins, KI = h->KIp;
-    if (N != 512 || desc->frame_hop != 256) return bail(CSS_ERR_INVALID_ARG, "the analysis transform is built for frame_len 512 / frame_hop 256");
-    std::vector<float> inv((size_t)N * KI, 0.f), tab(stft_table_floats());
+    // L window samples, NF FFT points (feature.py:27: frame_len rounded up to a power of two, or frame_len), F = NF / 2 + 1
+    const int L = desc->frame_len, F = desc->num_bins, KI = h->KIp, NF = 2 * (F - 1);
+    h->fft512 = L == 512 && desc->frame_hop == 256 && F == 257;
+    h->Lp = round_up(L, 32);
+    h->ovl = (L + desc->frame_hop - 1) / desc->frame_hop;
+    std::vector<float> inv((size_t)L * KI, 0.f), tab(stft_table_floats());
     stft_build_tables(tab.data());
-    const double S = 0.5 * std::sqrt((double)N * N / desc->frame_hop);
-    for (int n = 0; n < N; ++n) {
-        const double wn = 0.5 - 0.5 * cos(2.0 * M_PI * n / N);  // torch.hann_window (periodic)
+    const double S = 0.5 * std::sqrt((double)NF * NF / desc->frame_hop);
+    for (int n = 0; n < L; ++n) {
+        const double wn = 0.5 - 0.5 * cos(2.0 * M_PI * n / L);  // torch.hann_window(frame_len) (periodic)
         const double ws = (double)(float)std::sqrt((float)wn);  // W ** 0.5 on the float32 window
         for (int f = 0; f < F; ++f) {
             double c, s;
-            exact_cs((int64_t)f * n, N, &c, &s);
+            exact_cs((int64_t)f * n, NF, &c, &s);
             inv[(size_t)n * KI + f] = (float)(c * ws / S);
             inv[(size_t)n * KI + F + f] = (float)(0.0 - s * ws / S);
         }
@@ -702,6 +753,10 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
     if (hipMemcpy(h->stft_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->dft_inv_t, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(CSS_ERR_HIP, "transform table upload failed");
+    if (!h->fft512) {
+        if (hipMalloc((void**)&h->dft_fwd, (size_t)2 * F * h->Lp * sizeof(float)) != hipSuccess) return bail(CSS_ERR_HIP, "hipMalloc(analysis matrix) failed");
+        if (upload_analysis_matrix(h, CSS_WINDOW_HANN) != CSS_OK) return bail(CSS_ERR_HIP, "analysis matrix upload failed");
+    }
     // a weight beyond the split-f16 operand range (never seen in a trained checkpoint; weights are O(1)): this model
     // runs on the exact float32 kernels
     for (int64_t i = 0; i < need && h->split; ++i)
@@ -751,6 +806,7 @@ int css_destroy(css_handle_t h) {
     for (auto& b : h->pe_frag)
         if (b.p) hipFree(b.p);
     if (h->stft_tab) hipFree(h->stft_tab);
+    if (h->dft_fwd) hipFree(h->dft_fwd);
     if (h->dft_inv_t) hipFree(h->dft_inv_t);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
@@ -808,7 +864,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     h->cfg.w_last = h->w_host.data() + 2 * T;
     h->plan = p;
     h->n_ch = n_ch;
-    h->n_pad = (n_samples + 31) / 32 * 32;   // whole 32-sample groups: the rows may be stored as split-f16 operands
+    h->n_pad = (n_samples + (h->fft512 ? 0 : 64) + 31) / 32 * 32;   // whole 32-sample groups (+ slack the generic analysis product reads past the last frame)
     h->T_ld = (p.mix_frames + 3) / 4 * 4;
     h->stft_done = h->perms_done = h->have_override = false;
     h->has_session = true;
@@ -953,12 +1009,15 @@ static int stft_frames(css_ctx* h, int64_t t_lo, int64_t t_hi, const int16_t* pl
         if (planes16) launch_pcm16_to_channel_major(planes16, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, st);
         else launch_deinterleave(h->pcm_src, (float*)h->pcm_cm.p, h->plan.n_samples, h->n_ch, h->n_pad, i_lo, i_hi, 0, st);
     }
+    if (!h->fft512)   // the generic product reads up to 31 samples past a frame (times zero columns): they must be finite
+        HIPCHK(h, hipMemset2DAsync((float*)h->pcm_cm.p + h->plan.n_samples, (size_t)h->n_pad * sizeof(float), 0,
+                                   (size_t)(h->n_pad - h->plan.n_samples) * sizeof(float), (size_t)h->n_ch, st));
     CSS_PROF(CSS_PROF_STFT, st);
-    if (!launch_stft_fft((const float*)h->pcm_cm.p, h->n_pad, h->n_ch, t_lo, f_hi, h->stft_tab, (float*)h->X.p, h->T_ld, st,
-                         (float*)h->X.p + (int64_t)h->n_ch * 2 * F * h->T_ld))
+    bool ph = false;
+    if (!analysis_transform(h, (const float*)h->pcm_cm.p, h->n_pad, h->n_ch, t_lo, f_hi, (float*)h->X.p, h->T_ld, st,
+                            (float*)h->X.p + (int64_t)h->n_ch * 2 * F * h->T_ld, &ph))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
-    h->ph_valid = true;
-    (void)F;
+    h->ph_valid = ph;
     return CSS_OK;
 }
 
@@ -1324,7 +1383,7 @@ int css_stage_stitch(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     // the inverse transform of frame range [t_lo, t_hi) also needs frame t_lo - 1 (2-frame overlap-add),
     // and the dilate/erode gate needs activity `dilation + erosion` frames to either side
     const int64_t TL = h->plan.mix_frames;
-    const int64_t y_lo = std::max<int64_t>(t_lo - 1, 0);
+    const int64_t y_lo = std::max<int64_t>(t_lo - (h->ovl - 1), 0);   // (ovl = ceil(frame_len / hop) frames over a sample: 2 as shipped)
     const int64_t halo = h->cfg.dilation_frames + h->cfg.erosion_frames;
     if ((rc = css_stage_stitch_masks(h, std::max<int64_t>(y_lo - halo, 0), std::min<int64_t>(t_hi + halo, TL))) != CSS_OK) return rc;
     return css_stage_stitch_gate(h, y_lo, t_hi);
@@ -1360,7 +1419,7 @@ static void wave_ola_on(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, in
                         int64_t out_q0, hipStream_t st) {
     if (f_hi <= f_lo) return;
     CSS_PROF(CSS_PROF_WAVE_OLA, st);
-    launch_wave_ola((const float*)h->G.p, out, h->d.num_spks, h->plan.mix_frames, h->d.frame_hop, q_lo, q_hi, f_lo, f_hi, out_ld,
+    launch_wave_ola((const float*)h->G.p, out, h->d.num_spks, h->plan.mix_frames, h->d.frame_hop, h->d.frame_len, q_lo, q_hi, f_lo, f_hi, out_ld,
                     out_q0, h->split ? h->peak_dev : nullptr, st);
 }
 static int istft_impl(css_ctx* h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out, int64_t out_ld,
@@ -1376,13 +1435,15 @@ int css_stage_istft(css_handle_t h, int64_t t_lo, int64_t t_hi) {
     int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
     const int64_t TL = h->plan.mix_frames;
-    const int64_t q_hi = (t_hi == TL) ? TL + 1 : t_hi;  // the last range also writes the tail half-frame
-    return istft_impl(h, std::max<int64_t>(t_lo - 1, 0), t_hi, t_lo, q_hi, (float*)h->wav.p, h->plan.n_out, 0, h->stream);
+    const int64_t q_hi = (t_hi == TL) ? TL - 1 + h->ovl : t_hi;  // the last range also writes the closing (half) frame(s)
+    return istft_impl(h, std::max<int64_t>(t_lo - (h->ovl - 1), 0), t_hi, t_lo, q_hi, (float*)h->wav.p, h->plan.n_out, 0, h->stream);
 }
 
 int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld) {
     int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
+    if (h->d.frame_len != 2 * h->d.frame_hop)
+        return fail(h, CSS_ERR_INVALID_ARG, "the sharded schedules (seam = one hop block) are built for frame_len = 2 * frame_hop");
     if (!shard_dev || shard_ld < (t_hi - t_lo + 1) * h->d.frame_hop) return fail(h, CSS_ERR_INVALID_ARG, "shard buffer too small");
     return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo, h->stream);
 }
@@ -1498,7 +1559,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // queued passes OVERLAP when the output is page-locked (see css_ctx::pass_no); otherwise they just queue up
     // (with the beamformer on the tail stream -- CSS_TUNE_MVDR_ON_LANES = 0 -- a tail also reads the spectra X, which the
     // next pass's transform overwrites: such passes queue up without overlapping)
-    const bool piped = io.enqueue_only && io.pcm_host && wav_mapped && h->tune[CSS_TUNE_MVDR_ON_LANES];
+    const bool piped = h->fft512 && io.enqueue_only && io.pcm_host && wav_mapped && h->tune[CSS_TUNE_MVDR_ON_LANES];
     if (io.enqueue_only && h->queued && h->last_piped != (int)piped) {
         // the overlap mode changes inside a queue (a page-locked output follows a pageable one or the reverse): the two
         // modes order the level word, the mask buffers and the tail differently, so the queue is drained on the device
@@ -1546,6 +1607,42 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // ---- nothing to hide: with the samples already in HBM the plain stage sequence (whole transform, estimator with
     // its lanes, beamformer, costs, scan, overlap-add, gate, synthesis on one stream) measures 2 % ahead of the unit
     // pipeline below (profiles/r02_shard_overhead.md: 5.35 vs 5.43 ms per 60 s meeting, 143.0 vs 146.2 ms per 30 min)
+    if (!h->fft512) {
+        // Other frame sizes (ExtractorCfg.frame_len / frame_hop): the plain stage sequence on one stream, samples up and
+        // waveforms down as whole copies -- the pipelined schedules below are built around frame_len = 2 hop
+        if (io.planes_host || io.wav16_host)
+            return fail(h, CSS_ERR_INVALID_ARG, "the PCM16 edges are built for frame_len 512 / frame_hop 256: use css_run with float PCM");
+        if (io.pcm_host) {
+            if ((rc = ensure(h, h->pcm_in, (size_t)n * n_ch * sizeof(float))) != CSS_OK) return rc;
+            h->pcm_src = (const float*)h->pcm_in.p;
+            HIPCHK(h, hipMemcpyAsync(h->pcm_in.p, io.pcm_host, (size_t)n * n_ch * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        }
+        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->stream);
+        if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
+        if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
+        if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
+        if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
+        if ((rc = css_stage_pit_scan(h)) != CSS_OK) return rc;
+        if ((rc = css_stage_stitch(h, 0, TL)) != CSS_OK) return rc;
+        float* dst = io.wav_dev;
+        int64_t dst_ld = io.cap;
+        if (!dst) {
+            if ((rc = ensure(h, h->wav, (size_t)S * pl.n_out * sizeof(float))) != CSS_OK) return rc;
+            dst = (float*)h->wav.p; dst_ld = pl.n_out;
+        }
+        if ((rc = istft_impl(h, 0, TL, 0, TL - 1 + h->ovl, dst, dst_ld, 0, h->stream)) != CSS_OK) return rc;
+        if (io.wav_host)
+            for (int sp = 0; sp < S; ++sp)
+                HIPCHK(h, hipMemcpyAsync(io.wav_host + (size_t)sp * io.cap, dst + (size_t)sp * dst_ld, (size_t)pl.n_out * sizeof(float),
+                                         hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->range_flag_host, h->range_flag_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        hipEventRecord(h->ev[7], h->stream);
+        const auto host_t1 = std::chrono::steady_clock::now();
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        const auto host_t2 = std::chrono::steady_clock::now();
+        return finish_timings(h, host_t0, host_t1, host_t2, true);
+    }
     if (io.pcm_dev && io.wav_dev && !h->tune[CSS_TUNE_PIPELINE_DEVICE]) {
         launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->stream);
         if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
@@ -2087,7 +2184,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     float* mapped = nullptr;
     if (h->mapped_key != wav_host) { h->mapped_key = wav_host; h->mapped_val = mapped_host(wav_host); }
     mapped = (float*)h->mapped_val;
-    const bool groupable = h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= h->max_batch;
+    const bool groupable = h->fft512 && h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= h->max_batch;
     if (!groupable) {
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
         RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
@@ -2338,6 +2435,7 @@ int css_set_analysis_window(css_handle_t h, int32_t window) {
     stft_build_tables(tab.data(), window);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->stft_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!h->fft512 && upload_analysis_matrix(h, window) != CSS_OK) return fail(h, CSS_ERR_HIP, "analysis matrix upload failed");
     return CSS_OK;
 }
 
@@ -2432,7 +2530,7 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     if (t_frames != T) return fail(h, CSS_ERR_SHAPE, "t_frames must be floor((n - frame_len)/hop) + 1 = " + std::to_string(T));
     if (T == 0) return CSS_OK;
     HIPCHK(h, hipSetDevice(h->device));
-    const int64_t n_pad = (n_samples + 3) / 4 * 4;
+    const int64_t n_pad = (n_samples + (h->fft512 ? 0 : 64) + 3) / 4 * 4;
     const size_t in_b = (size_t)n_samples * n_ch * sizeof(float), cm_b = (size_t)n_pad * n_ch * sizeof(float);
     const size_t out_b = (size_t)n_ch * 2 * F * T * sizeof(float);
     int rc;
@@ -2441,8 +2539,9 @@ int css_stft_host(css_handle_t h, const float* pcm, int64_t n_samples, int32_t n
     float* cm = in + ((size_t)n_samples * n_ch + 3) / 4 * 4;
     float* out = cm + (size_t)n_pad * n_ch;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_b, hipMemcpyHostToDevice, h->stream));
+    if (!h->fft512) HIPCHK(h, hipMemsetAsync(cm, 0, cm_b, h->stream));
     launch_deinterleave(in, cm, n_samples, n_ch, n_pad, 0, n_pad, 0, h->stream);
-    if (!launch_stft_fft(cm, n_pad, n_ch, 0, T, h->stft_tab, out, T, h->stream))
+    if (!analysis_transform(h, cm, n_pad, n_ch, 0, T, out, T, h->stream, nullptr, nullptr))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     HIPCHK(h, hipMemcpyAsync(x_planes, out, out_b, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2491,7 +2590,7 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     const int T = (int)T64;
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t TT = (int64_t)batch * T;
-    const int64_t n_pad = (n_samples + 31) / 32 * 32;
+    const int64_t n_pad = (n_samples + (h->fft512 ? 0 : 64) + 31) / 32 * 32;
     const size_t in_f = (size_t)batch * n_samples * C, cm_f = (size_t)batch * C * n_pad;
     const size_t x_f = (size_t)C * 2 * F * TT, ph_f = (size_t)C * F * TT, m_f = (size_t)nm * F * TT;
     int rc;
@@ -2502,16 +2601,18 @@ static int forward_staged(css_handle_t h, const float* pcm, int32_t batch, int64
     float* PH = X + (x_f + 15) / 16 * 16;
     float* M = PH + (ph_f + 15) / 16 * 16;
     HIPCHK(h, hipMemcpyAsync(in, pcm, in_f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!h->fft512) HIPCHK(h, hipMemsetAsync(cm, 0, cm_f * sizeof(float), h->stream));
+    bool ph = false;
     for (int b = 0; b < batch; ++b) {
         // analysis transform of clip b into columns [b T, (b+1) T) of the planes [C][2F][batch * T]
         launch_deinterleave(in + (size_t)b * n_samples * C, cm + (size_t)b * C * n_pad, n_samples, C, n_pad, 0, n_pad, 0, h->stream);
-        if (!launch_stft_fft(cm + (size_t)b * C * n_pad, n_pad, C, 0, T, h->stft_tab, X + (int64_t)b * T, TT, h->stream, PH + (int64_t)b * T))
+        if (!analysis_transform(h, cm + (size_t)b * C * n_pad, n_pad, C, 0, T, X + (int64_t)b * T, TT, h->stream, PH + (int64_t)b * T, &ph))
             return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     }
     const int64_t cap = std::min<int64_t>(h->max_batch, batch);
     if ((rc = ensure_activations(h, cap, T)) != CSS_OK) return rc;
     MaskIo io{X, TT, TT, T, T, M, TT};  // clip b is the "segment" starting at frame b*T
-    io.PH = PH;
+    io.PH = ph ? PH : nullptr;
     for (int64_t s0 = 0; s0 < batch; s0 += cap)
         if ((rc = masknet_batch(h, io, s0, (int)std::min<int64_t>(cap, batch - s0))) != CSS_OK) return rc;
     *Xo = X; *Mo = M; *To = T;
@@ -2544,7 +2645,7 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
     if (loss_name < 0 || loss_name > 1 || base_loss < 0 || base_loss > 1) return fail(h, CSS_ERR_INVALID_ARG, "unknown loss_name / base_loss");
     const int F = h->d.num_bins, S = h->d.num_spks;
     if (S > 3 || h->d.num_nois != 1) return fail(h, CSS_ERR_INVALID_ARG, "at most three speaker outputs and one noise output");
-    const int64_t n_pad = (n_samples + 31) / 32 * 32;
+    const int64_t n_pad = (n_samples + (h->fft512 ? 0 : 64) + 31) / 32 * 32;
     const int nsig = batch * (S + 1), chunks = val_loss_chunks(F);
     const int64_t T64 = n_samples >= h->d.frame_len ? (n_samples - h->d.frame_len) / h->d.frame_hop + 1 : 0;
     const size_t sig_f = (size_t)nsig * n_pad, g_f = (size_t)nsig * 2 * F * std::max<int64_t>(T64, 1), p_f = (size_t)batch * chunks * 16 * 2;
@@ -2562,7 +2663,7 @@ int css_validation_loss_host(css_handle_t h, const float* mix, const float* gt_s
         HIPCHK(h, hipMemcpyAsync(sig + ((size_t)b * (S + 1) + S) * n_pad, gt_noise + (size_t)b * n_samples,
                                  (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, h->stream));
     }
-    if (!launch_stft_fft(sig, n_pad, nsig, 0, T, h->stft_tab, G, T, h->stream))
+    if (!analysis_transform(h, sig, n_pad, nsig, 0, T, G, T, h->stream, nullptr, nullptr))
         return fail(h, CSS_ERR_HIP, "the analysis transform's LDS could not be reserved");
     launch_val_loss(X, M, G, batch, T, F, S, loss_name, base_loss, clip_gt ? 1 : 0, partial, h->stream);
     std::vector<double> part((size_t)batch * chunks * 16);
@@ -2708,7 +2809,7 @@ int css_istft_host(css_handle_t h, const float* y_planes, int32_t batch, int64_t
     g.M = (int)t_frames; g.N = N; g.K = KI; g.batch = batch;
     g.alpha = 1.f;
     launch_gemm(g, h->stream);
-    launch_wave_ola(G, wv, batch, t_frames, hop, 0, t_frames + 1, 0, t_frames, n_out, 0, nullptr, h->stream);
+    launch_wave_ola(G, wv, batch, t_frames, hop, N, 0, t_frames - 1 + h->ovl, 0, t_frames, n_out, 0, nullptr, h->stream);
     HIPCHK(h, hipMemcpyAsync(wav, wv, w_f * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CSS_OK;

@@ -439,10 +439,11 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
 
 // ------------------------------------------------------------------------------------------------
 // Overlap-add that completes conv_transpose1d (feature.py:162) after the synthesis GEMM produced
-// G[b][q][0..2*hop): output sample hop*q + r receives frame q (first half) and frame q-1 (second half).
+// G[b][q][0..L): output sample hop*q + r receives the frames q - j that cover it, j = ceil-ish(L / hop) - 1 .. 0 (frame_len =
+// 2 hop: frame q - 1's second half and frame q's first half).
 // Gather form: one thread per output sample, no atomics, bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-__global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ out, int64_t T_frames, int hop,
+__global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__ out, int64_t T_frames, int hop, int L,
                                 int64_t q_lo, int64_t q_hi, int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0,
                                 const unsigned int* __restrict__ level) {
     const int b = blockIdx.y;
@@ -452,20 +453,27 @@ __global__ void wave_ola_kernel(const float* __restrict__ G, float* __restrict__
     if (q >= q_hi) return;
     const int64_t n = (q - out_q0) * hop + r;
     if (n >= out_ld) return;
-    const float* g = G + (int64_t)b * T_frames * 2 * hop;
+    const float* g = G + (int64_t)b * T_frames * L;
+    // frames q - j cover this sample at offset r + j hop < L; added oldest first (frame_len = 2 hop: frame q - 1's second
+    // half, then frame q's first half -- the order this kernel has always had)
     float v = 0.f;
-    if (q - 1 >= f_lo && q - 1 < f_hi) v = g[(q - 1) * 2 * hop + hop + r];
-    if (q >= f_lo && q < f_hi) v += g[q * 2 * hop + r];
+    const int jmax = (L - 1 - r) / hop;
+    for (int j = jmax; j >= 0; --j) {
+        const int64_t t = q - j;
+        if (t < f_lo || t >= f_hi) continue;
+        const float x = g[t * L + r + (int64_t)j * hop];
+        v = j == jmax ? x : v + x;   // (the oldest frame is assigned, the later ones added to what is there -- 0.f when it was missing)
+    }
     if (level) v *= 1.0f / level_gain(level);   // a power of two: exact
     out[(int64_t)b * out_ld + n] = v;
 }
 
-void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int L, int64_t q_lo, int64_t q_hi,
                      int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, const unsigned int* level, hipStream_t s) {
     const int64_t total = (q_hi - q_lo) * hop;
     if (total <= 0) return;
     const dim3 grid((unsigned)((total + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, level);
+    hipLaunchKernelGGL(wave_ola_kernel, grid, block, 0, s, G, out, T_frames, hop, L, q_lo, q_hi, f_lo, f_hi, out_ld, out_q0, level);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -55,8 +55,11 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     constexpr int NPA = (BM + 63) / 64;      // staging passes over the A tile (64 rows x 16 floats per pass)
     // ---- staging: thread -> (row srow + 64 i, floats sk .. sk + 3) of the slab
     const int srow = tid >> 2, sk = (tid & 3) * 4;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((int64_t)M * g.lda * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)((int64_t)N * g.ldb * 4), 0x00020000);
+    // (rows may overlap -- the analysis transform of an arbitrary frame size hands the recording's frames over as rows with
+    // stride hop < K: the extent is the last row's end, not rows x stride)
+    const int64_t extA = (int64_t)(M - 1) * g.lda + (g.lda > g.K ? g.lda : g.K), extB = (int64_t)(N - 1) * g.ldb + (g.ldb > g.K ? g.ldb : g.K);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)(extA * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)(extB * 4), 0x00020000);
     const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
     const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
     const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
@@ -277,7 +280,8 @@ bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return true;
     if (g.K % F_BK) return false;
     const int64_t lim = (int64_t)1 << 31;
-    if (((int64_t)g.M + 128) * g.lda * 4 >= lim || ((int64_t)g.N + 128) * g.ldb * 4 >= lim) return false;
+    if ((((int64_t)g.M + 128) * g.lda + g.K) * 4 >= lim || (((int64_t)g.N + 128) * g.ldb + g.K) * 4 >= lim) return false;
+    if ((g.lda % 4) || (g.ldb % 4) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15)) return false;   // 16-byte operand loads
     constexpr int NCU = 256;
     F32Plan p;
     p.u = (g.M + 31) / 32;

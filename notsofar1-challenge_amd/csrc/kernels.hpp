@@ -177,7 +177,7 @@ void launch_features(const float* X, int64_t T_ld, int64_t stft_frames, int C, i
 // out[b][hop*(q - out_q0) + r] = G[b][q][r] + G[b][q-1][hop + r] for output blocks q in [q_lo, q_hi), taking
 // only frames in [f_lo, f_hi) (frame_len == 2*hop); out has row stride out_ld
 // level (may be null): the samples are multiplied by 1 / level_gain(level) (undoes the scaling of the split spectra rows)
-void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int64_t q_lo, int64_t q_hi,
+void launch_wave_ola(const float* G, float* out, int B, int64_t T_frames, int hop, int frame_len, int64_t q_lo, int64_t q_hi,
                      int64_t f_lo, int64_t f_hi, int64_t out_ld, int64_t out_q0, const unsigned int* level, hipStream_t s);
 // gathered [world][S][ld] waveform shards (rank r: output blocks t_lo[r] .. t_hi[r]) -> out [S][out_ld] (world <= 64)
 void launch_join_shards(const float* gathered, int64_t ld, const int64_t* t_lo, const int64_t* t_hi, int world, int S, int hop,

@@ -81,9 +81,12 @@ def desc_from_cfg(cfg: ConformerCssCfg) -> ModelDesc:
     """ConformerCssCfg -> the C ABI's model descriptor.  The spectral and IPD options of ExtractorCfg
     (`log_spectrogram`, `mvn_spectrogram`, `ipd_index`, `ipd_mean_normalize`, `ipd_mean_normalize_version`, `ipd_cos`) are
     all implemented (css_set_feature_options), and so are both analysis windows init_kernel builds, 'hann' and 'sqrt_hann'
-    (css_set_analysis_window; feature.py:24-36); `round_pow_of_two` changes nothing at a power-of-two frame length
-    (feature.py:27).  Rejected: another frame size (the FFT kernel is the 512-point transform with hop 256) and
-    `ang_index` -- the reference's own wrapper never passes the direction of arrival its AngleFeature needs
+    (css_set_analysis_window; feature.py:24-36).  `frame_len` / `frame_hop` / `round_pow_of_two` (init_kernel,
+    feature.py:19-45): N = frame_len rounded up to a power of two (or frame_len itself) FFT points, N / 2 + 1 bins, a window
+    of frame_len samples, any hop that is a multiple of 4; 512 / 256 takes the FFT kernel and the pipelined schedules, other
+    sizes the DFT-matrix product and the plain stage sequence.  (The reference's own wrapper builds its network with 257
+    mask bins whatever the extractor says -- NnetCfg has no num_bins, conformer.py:260 -- so through it only N = 512 can
+    run: frame_len in (256, 512] with round_pow_of_two, e.g. 400 / 160.)  Rejected: `ang_index` -- the reference's own wrapper never passes the direction of arrival its AngleFeature needs
     (conformer_wrapper.py:96-100 calls the executor without `doa`), so no model can use it there either."""
     e, n = cfg.extractor_conf, cfg.nnet_conf
     if e.ang_index != _SUPPORTED_EXTRACTOR.ang_index:
@@ -91,8 +94,9 @@ def desc_from_cfg(cfg: ConformerCssCfg) -> ModelDesc:
                                   f"(supported: {_SUPPORTED_EXTRACTOR.ang_index!r})")
     if e.window not in _lib.ANALYSIS_WINDOWS:
         raise RuntimeError("Now only support sqrt hanning window or hann window")   # feature.py:24-25
-    if (e.frame_len, e.frame_hop) != (512, 256):
-        raise NotImplementedError("the analysis transform is built for frame_len 512 / frame_hop 256")
+    n_fft = 2 ** int(np.ceil(np.log2(e.frame_len))) if e.round_pow_of_two else e.frame_len     # feature.py:27
+    if e.frame_len % 4 or e.frame_hop % 4 or not (4 <= e.frame_hop <= e.frame_len) or e.frame_len < 32 or n_fft % 2:
+        raise NotImplementedError("frame_len / frame_hop must be multiples of 4, 4 <= frame_hop <= frame_len, frame_len >= 32")
     pairs = ipd_pairs(e.ipd_index)
     if len(pairs) > 16:
         raise NotImplementedError("at most 16 IPD pairs")
@@ -100,7 +104,7 @@ def desc_from_cfg(cfg: ConformerCssCfg) -> ModelDesc:
         raise RuntimeError(f"expect ipd_mean_normalization version 1, 2 or 3, got {e.ipd_mean_normalize_version}")  # feature.py:228-231
     num_mics = (max(max(p) for p in pairs) + 1) if pairs else 1
     num_mics = 7 if pairs and num_mics <= 7 else num_mics        # the NOTSOFAR array (mic_array_model.py:4)
-    bins = e.frame_len // 2 + 1
+    bins = n_fft // 2 + 1
     assert n.in_features == bins * (1 + len(pairs)), \
         f"in_features={n.in_features} does not match {bins} bins x (1 + {len(pairs)} IPD pairs)"
     c = n.conformer_conf

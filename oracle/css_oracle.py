@@ -107,42 +107,51 @@ def hann_periodic(n: int, dtype=np.float32) -> np.ndarray:
     return (0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)).astype(dtype)
 
 
-def _dft_angles(frame_len: int):
-    """cos/sin of 2 pi f n / N with the argument reduced mod N in integers, so that the DC and Nyquist
-    sine rows are EXACTLY zero -- as they are in the reference's kernel, which is the rfft of an
-    identity matrix (feature.py:40).  Exact zeros there make Im X[0] = Im X[N/2] = +0.0, which the
-    phase features below depend on."""
+def fft_points(frame_len: int, round_pow_of_two: bool = True) -> int:
+    """feature.py:27: N = 2 ** ceil(log2(frame_len)) if round_pow_of_two else frame_len"""
+    return 2 ** int(math.ceil(math.log2(frame_len))) if round_pow_of_two else frame_len
+
+
+def _dft_angles(frame_len: int, n_fft: Optional[int] = None):
+    """cos/sin of 2 pi f n / N (f <= N / 2, n < frame_len) with the argument reduced mod N in integers, so that the DC and
+    Nyquist sine rows are EXACTLY zero -- as they are in the reference's kernel, which is the rfft of an identity matrix
+    cut to its first frame_len rows (feature.py:40).  Exact zeros there make Im X[0] = Im X[N/2] = +0.0, which the phase
+    features below depend on."""
+    N = frame_len if n_fft is None else n_fft
     n = np.arange(frame_len, dtype=np.int64)
-    f = np.arange(frame_len // 2 + 1, dtype=np.int64)
-    k = np.outer(f, n) % frame_len
-    ang = 2.0 * np.pi * k.astype(np.float64) / frame_len
+    f = np.arange(N // 2 + 1, dtype=np.int64)
+    k = np.outer(f, n) % N
+    ang = 2.0 * np.pi * k.astype(np.float64) / N
     c, s = np.cos(ang), np.sin(ang)
-    s[(2 * k) % frame_len == 0] = 0.0      # multiples of pi
-    c[(4 * k) % frame_len == 0] = np.round(c[(4 * k) % frame_len == 0])  # multiples of pi/2
+    s[(2 * k) % N == 0] = 0.0      # multiples of pi
+    c[(4 * k) % N == 0] = np.round(c[(4 * k) % N == 0])  # multiples of pi/2
     return c, s
 
 
-def stft_kernel(frame_len: int = 512, dtype=np.float32, window: str = "hann", frame_hop: int = 256) -> np.ndarray:
-    """Analysis kernel K[2F, frame_len] (rows 0..F-1 = cos*w, rows F.. = -sin*w).  feature.py:19-45:
+def stft_kernel(frame_len: int = 512, dtype=np.float32, window: str = "hann", frame_hop: int = 256, n_fft: Optional[int] = None) -> np.ndarray:
+    """Analysis kernel K[2F, frame_len] (rows 0..F-1 = cos*w, rows F.. = -sin*w; F = N / 2 + 1, N = n_fft FFT points,
+    default frame_len).  feature.py:19-45:
     window='hann' -> S = 1; window='sqrt_hann' -> W = hann ** 0.5 (on the float32 window, feature.py:29-31) and
     S = 0.5 sqrt(N N / hop) (init_kernel's `normalize` stays True: STFTBase does not pass its own, feature.py:63-66)."""
     if window not in ("hann", "sqrt_hann"):
         raise RuntimeError("Now only support sqrt hanning window or hann window")   # feature.py:24-25
-    c, s = _dft_angles(frame_len)
+    N = frame_len if n_fft is None else n_fft
+    c, s = _dft_angles(frame_len, N)
     if window == "hann":
         w = hann_periodic(frame_len, np.float64)
     else:
-        w = np.sqrt(hann_periodic(frame_len, np.float32)).astype(np.float64) / (0.5 * math.sqrt(frame_len * frame_len / frame_hop))
+        w = np.sqrt(hann_periodic(frame_len, np.float32)).astype(np.float64) / (0.5 * math.sqrt(N * N / frame_hop))
     k = np.concatenate([c * w, 0.0 - s * w], axis=0)
     return k.astype(dtype)
 
 
-def istft_kernel(frame_len: int = 512, frame_hop: int = 256, dtype=np.float32) -> np.ndarray:
-    """Synthesis kernel K[2F, frame_len]: sqrt-hann / S with S = 0.5*sqrt(N*N/hop) = 16.
+def istft_kernel(frame_len: int = 512, frame_hop: int = 256, dtype=np.float32, n_fft: Optional[int] = None) -> np.ndarray:
+    """Synthesis kernel K[2F, frame_len]: sqrt-hann / S with S = 0.5*sqrt(N*N/hop) (16 as shipped).
     feature.py:30-36 (iSTFT is built without ``window`` -> 'sqrt_hann', feature.py:422-425)."""
-    c, sn = _dft_angles(frame_len)
+    N = frame_len if n_fft is None else n_fft
+    c, sn = _dft_angles(frame_len, N)
     w = np.sqrt(hann_periodic(frame_len, np.float64))
-    s = 0.5 * math.sqrt(frame_len * frame_len / frame_hop)
+    s = 0.5 * math.sqrt(N * N / frame_hop)
     k = np.concatenate([c * w / s, 0.0 - sn * w / s], axis=0)
     return k.astype(dtype)
 
@@ -154,7 +163,8 @@ def num_frames(n_samples: int, frame_len: int = 512, frame_hop: int = 256) -> in
     return (n_samples - frame_len) // frame_hop + 1
 
 
-def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256, window: str = "hann") -> np.ndarray:
+def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256, window: str = "hann",
+         n_fft: Optional[int] = None) -> np.ndarray:
     """x [N, C] (or [N]) -> complex X [F, T, C] (or [F, T]).
 
     ConformerCssWrapper.stft (conformer_wrapper.py:106-129): conv1d with the Hann-DFT kernel
@@ -165,8 +175,8 @@ def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int =
         x = x[:, None]
     n, c = x.shape
     t = num_frames(n, frame_len, frame_hop)
-    k = stft_kernel(frame_len, dtype, window, frame_hop)
-    nb = frame_len // 2 + 1
+    k = stft_kernel(frame_len, dtype, window, frame_hop, n_fft)
+    nb = k.shape[0] // 2
     cdtype = np.complex64 if dtype == np.float32 else np.complex128
     out = np.zeros((nb, t, c), dtype=cdtype)
     xs = np.ascontiguousarray(x.T.astype(dtype))  # [C, N]
@@ -181,14 +191,14 @@ def stft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int =
     return out[:, :, 0] if squeeze else out
 
 
-def istft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256) -> np.ndarray:
+def istft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int = 256, n_fft: Optional[int] = None) -> np.ndarray:
     """complex X [B, F, T] -> real [B, (T-1)*hop + frame_len].
 
     ConformerCssWrapper.istft (conformer_wrapper.py:131-146): abs/angle, then m cos p / m sin p
-    (feature.py:157-158) and conv_transpose1d with the sqrt-Hann/16 kernel (feature.py:162).
+    (feature.py:157-158) and conv_transpose1d with the sqrt-Hann / S kernel (feature.py:162).
     """
     b, nb, t = x.shape
-    k = istft_kernel(frame_len, frame_hop, dtype)  # [2F, L]
+    k = istft_kernel(frame_len, frame_hop, dtype, n_fft)  # [2F, L]
     m = np.abs(x).astype(dtype)
     p = _angle(x, dtype)
     r = m * _cos(p, dtype)
@@ -197,10 +207,12 @@ def istft(x: np.ndarray, dtype=np.float32, frame_len: int = 512, frame_hop: int 
     out = np.zeros((b, (t - 1) * frame_hop + frame_len), dtype=dtype)
     for bi in range(b):
         g = c[bi].T @ k  # [T, L]
-        # overlap-add: frame t lands at [t*hop, t*hop+L)
-        for half in range(frame_len // frame_hop):
-            seg = g[:, half * frame_hop:(half + 1) * frame_hop].reshape(-1)
-            out[bi, half * frame_hop: half * frame_hop + seg.size] += seg
+        # overlap-add: frame t lands at [t*hop, t*hop+L); an output sample receives its frames oldest first
+        for j in reversed(range((frame_len + frame_hop - 1) // frame_hop)):
+            piece = g[:, j * frame_hop:min((j + 1) * frame_hop, frame_len)]     # offsets [j hop, (j+1) hop) of every frame
+            w = piece.shape[1]
+            for tt in range(t):
+                out[bi, (tt + j) * frame_hop:(tt + j) * frame_hop + w] += piece[tt]
     return out
 
 
@@ -644,20 +656,23 @@ def make_plan(n_samples: int, fs: int, cfg, frame_len: int = 512, frame_hop: int
 # ----------------------------------------------------------------------------------------------
 def separate_and_stitch(speech_mix: np.ndarray, params: ConformerParams, fs: int, cfg,
                         mvdr_cplx=None, separate_fn=None, taps: Optional[dict] = None,
-                        wta_override: Optional[np.ndarray] = None):
+                        wta_override: Optional[np.ndarray] = None, frame: Optional[dict] = None):
     """speech_mix [1, N, C] float32 -> (list of S float32 [N_out], side_info).
 
     ``separate_fn(i, stft_seg[F, T, C]) -> (spk [F,T,S], noise [F,T,1])`` overrides the mask estimator
     (used by tests to inject e.g. rotated speaker orders); ``wta_override``
-    [num_segments, F, T] injects winner-take-all decisions (see ``make_wta``)."""
+    [num_segments, F, T] injects winner-take-all decisions (see ``make_wta``).  ``frame``: the extractor's geometry,
+    dict(frame_len=, frame_hop=, n_fft=, window=) (ExtractorCfg, feature.py:19-45); default 512 / 256 / 512 / 'hann'."""
+    fr = dict(frame_len=512, frame_hop=256, n_fft=None, window="hann")
+    fr.update(frame or {})
     assert speech_mix.ndim == 3, f"expecting 3 dimensions, got {speech_mix.shape}"          # css.py:139
     assert speech_mix.shape[0] == 1, "assuming 1 example in batch"                          # css.py:196
     dt = params.dtype if params is not None else np.float32
     x = speech_mix[0]
     n, c = x.shape
-    plan = make_plan(n, fs, cfg)
+    plan = make_plan(n, fs, cfg, fr["frame_len"], fr["frame_hop"])
     tseg, hop = plan.segment_frames, plan.hop_frames
-    stft_mix = stft(x, dt)  # [F, T_long, C]                                               css.py:155
+    stft_mix = stft(x, dt, fr["frame_len"], fr["frame_hop"], fr["window"], fr["n_fft"])  # [F, T_long, C]                                               css.py:155
     nb = stft_mix.shape[0]
     if stft_mix.shape[1] < tseg:                                                            # css.py:159-164
         pad = np.zeros((nb, tseg - stft_mix.shape[1], c), dtype=stft_mix.dtype)
@@ -735,7 +750,7 @@ def separate_and_stitch(speech_mix: np.ndarray, params: ConformerParams, fs: int
     act_final = np.stack([erode(dilate(activity_b[:, k], plan.dilation_frames), plan.erosion_frames)
                           for k in range(s)], axis=1)
     stft_st = stft_st * act_final[None].astype(np.float32)
-    wavs = istft(np.ascontiguousarray(np.moveaxis(stft_st, 2, 0)), dt)                     # css.py:316-319
+    wavs = istft(np.ascontiguousarray(np.moveaxis(stft_st, 2, 0)), dt, fr["frame_len"], fr["frame_hop"], fr["n_fft"])   # css.py:316-319
     side = {
         "mask_stitched": mask_st[None],            # [1, F, T_long, S]
         "activity_b": activity_b,                  # [T_long, S]

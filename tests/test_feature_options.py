@@ -99,9 +99,14 @@ def test_hip_features_and_masks_vs_oracle_and_reference(name, golden, mix60):
 
 def test_unsupported_extractor_options_are_rejected_loudly():
     S = pkg("separator")
-    for kw in (dict(ang_index="1,0;2,0"), dict(frame_len=400, frame_hop=160)):
+    for kw in (dict(ang_index="1,0;2,0"), dict(frame_len=400, frame_hop=150), dict(frame_len=402, frame_hop=160), dict(frame_len=256, frame_hop=512)):
         with pytest.raises(NotImplementedError):
             S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(**kw)))
+    # other frame sizes are mapped as init_kernel maps them (feature.py:27): 400 samples on 512 FFT points -> 257 bins
+    d = S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(frame_len=400, frame_hop=160)))
+    assert (d.frame_len, d.frame_hop, d.num_bins) == (400, 160, 257)
+    with pytest.raises(AssertionError):    # 1024 FFT points are 513 bins: not this network's 1799 = 257 x 7 inputs
+        S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(frame_len=1024, frame_hop=256)))
     with pytest.raises(RuntimeError):
         S.desc_from_cfg(S.ConformerCssCfg(extractor_conf=S.ExtractorCfg(ipd_mean_normalize_version=4)))
     with pytest.raises(RuntimeError):      # init_kernel's own error (feature.py:24-25)
