@@ -1,14 +1,38 @@
-"""Row N4's oracle (`oracle/css_oracle.py::whisper_log_mel`) against an INDEPENDENT implementation of Whisper's front
-end that the image does hold: `transformers.WhisperFeatureExtractor` (numpy; Hugging Face's counterpart of
-whisper/audio.py `log_mel_spectrogram`, the function the reference's ASR leg feeds -- asr/asr.py via `whisper.transcribe`).
-openai-whisper itself is not in the image, so this pins the restatement to the published algorithm as a second party
-implements it, not to the package the reference imports.  CPU only."""
+"""Row N4's oracle (`oracle/css_oracle.py::whisper_log_mel`) pinned twice.  (1) To COMMITTED VECTORS of Whisper's published
+definition (tests/golden/whisper_logmel_r5.npz from gen_golden_whisper.py: whisper/audio.py's `log_mel_spectrogram` evaluated
+with torch.stft -- the call whisper itself makes -- and its `mel_filters` asset rebuilt from the librosa definition that
+file's docstring names; no code shared with the oracle, the HIP kernels or transformers).  (2) To an independent
+implementation the image does hold: `transformers.WhisperFeatureExtractor` (numpy).  openai-whisper itself is not in the
+image and not under /root/reference (the reference imports it, asr/asr.py).  CPU only."""
 import numpy as np
 import pytest
 
 import css_oracle as O
 
+from conftest import GOLDEN
+
 transformers = pytest.importorskip("transformers")
+
+
+def _signals():
+    rs = np.random.RandomState(4)
+    t = np.arange(30 * 16000) / 16000.0
+    chunk = (0.2 * np.sin(2 * np.pi * 440 * t) * (np.sin(2 * np.pi * 0.3 * t) > 0) + 0.02 * rs.randn(t.size)).astype(np.float32)
+    clip = (0.1 * np.random.RandomState(5).randn(7 * 16000)).astype(np.float32)
+    return {"chunk30": chunk, "clip7": clip}
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_oracle_vs_the_committed_vectors_of_the_published_definition(n_mels):
+    import os
+    g = np.load(os.path.join(GOLDEN, "whisper_logmel_r5.npz"))
+    bank = g[f"mel_filters_{n_mels}"]
+    assert bank.shape == (n_mels, 201) and np.abs(O._slaney_mel_bank(n_mels) - bank).max() < 1e-7
+    for name, x in _signals().items():
+        ref = g[f"{name}_logmel_{n_mels}"]
+        got = O.whisper_log_mel(x, n_mels)[:, ::3]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert np.abs(got - ref).max() < 2e-4, (name, float(np.abs(got - ref).max()))
 
 
 def _hf(audio, n_mels):
