@@ -13,7 +13,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcss_mi355.so")
+# (CSS_MI355_LIBRARY: another build of the SAME library -- the AddressSanitizer build of tools/asan_tests.sh; nothing else)
+LIB_PATH = os.environ.get("CSS_MI355_LIBRARY") or os.path.join(_HERE, "libcss_mi355.so")
 
 
 class CssLibraryError(RuntimeError):
