@@ -214,7 +214,8 @@ enum css_tuning {
                                            * overlap-add kernel writes the page-locked output over PCIe itself                   */
     CSS_TUNE_F32_GEMM = 9,                /* CSS_LINEAR_EXACT_F32 products: 0 (default): gemm_f32.hip, four independent blocks per CU and
                                            * tile heights balanced over the CUs; 1: the round-4 kernel (gemm.hip); 2..5: gemm_f32.hip with
-                                           * every tile 32 / 64 / 96 / 128 rows.  Same bits whichever                               */
+                                           * every tile 32 / 64 / 96 / 128 rows; 6: gemm_f32.hip with the weights row-major through LDS
+                                           * (the default reads them as register fragments).  Same bits whichever                  */
     CSS_TUNE_COUNT = 10
 };
 int css_set_tuning(css_handle_t h, int which, int value);

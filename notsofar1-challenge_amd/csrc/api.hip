@@ -100,6 +100,7 @@ struct css_ctx : SessState {
     bool split_ok = true;        // false: a weight lies outside the split-f16 operand range, CSS_LINEAR_SPLIT_F16 is refused
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
+    float* wfrag = nullptr;      // exact float32 mode: the Linear weights in gemm_f32.hip's fragment order (same offsets as blob)
     float* dft_tiled = nullptr;  // ... and in the tile-major layout of the weights-direct GEMM (whole-meeting synthesis)
     float* head_tiled = nullptr; // the mask head's weights in that layout (rows rounded up to 32; wsplit keeps the row-major image)
     DevBuf pe_frag[2];           // relative-position rows in attention-operand order for segment length pe_frag_T
@@ -473,7 +474,7 @@ void gemm(css_ctx* h, const GemmArgs& g, hipStream_t st) {
     if (!g.split_in && !g.layout && h->tune[CSS_TUNE_F32_GEMM]) {   // (A/B and tests: which exact float32 kernel; same bits)
         GemmArgs q = g;
         const int t = h->tune[CSS_TUNE_F32_GEMM];
-        q.layout = t == 1 ? 2 : 10 + std::min(t - 1, 4);
+        q.layout = t == 1 ? 2 : (t == 6 ? 1 : 10 + std::min(t - 1, 4));
         launch_gemm(q, st);
         return;
     }
@@ -585,6 +586,26 @@ int make_split_weights(css_ctx* h) {
     // the relative-position table, row-major split: the attention kernel uses its rows like key rows
     const int dk = D / d.attention_heads;
     launch_split_convert(h->w.pe_k, dk, h->wsplit + (h->w.pe_k - h->blob), 2 * (int64_t)d.maxlen, dk, dk, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+// CSS_LINEAR_EXACT_F32: the Linear weights once more, float32 in the fragment order of gemm_f32.hip (GemmArgs::b_frag32): a
+// wave reads its 32 columns' operands of a slab as two coalesced 1 KiB loads straight into registers.  Built on first use.
+int make_frag_weights(css_ctx* h) {
+    if (h->wfrag) return CSS_OK;
+    const CssModelDesc& d = h->d;
+    const int64_t need = bind_weights(d, nullptr, nullptr);
+    HIPCHK(h, hipMalloc((void**)&h->wfrag, need * sizeof(float)));
+    const int D = d.attention_dim, FF = d.linear_units;
+    auto conv = [&](const float* w, int rows, int K) { launch_f32_fragments(w, K, h->wfrag + (w - h->blob), rows, K, h->stream); };
+    conv(h->w.embed_w, D, h->Kp);
+    for (const BlockWeights& b : h->w.blocks) {
+        conv(b.ffi_w1, FF, D); conv(b.ffi_w2, D, FF);
+        conv(b.wqkv, 3 * D, D); conv(b.wo, D, D);
+        conv(b.ffo_w1, FF, D); conv(b.ffo_w2, D, FF);
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return CSS_OK;
@@ -763,6 +784,7 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         if (!(std::fabs(blob_host[i]) <= 65504.f)) h->split = false;
     h->split_ok = h->split;
     if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
+    if (!h->split && make_frag_weights(h) != CSS_OK) { (void)hipGetLastError(); if (h->wfrag) { hipFree(h->wfrag); h->wfrag = nullptr; } }
     *out = h;
     return CSS_OK;
 }
@@ -800,6 +822,7 @@ int css_destroy(css_handle_t h) {
     if (h->range_flag_host) hipHostFree(h->range_flag_host);
     for (auto& e : h->ev_pool) hipEventDestroy(e);
     if (h->wsplit) hipFree(h->wsplit);
+    if (h->wfrag) hipFree(h->wfrag);
     if (h->dft_split) hipFree(h->dft_split);
     if (h->dft_tiled) hipFree(h->dft_tiled);
     if (h->head_tiled) hipFree(h->head_tiled);
@@ -1077,10 +1100,15 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
     // directly (features, LayerNorm, the FFN's first GEMM, attention), the residual stream x stays float32.
     const int sp = h->split ? 1 : 0;
     auto WS = [&](const float* w) { return sp ? h->wsplit + (w - h->blob) : w; };
+    // exact float32: the weights in fragment order for gemm_f32.hip (CSS_TUNE_F32_GEMM 0 and 2..5; 1 = round 4's kernel and
+    // 6 = gemm_f32.hip with both operands through LDS read the row-major weights) -- same bits either way
+    const int f32_tune = h->tune[CSS_TUNE_F32_GEMM];
+    const bool frag = !sp && h->wfrag && f32_tune != 1 && f32_tune != 6 && (int64_t)M * std::max(h->Kp, FF) * 4 < ((int64_t)1 << 30);
     auto lin = [&](const float* A, int64_t lda, const float* Wt, const float* bias, float* C, int64_t ldc, int n, int k,
                    int act, int split_out) {
-        GemmArgs g = linear(A, lda, WS(Wt), lda, bias, C, ldc, M, n, k, act);
+        GemmArgs g = linear(A, lda, frag ? h->wfrag + (Wt - h->blob) : WS(Wt), lda, bias, C, ldc, M, n, k, act);
         g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
+        g.b_frag32 = frag ? 1 : 0;
         g.range_flag = sp ? h->range_flag_dev : nullptr;
         return g;
     };
@@ -2392,6 +2420,9 @@ int css_set_linear_mode(css_handle_t h, int mode) {
     if (split) {
         int rc = make_split_weights(h);
         if (rc) return rc;
+    } else if (make_frag_weights(h) != CSS_OK) {
+        (void)hipGetLastError();   // (no room for the second image: the float32 kernel takes the row-major weights through LDS)
+        if (h->wfrag) { hipFree(h->wfrag); h->wfrag = nullptr; }
     }
     // the feature rows change format; their K padding must read as zero in either
     if (h->feat.p) HIPCHK(h, hipMemsetAsync(h->feat.p, 0, h->feat.cap, h->stream));

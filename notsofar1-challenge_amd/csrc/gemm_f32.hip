@@ -46,7 +46,11 @@ __device__ __forceinline__ float epi_value(float acc, float bn, float bm, int ac
     return v;
 }
 
-template <int TM>
+// BD: the B operand is a static weight in FRAGMENT order (launch_f32_fragments: float4 index ((j K/8 + kc) 64 + lane) holds
+// W[32 j + (lane & 31)][8 kc + 4 (lane >> 5) .. + 3], i.e. what lane `lane` feeds to the four MFMAs of chunk kc for column
+// tile j): it goes global -> registers as one coalesced 1 KiB load per wave and chunk -- no LDS store, no LDS read, half the
+// slab buffer -- because every memory instruction of this loop costs matrix issue time.
+template <int TM, bool BD>
 __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restrict__ A, const float* __restrict__ B,
                                          float* __restrict__ C, const int m0, const int n0, float* __restrict__ lds) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
@@ -59,7 +63,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     // stride hop < K: the extent is the last row's end, not rows x stride)
     const int64_t extA = (int64_t)(M - 1) * g.lda + (g.lda > g.K ? g.lda : g.K), extB = (int64_t)(N - 1) * g.ldb + (g.ldb > g.K ? g.ldb : g.K);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)(extA * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)(extB * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)((BD ? (int64_t)((N + 31) / 32 * 32) * g.K : extB) * 4), 0x00020000);
     const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
     const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
     const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
@@ -85,19 +89,28 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 #define F32_LSTORE(buf) __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's pieces of the next slab have landed */
 #else
     f32x4 ra[NPA], rb[2];
+    f32x4 wc[2], wn[2];   // BD: this slab's / the next slab's weight fragments (two chunks of 8 k each)
+    const int vw = (int)((((int64_t)(n0 / 32 + w) * (g.K / 8)) * 64 + lane) * 16);
 #define F32_GLOAD(k0, buf)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                            \
         if (i + 1 < NPA || a1_on) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (k0) * 4 + i * passA, 0)); \
     }                                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
-        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voB, (k0) * 4 + i * passB, 0));
+    if constexpr (!BD) {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voB, (k0) * 4 + i * passB, 0)); \
+    } else {                                                                                                     \
+        wn[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vw, ((k0) / 8) * 1024, 0)); \
+        wn[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vw, ((k0) / 8 + 1) * 1024, 0)); \
+    }
 #define F32_LSTORE(buf)                                                                                          \
     {                                                                                                            \
         float* as_ = lds + (buf) * F_BUF + srow * F_LD + sk;                                                     \
         _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                        \
             if (i + 1 < NPA || a1_on) *reinterpret_cast<f32x4*>(as_ + i * 64 * F_LD) = ra[i];                    \
         }                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(as_ + (128 + i * 64) * F_LD) = rb[i]; \
+        if constexpr (!BD) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(as_ + (128 + i * 64) * F_LD) = rb[i]; \
+        }                                                                                                        \
     }
 #endif
     f32x16 acc[TM];
@@ -106,6 +119,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const int nk = g.K / F_BK;
     F32_GLOAD(0, 0)
     F32_LSTORE(0)
+    if constexpr (BD) { wc[0] = wn[0]; wc[1] = wn[1]; }
     __syncthreads();
 #if F32_DMA
     constexpr int S_BUF = D_BUF, S_LD = 16;
@@ -156,7 +170,8 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
         const float* bs = lds + (buf) * S_BUF + boff;                                                            \
         _Pragma("unroll") for (int ch = 0; ch < 2; ++ch) {                                                       \
             f32x4 b = abl_b;                                                                                     \
-            if (!(F32_ABLATE & 4)) b = *reinterpret_cast<const f32x4*>(bs + F32_SLOT(ch));                       \
+            if constexpr (BD) b = wc[ch];                                                                        \
+            else if (!(F32_ABLATE & 4)) b = *reinterpret_cast<const f32x4*>(bs + F32_SLOT(ch));                  \
             f32x4 a[TM];                                                                                         \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
                 a[i] = abl_a;                                                                                    \
@@ -178,6 +193,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
         __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the loads below the MFMAs, next to their LDS stores)
         F32_COMPUTE(kt & 1)
         if (!(F32_ABLATE & 2)) { F32_LSTORE((kt + 1) & 1) }
+        if constexpr (BD) { wc[0] = wn[0]; wc[1] = wn[1]; }
         if (!(F32_ABLATE & 1)) __syncthreads();
     }
     // the last slab: the first tile's epilogue operands travel under its MFMAs
@@ -238,6 +254,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 // unit.  Virtual CU v of `ncu` takes [v U / ncu, (v + 1) U / ncu), its block j of four a quarter of that.
 struct F32Plan { int u, tiles_n, ncu, max_tm; int64_t U; unsigned long long* dbg; };   // dbg (tools): block 0 records shader / wall clocks
 
+template <bool BD>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * F_BUF];
     const int b = blockIdx.x, v = b % p.ncu, j = b / p.ncu;
@@ -264,10 +281,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p)
         if (!first) __syncthreads();   // the previous tile's epilogue patches lie over the slab buffers
         first = false;
         switch (tm) {
-            case 1: f32_tile<1>(g, A, B, C, 32 * r, tn * BN, lds); break;
-            case 2: f32_tile<2>(g, A, B, C, 32 * r, tn * BN, lds); break;
-            case 3: f32_tile<3>(g, A, B, C, 32 * r, tn * BN, lds); break;
-            default: f32_tile<4>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            case 1: f32_tile<1, BD>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            case 2: f32_tile<2, BD>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            case 3: f32_tile<3, BD>(g, A, B, C, 32 * r, tn * BN, lds); break;
+            default: f32_tile<4, BD>(g, A, B, C, 32 * r, tn * BN, lds); break;
         }
         pos += tm;
         want = p.max_tm;
@@ -281,7 +298,8 @@ bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
     if (g.K % F_BK) return false;
     const int64_t lim = (int64_t)1 << 31;
     if ((((int64_t)g.M + 128) * g.lda + g.K) * 4 >= lim || (((int64_t)g.N + 128) * g.ldb + g.K) * 4 >= lim) return false;
-    if ((g.lda % 4) || (g.ldb % 4) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15)) return false;   // 16-byte operand loads
+    if (g.b_frag32 && (g.N % 32 || g.K % 16 || g.batch != 1 || ((int64_t)g.N * g.K * 4 >= lim))) return false;
+    if ((g.lda % 4) || (!g.b_frag32 && (g.ldb % 4)) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15)) return false;   // 16-byte operand loads
     constexpr int NCU = 256;
     F32Plan p;
     p.u = (g.M + 31) / 32;
@@ -290,8 +308,27 @@ bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
     p.max_tm = (forced_tm >= 1 && forced_tm <= 4) ? forced_tm : 4;
     p.U = (int64_t)p.u * p.tiles_n * g.batch;
     p.dbg = g.narrow_epilogue == 77 ? reinterpret_cast<unsigned long long*>(g.range_flag) : nullptr;   // (tools/gemm_f32_bench.hip)
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(4 * NCU), dim3(256), 0, s, g, p);
+    if (g.b_frag32) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(4 * NCU), dim3(256), 0, s, g, p);
+    else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(4 * NCU), dim3(256), 0, s, g, p);
     return true;
+}
+
+
+// float32 W [N][K] (row stride ld_src; N % 32 == 0, K % 8 == 0) -> fragment order for gemm_f32_kernel<true> (see f32_tile)
+__global__ void f32_fragments_kernel(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int N, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of dst
+    const int64_t total = (int64_t)(N / 32) * (K / 8) * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t t = idx >> 6;
+    const int kc = (int)(t % (K / 8)), j = (int)(t / (K / 8));
+    const float* p = src + (int64_t)(32 * j + (lane & 31)) * ld_src + 8 * kc + 4 * (lane >> 5);
+    reinterpret_cast<float4*>(dst)[idx] = make_float4(p[0], p[1], p[2], p[3]);
+}
+void launch_f32_fragments(const float* src, int64_t ld_src, float* dst, int N, int K, hipStream_t s) {
+    const int64_t total = (int64_t)(N / 32) * (K / 8) * 64;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(f32_fragments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, N, K);
 }
 
 }  // namespace css

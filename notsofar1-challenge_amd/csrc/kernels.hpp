@@ -32,6 +32,8 @@ struct GemmArgs {
     // b_tiled (with split_in): B is a weight matrix in the tile-major split layout of gemm_split_wd.hip
     // (launch_split_convert_tiled); batch must be 1 and N % 32 == 0.
     int b_tiled;
+    // b_frag32 (exact float32, gemm_f32.hip): B is a weight in float32 FRAGMENT order (launch_f32_fragments); batch 1, N % 32 == 0
+    int b_frag32;
     // hint: other kernels run beside this launch (two-lane mask estimator): prefer 4-wave 64-row tiles, two of which
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;
@@ -62,6 +64,8 @@ void launch_gemm(const GemmArgs& g, hipStream_t s);        // dispatches on g.sp
 // gemm.hip's kernel); forced_tm = 1..4: every tile 32 * forced_tm rows, 0: the balanced plan.  false: not launched (an
 // operand beyond the 32-bit buffer offsets, K % 16): the caller takes gemm.hip's kernel
 bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm);
+// float32 W [N][K] (row stride ld_src; N % 32 == 0, K % 8 == 0) -> the fragment order GemmArgs::b_frag32 names, N * K floats
+void launch_f32_fragments(const float* src, int64_t ld_src, float* dst, int N, int K, hipStream_t s);
 void launch_gemm_split(const GemmArgs& g, hipStream_t s);  // gemm_split.hip
 void launch_gemm_split_wd(const GemmArgs& g, hipStream_t s);  // gemm_split_wd.hip (g.b_tiled)
 // float32 W [N][K] (row stride ld_src, K % 32 == 0) -> tile-major split-f16 weights, (N rounded up to 32) * K floats

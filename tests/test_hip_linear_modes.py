@@ -134,7 +134,7 @@ def test_exact_mode_is_bit_identical_on_either_float32_gemm(L, sep, mix_stage):
     h.set_linear_mode("exact_f32")
     try:
         ref = None
-        for tune in (1, 0, 2, 3, 4, 5):   # 1: gemm.hip; 0: gemm_f32.hip; 2..5: gemm_f32.hip, tiles of at most 32 .. 128 rows
+        for tune in (1, 0, 2, 3, 4, 5, 6):   # 1: gemm.hip; 0: gemm_f32.hip; 2..5: tiles of at most 32 .. 128 rows; 6: weights through LDS
             h.set_tuning("f32_gemm", tune)
             wav = h.run(mix_stage[0], run_cfg)
             got = (_masks(h, L, h.get_plan().num_segments).copy(), h.read(L.BUF_HIDDEN).copy(), wav.copy())
