@@ -202,3 +202,81 @@ def test_trained_like_weights_vs_reference(L, sep_trained, mix60, golden, mc_sta
             assert err[k] < 3e-3, (mode, err)   # free-running: 22 differing winner sets move their bins' beamformers (hazard 1)
     finally:
         h.set_linear_mode("split_f16")
+
+
+def test_config2_nontrivial_decisions_from_the_estimators_own_masks(L, sep_mc, golden):
+    """On the golden weights configs[1] decides nothing: identity permutations, a gate that never closes.  Here the reference
+    ran with a separator-protocol wrapper that hands segment i's speaker masks back in a seeded order (all six occur) and
+    with the activity threshold inside the range the stitched masks' activity covers (gen_golden_r5c.py).  The same wrapper
+    around HipSeparator goes through the drop-in driver's protocol path (css.py:131,199): the masks are the HIP
+    estimator's, the shuffle is undone by the HIP permutation solver at every one of the 39 boundaries, the gate opens and
+    closes by itself -- permutations, both activity maps and the stitched masks against the reference, waveforms on the
+    reference's winner-take-all decisions <= 1e-4 over the whole meeting."""
+    import torch
+    CSS, SYN = pkg("css"), pkg("synth")
+    g = golden("e2e60_r5_decisions.npz")
+    n = int(g["mix_samples"])
+    mix = SYN.synth_meeting(n / 16000.0, 7, seed=int(g["mix_seed"]))[:, :n]
+    orders = g["orders"]
+    inner = sep_mc
+
+    class Shuffled:
+        """segment i's speaker masks in the order orders[i] (the reference side: gen_golden_r5c.ShuffledOutputs)"""
+        training = False
+
+        def __init__(self):
+            self.calls = 0
+
+        def to(self, dev):
+            return self
+
+        def cpu(self):
+            return self
+
+        def stft(self, s):
+            return inner.stft(s)
+
+        def istft(self, s):
+            return inner.istft(s)
+
+        def separate(self, stft_seg):
+            out = inner.separate(stft_seg)
+            o = [int(v) for v in orders[self.calls]]
+            self.calls += 1
+            return {"spk_masks": out["spk_masks"][..., o].contiguous(), "noise_masks": out["noise_masks"]}
+
+    cfg = CSS.CssCfg(activity_th=float(g["activity_th"]), show_progressbar=False)
+    sh = Shuffled()
+    wavs, side = CSS.separate_and_stitch(mix, sh, 16000, "cuda:0", cfg)
+    nseg = int(g["num_segments"])
+    assert sh.calls == nseg and len(wavs) == S and len(wavs[0]) == int(g["wav_len"])
+    shape = tuple(g["activity_shape"])
+    act_b = np.asarray(side["activity_b"].cpu() if hasattr(side["activity_b"], "cpu") else side["activity_b"]).astype(bool)
+    act_f = np.asarray(side["activity_final"].cpu() if hasattr(side["activity_final"], "cpu") else side["activity_final"]).astype(bool)[0]
+    ref_b, ref_f = unpack_bits(g["activity_b"], shape), unpack_bits(g["activity_final"], shape)
+    assert 0.2 < ref_b.mean() < 0.8 and (~ref_f).any()                      # the fixture's gate really works
+    assert np.array_equal(act_b, ref_b) and np.array_equal(act_f, ref_f)
+    stage = CSS._stage_separator(7, S, "cuda:0")
+    perms = stage.handle.read(L.BUF_PERMS)
+    assert [tuple(p) for p in perms[1:]] == [tuple(p) for p in g["pit_perm"]]
+    assert len({tuple(p) for p in perms[1:]}) == 6
+    ms = np.asarray(side["mask_stitched"].cpu() if hasattr(side["mask_stitched"], "cpu") else side["mask_stitched"])[0]   # [F, T, S]
+    assert np.abs(ms[::32, ::16] - g["mask_stitched"]).max() < 6e-6
+    # waveforms: the protocol path's masks sit in the stage handle; re-run everything behind them on the reference's decisions
+    h = stage.handle
+    wta = unpack2(g["wta_packed"], g["wta_shape"])
+    m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
+    flips = int(sum((np.argmax(m[:, :, i], axis=0) != wta[i]).sum() for i in range(nseg)))
+    TL = int(h.get_plan().mix_frames)
+    h.write(L.BUF_WTA_OVERRIDE, wta)
+    h.stage_mvdr(0, nseg); h.stage_pit_costs(0, nseg - 1); h.stage_pit_scan(); h.stage_stitch(0, TL); h.stage_istft(0, TL)
+    forced = h.read(L.BUF_WAV)
+    ferr = [rel_rms(forced[k, ::64], g["wav_dec64"][k]) for k in range(S)]
+    free_err = [rel_rms(np.asarray(wavs[k])[::64], g["wav_dec64"][k]) for k in range(S)]
+    _report("config2_nontrivial_decisions", {"permutations_non_identity": int((np.array(g["pit_perm"]) != np.arange(3)).any(axis=1).sum()),
+                                             "distinct_permutations": 6, "activity_b_set_fraction": float(ref_b.mean()),
+                                             "gate_closed_frames": int((~ref_f).sum()), "wta_flips": flips,
+                                             "waveform_rel_rms_on_the_reference_decisions": ferr, "waveform_rel_rms_free_running": free_err})
+    for k in range(S):
+        assert ferr[k] < 1e-4, ferr
+    assert flips <= 2
