@@ -459,7 +459,14 @@ def main():
         def rec_n(el, steps, note):
             return {"ms_per_step": round(1e3 * el / steps, 3), "value": round(seconds * steps / el, 2), "note": note}
 
+        # the headline is the reference's own arithmetic (float32 operands), as at N = 1; the library's default split-f16 mode
+        # is timed first and reported beside it (`split_f16`, `value_split_f16`)
         step("all"); barrier()   # initialisation, not a step: device buffers, communicator channels, index maps
+        el_split = timed_steps("all", args.steps, args.warmup)
+        assert torch.isfinite(out_host).all()
+        h.sync(); barrier()
+        h.set_linear_mode("exact_f32")
+        step("all"); barrier()
         el_all = timed_steps("all", args.steps, args.warmup)
         assert torch.isfinite(out_host).all()
         el_range = timed_steps("range", args.steps, max(args.warmup, 1))
@@ -545,6 +552,10 @@ def main():
             "collective": evidence,
             "roofline": roof,
             "clocks": gpu_clocks(),
+            "value_is_arithmetic": "CSS_LINEAR_EXACT_F32 (float32 operands): the reference's operand precision; the default split-f16 mode: `split_f16`",
+            "split_f16": {**rec_n(el_split, args.steps, "the same gather_all step in the library's default split-f16 mode (22-bit operands)"),
+                          "dtype": dtype_of["split_f16"]},
+            "value_split_f16": round(seconds * args.steps / el_split, 2), "dtype_split_f16": dtype_of["split_f16"],
         })
         if rank == 0:
             # the same meeting alone on this rank's GPU, host to host (what N = 1 would print for this workload)
@@ -553,6 +564,8 @@ def main():
             out_all = L.pinned_empty((S, n_out), np.float32)
             sep1 = SEP.HipSeparator(state, None, device=local_rank, max_batch_segments=args.max_batch)
             try:
+                ms1_split = fused_host_to_host(sep1.handle, pcm_all, out_all, 3, 1)
+                sep1.handle.set_linear_mode("exact_f32")     # like with like: the headline's arithmetic
                 ms1 = fused_host_to_host(sep1.handle, pcm_all, out_all, 3, 1)
             finally:
                 sep1.close()
@@ -560,6 +573,8 @@ def main():
                                                   "speedup": round(ms1 / ms_all, 3),
                                                   "speedup_gather_range": round(ms1 / (1e3 * el_range / args.steps), 3)}
             result["speedup_vs_1gpu_same_workload"] = round(ms1 / ms_all, 3)
+            result["split_f16"]["single_gpu_same_workload"] = {"ms_per_step": round(ms1_split, 3), "value": round(seconds / (ms1_split * 1e-3), 2),
+                                                                "speedup": round(ms1_split / (1e3 * el_split / args.steps), 3)}
         dist.barrier()
         if rank == 0:
             emit_record(result)
