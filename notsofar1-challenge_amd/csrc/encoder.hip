@@ -419,26 +419,31 @@ bool launch_conv_module(const float* x_in, float* x_out, const float* ln_w, cons
 // inside one wave, so a second resident wave is worth more than the third operand buffer it costs (NTB 3 -> 2 keeps the
 // register count at 234 for six key tiles; measured: attention 0.71 -> 0.67 ms per pass).  Eight key tiles (T up to 256)
 // would spill at that bound and keep one wave.
-template <int NJT, bool QKS, bool FRAG>
-__global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
+template <int NJT, bool QKS, bool FRAG, int W>
+__global__ __launch_bounds__(64 * W, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkf,
                                                          const float* __restrict__ pe,
                                                          float* __restrict__ ctx, int T, int D, int maxlen,
-                                                         int split_out, int heads) {
+                                                         int split_out, int heads, int n_items) {
     constexpr int DK = 64;
     // The position term lives in an LDS ring of three 32-offset tiles per query row (row stride 98 floats:
     // the skewed reads of 32 lanes land on addresses 3c + const (mod 32), i.e. 32 distinct banks).  A key tile
     // only ever needs three consecutive offset tiles, and the window slides down by one tile per key tile, so
     // the ring replaces the full [32][217] table (29 KB, 5 waves per CU) by 12.5 KB (register-limited 8 per CU).
     constexpr int LDR = 98;
-    __shared__ __attribute__((aligned(16))) float lds[32 * LDR];
+    // W waves per block, each an item of its own with its own ring; they never meet (no barrier).  The wave index goes through
+    // readfirstlane so that segment, head and every base address stay in scalar registers.
+    const int wv = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    __shared__ __attribute__((aligned(16))) float lds_all[W][32 * LDR];
+    float (&lds)[32 * LDR] = lds_all[wv];
     // Block order (round 4): workgroup L runs on XCD L % 8, and the NJT query tiles of one (segment, head) read the SAME
     // keys, values and position tiles.  Dealt round robin they sat in six different L2s, each of which fetched those
     // operands again: 579 MB per launch of 120 segments against 183 MB algorithmic, 6.2 TB/s -- the launch was bound by
     // the fabric (profiles/r04_pmc.md).  Every XCD now takes a contiguous range of the (segment, head, query tile) space,
     // so the tiles of a (segment, head) run back to back behind one L2.
-    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x);
+    const int item = css_xcd_item((int)blockIdx.x, (int)gridDim.x) * W + wv;
+    if (item >= n_items) return;
     const int qt = item % NJT, head = (item / NJT) % heads, seg = item / (NJT * heads);
-    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int ld = 3 * D;
     const float* qb = qkv + (int64_t)seg * T * ld + head * DK;
     const float* kb = qb + D;
@@ -465,30 +470,6 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
         CSS_ATT_LOAD8(q, qb + (int64_t)iq * ld)
     }
 
-    // Operand tiles are prefetched a whole tile (8 x 16 B per lane) ahead of the 32 MFMAs that consume
-    // them: the compiler's own schedule kept one load in flight (vmcnt(1) every 4 MFMAs) and exposed the
-    // L2 latency 8 times per tile.
-    // acc (zero on entry) = src . q over d_k = 64: 32 float32 MFMAs, or 12 f16 MFMAs on split operands
-    // (hi*hi into acc, hi*lo + lo*hi into a second accumulator that is folded in with 2^-11)
-#define CSS_ATT_MFMA32(acc, src)                                                                  \
-    if constexpr (QKS) {                                                                          \
-        f32x16 cor_ = {0};                                                                        \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
-            const f16x8 sh_ = __builtin_bit_cast(f16x8, src[2 * kk]), sl_ = __builtin_bit_cast(f16x8, src[2 * kk + 1]); \
-            const f16x8 qh_ = __builtin_bit_cast(f16x8, q[2 * kk]), ql_ = __builtin_bit_cast(f16x8, q[2 * kk + 1]);     \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, qh_, acc, 0, 0, 0);                 \
-            cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, ql_, cor_, 0, 0, 0);               \
-            cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl_, qh_, cor_, 0, 0, 0);               \
-        }                                                                                         \
-        acc += cor_ * SPLIT_LO_INV;                                                               \
-    } else {                                                                                      \
-        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                        \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].x, q[ch].x, acc, 0, 0, 0);         \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].y, q[ch].y, acc, 0, 0, 0);         \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].z, q[ch].z, acc, 0, 0, 0);         \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[ch].w, q[ch].w, acc, 0, 0, 0);         \
-        }                                                                                         \
-    }
     const int rel0 = i0 - (T - 1);
     // Offset tile rt of query tile qt holds the position rows 32 (qt + rt) - (T - 1) + c, c = 0..31: a function of
     // qt + rt only.  `pe` is the fragment-major table pe_fragments_kernel builds for this T: tile m, chunk ch, lane l
@@ -538,12 +519,42 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
     float4 tb[NTB][8];
     f32x16 S[NJT];
     int step = 0;
+    // One step = the 32 (12) MFMAs of the operand tile in tb[step % NTB], with the NEXT tile's eight 16-byte loads issued ONE PER
+    // FOUR MFMAs (two per three in split mode) instead of as a burst in front of them (round 5: a burst of vector-memory
+    // instructions stalls the in-order wave at the memory pipe's queue with its MFMAs behind it; tools/mfma_f32_chain.hip,
+    // DESIGN.md 3.2 -- float32 attention 173 -> 154 us per 120 segments from this alone).
+#define CSS_ATT_LOAD_CH(dst, s_, ch)                                                                       \
+    {                                                                                                      \
+        if (step_rt(s_) >= 0) dst[ch] = reinterpret_cast<const float4*>(pe_tile(step_rt(s_)))[(ch) * 64];  \
+        else if constexpr (FRAG) dst[ch] = qkt[(step_jt(s_) * 2 + 1) * 512 + (ch) * 64];                   \
+        else dst[ch] = *reinterpret_cast<const float4*>(k_row(step_jt(s_)) + (QKS ? (((ch) >> 2) * 32 + (((ch) >> 1) & 1) * 8 + ((ch) & 1) * 16) : 8 * (ch)) + 4 * h); \
+    }
 #define CSS_ATT_STEP(acc)                                                                                  \
     {                                                                                                      \
-        if (step + NTB - 1 < NS) { CSS_ATT_LOAD_STEP(tb[(step + NTB - 1) % NTB], min(step + NTB - 1, NS - 1)) } \
-        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the MFMAs (the scheduler sinks it) */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                       \
-        CSS_ATT_MFMA32(acc, tb[step % NTB])                                                                \
+        f32x16 cor_ = {0};                                                                                 \
+        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                                                 \
+            if (step + NTB - 1 < NS) { CSS_ATT_LOAD_CH(tb[(step + NTB - 1) % NTB], min(step + NTB - 1, NS - 1), ch) } \
+            const float4 s4_ = tb[step % NTB][ch];                                                         \
+            if constexpr (QKS) {   /* hi*hi into acc, hi*lo + lo*hi into a second accumulator folded in with 2^-11 */ \
+                if (ch & 1) {                                                                              \
+                    const f16x8 sh_ = __builtin_bit_cast(f16x8, tb[step % NTB][ch - 1]), sl_ = __builtin_bit_cast(f16x8, s4_); \
+                    const f16x8 qh_ = __builtin_bit_cast(f16x8, q[ch - 1]), ql_ = __builtin_bit_cast(f16x8, q[ch]);         \
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, qh_, acc, 0, 0, 0);                  \
+                    cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh_, ql_, cor_, 0, 0, 0);                \
+                    cor_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl_, qh_, cor_, 0, 0, 0);                \
+                    __builtin_amdgcn_sched_barrier(0);                                                     \
+                }                                                                                          \
+            } else {                                                                                       \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s4_.x, q[ch].x, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s4_.y, q[ch].y, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s4_.z, q[ch].z, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s4_.w, q[ch].w, acc, 0, 0, 0);                  \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+        }                                                                                                  \
+        if constexpr (QKS) acc += cor_ * SPLIT_LO_INV;                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         ++step;                                                                                            \
     }
@@ -616,7 +627,10 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
     }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    __syncthreads();  // all skewed reads done before the LDS region is reused for the output tile
+    // all skewed reads done before the LDS region is reused for the output tile: the region belongs to this wave alone and a
+    // wave's LDS instructions execute in order, so nothing is waited for -- the compiler must only keep the order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // ---- O^T[d][i] = sum_j v[j][d] * P[i][j]; the MFMA k index of half h at step (jt, r) is the key
     //      row this lane's S[jt][r] belongs to, so P feeds the B operand straight from registers.
@@ -713,43 +727,43 @@ __global__ __launch_bounds__(64, (NJT <= 7 ? 2 : 1)) void relpos_attn_kernel(con
 #undef CSS_ATT_VSTORE
 #undef CSS_ATT_TR
     } else {
-    // V groups (dt, jt) are consumed in order g = dt * NJT + jt and fetched two groups ahead (vb3[g % 3])
-    float vb3[3][16];
-    // uniform row pointer + one per-lane offset (scalar base addressing); only the last key tile clamps its rows
-    const unsigned vlane = (unsigned)(4 * h * ld + c);
-#define CSS_ATT_LOADV(dst, g_)                                                                \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
-        const int ju_ = ((g_) % NJT) * 32 + (r & 3) + 8 * (r >> 2);                           \
-        if ((g_) % NJT < NJT - 1) {                                                           \
-            const float* vrow_ = vb + (int64_t)ju_ * ld;                                      \
-            dst[r] = vrow_[vlane + (unsigned)(((g_) / NJT) * 32)];                            \
-        } else {                                                                              \
-            dst[r] = vb[(int64_t)min(ju_ + 4 * h, T - 1) * ld + ((g_) / NJT) * 32 + c];       \
-        }                                                                                     \
-    }
-    CSS_ATT_LOADV(vb3[0], 0)
-    CSS_ATT_LOADV(vb3[1], 1)
+    // Exact float32 P.V.  The value rows arrive as 8-BYTE loads: lane (c, h) takes features 2c, 2c + 1 of the key its S[jt][r]
+    // belongs to (half h: 4 rows further) -- a load instruction is two whole 256-byte rows of the head -- and feeds two
+    // accumulators, the even and the odd features.  Until round 5 these were 192 four-byte loads per wave, one per MFMA:
+    // beside a stream of these MFMAs a 4-byte load costs the matrix pipe ~60 cycles at that density, an 8-byte load ~8, a
+    // 16-byte load nothing (tools/mfma_f32_chain.hip), and two waves of a SIMD spent 46 k clocks in this phase for 24.6 k of
+    // MFMA issue.  Buffer loads: one per-lane offset, the row as a scalar offset, rows past T read zero (their probabilities
+    // are zero); the next key tile's 16 loads are issued one per MFMA pair.  Every output element still sums its keys in
+    // ascending order: bit for bit the results of the 4-byte form.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 vb2[2][16];
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, (int)(((int64_t)(T - 1) * ld + DK) * 4), 0x00020000);
+    const int vvo = (4 * h * ld + 2 * c) * 4, ldb = ld * 4;
+#define CSS_ATT_LOADV(jt_, r_) __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsv, vvo, ((jt_) * 32 + ((r_) & 3) + 8 * ((r_) >> 2)) * ldb, 0))
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        f32x16 o = {0};
+    for (int r = 0; r < 16; ++r) vb2[0][r] = CSS_ATT_LOADV(0, r);
+    f32x16 oe = {0}, oo = {0};
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const int g = dt * NJT + jt;
-            if (g + 2 < 2 * NJT) { CSS_ATT_LOADV(vb3[(g + 2) % 3], g + 2) }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vb3[g % 3][r], S[jt][r], o, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int jt = 0; jt < NJT; ++jt) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            lds[c * OLD + d] = o[r] * inv;
+            if (jt + 1 < NJT) vb2[(jt + 1) & 1][r] = CSS_ATT_LOADV(jt + 1, r);
+            oe = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2[jt & 1][r].x, S[jt][r], oe, 0, 0, 0);
+            oo = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2[jt & 1][r].y, S[jt][r], oo, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = 2 * ((r & 3) + 8 * (r >> 2) + 4 * h);
+        lds[c * OLD + d] = oe[r] * inv;
+        lds[c * OLD + d + 1] = oo[r] * inv;
     }
 #undef CSS_ATT_LOADV
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // 32 query rows x 64 features leave in 16-byte pieces (the store tail of a row-per-lane epilogue is bound by store
     // issue, not bandwidth): lane l takes features 4 (l % 16) .. + 3 of rows l / 16 + 4 k
     {
@@ -940,17 +954,22 @@ void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int sp
     hipLaunchKernelGGL(pe_fragments_kernel, dim3((ntiles * 8 * 64 + 255) / 256), dim3(256), 0, s, pe, frag, T, maxlen, ntiles, split);
 }
 
+#ifndef CSS_ATT_WAVES
+#define CSS_ATT_WAVES 1   // waves (items) per block of the tuned instantiations (NJT <= 7)
+#endif
 void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
                              int H, int maxlen, int qk_split, int split_out, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    const dim3 grid((unsigned)qtiles * (unsigned)H * (unsigned)nseg), block(64);
+    const int n_items = qtiles * H * nseg;
     // the tile schedule is static per instantiation, so NJT must be exactly ceil(T / 32)
-#define CSS_ATT_CASE(n)                                                                                                      \
-    case n:                                                                                                                  \
-        if (qk_split && qk_frag) hipLaunchKernelGGL((relpos_attn_kernel<n, true, true>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);  \
-        else if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);  \
-        else hipLaunchKernelGGL((relpos_attn_kernel<n, false, false>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H);          \
-        break;
+#define CSS_ATT_LAUNCH(n, w)                                                                                                 \
+    {                                                                                                                        \
+        const dim3 grid((unsigned)((n_items + (w) - 1) / (w))), block(64 * (w));                                              \
+        if (qk_split && qk_frag) hipLaunchKernelGGL((relpos_attn_kernel<n, true, true, w>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H, n_items);  \
+        else if (qk_split) hipLaunchKernelGGL((relpos_attn_kernel<n, true, false, w>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H, n_items);  \
+        else hipLaunchKernelGGL((relpos_attn_kernel<n, false, false, w>), grid, block, 0, s, qkv, qk_frag, pe_frag, ctx, T, D, maxlen, split_out, H, n_items);          \
+    }
+#define CSS_ATT_CASE(n) case n: CSS_ATT_LAUNCH(n, (n <= 7 ? CSS_ATT_WAVES : 1)) break;
     switch (qtiles) {
         CSS_ATT_CASE(1) CSS_ATT_CASE(2) CSS_ATT_CASE(3) CSS_ATT_CASE(4)
         CSS_ATT_CASE(5) CSS_ATT_CASE(6) CSS_ATT_CASE(7) CSS_ATT_CASE(8)
@@ -961,6 +980,7 @@ void launch_relpos_attention(const float* qkv, const float* qk_frag, const float
         default: break;  // longer segments are rejected at css_begin (segment_frames <= 512)
     }
 #undef CSS_ATT_CASE
+#undef CSS_ATT_LAUNCH
 }
 
 }  // namespace css
