@@ -67,6 +67,9 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
     const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
     const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
+#ifndef F32_SPREAD
+#define F32_SPREAD 1   // the next slab's global loads one per two MFMA groups of this slab instead of as a burst in front of it
+#endif
 #ifndef F32_DMA
 #define F32_DMA 0   // 1: global -> LDS by the DMA path (buffer_load ... lds), unpadded 64-byte LDS rows with an XOR swizzle
 #endif
@@ -87,6 +90,9 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(lds + (buf) * D_BUF + (128 + i * 64 + 16 * w) * 16), 16, dvoB, (k0) * 4 + i * passB, 0, 0);
 #define F32_LSTORE(buf) __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's pieces of the next slab have landed */
+#define F32_GLOAD1(k0, j)
+#undef F32_SPREAD
+#define F32_SPREAD 0
 #else
     f32x4 ra[NPA], rb[2];
     f32x4 wc[2], wn[2];   // BD: this slab's / the next slab's weight fragments (two chunks of 8 k each)
@@ -101,6 +107,16 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     } else {                                                                                                     \
         wn[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vw, ((k0) / 8) * 1024, 0)); \
         wn[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vw, ((k0) / 8 + 1) * 1024, 0)); \
+    }
+    // load j of the next slab (A passes first, then the two B / weight pieces): F32_SPREAD issues them one per two MFMA groups
+#define F32_GLOAD1(k0, j)                                                                                        \
+    {                                                                                                            \
+        if ((j) < NPA) {                                                                                         \
+            if ((j) + 1 < NPA || a1_on) ra[(j) < NPA ? (j) : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (k0) * 4 + (j) * passA, 0)); \
+        } else if ((j) < NPA + 2) {                                                                              \
+            if constexpr (!BD) rb[(j) - NPA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voB, (k0) * 4 + ((j) - NPA) * passB, 0)); \
+            else wn[(j) - NPA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vw, ((k0) / 8 + (j) - NPA) * 1024, 0)); \
+        }                                                                                                        \
     }
 #define F32_LSTORE(buf)                                                                                          \
     {                                                                                                            \
@@ -179,17 +195,21 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+                if (F32_SPREAD && spread_k0 >= 0 && !(e & 1)) { F32_GLOAD1(spread_k0, ch * 2 + (e >> 1)) __builtin_amdgcn_sched_barrier(0); } \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
                     if (F32_ABLATE & 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i][e]), "v"(b[e])); \
                     else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[e], acc[i], 0, 0, 0);          \
                 }                                                                                                \
+                if (F32_SPREAD && spread_k0 >= 0) __builtin_amdgcn_sched_barrier(0);                             \
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
     }
     // slabs 0 .. nk - 2: the next slab travels global -> registers under this slab's MFMAs, then registers -> LDS
+    int spread_k0 = -1;
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        if (!(F32_ABLATE & 2)) { F32_GLOAD((kt + 1) * F_BK, (kt + 1) & 1) }
+        if (F32_SPREAD) spread_k0 = (kt + 1) * F_BK;
+        else if (!(F32_ABLATE & 2)) { F32_GLOAD((kt + 1) * F_BK, (kt + 1) & 1) }
         __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the loads below the MFMAs, next to their LDS stores)
         F32_COMPUTE(kt & 1)
         if (!(F32_ABLATE & 2)) { F32_LSTORE((kt + 1) & 1) }
@@ -202,11 +222,13 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
         asm volatile("" : "+v"(lane_));
         prefetch(0, 0, lane_);
     }
+    spread_k0 = -1;
     F32_COMPUTE((nk - 1) & 1)
     __syncthreads();
 #undef F32_COMPUTE
 #undef F32_SLOT
 #undef F32_GLOAD
+#undef F32_GLOAD1
 #undef F32_LSTORE
 
     // ---- epilogue: every 32 x 32 tile takes a turn through the wave's LDS patch and leaves as 16-byte row pieces

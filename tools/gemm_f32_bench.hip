@@ -33,10 +33,10 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(float* out, int iters) {
 
 int main(int argc, char** argv) {
     struct Shape { int N, K; const char* name; int mode; };   // mode 1: bias + residual (alpha 0.5), 0: bias only
-    Shape shapes[] = {{512, 512, "attn-out", 1}, {1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 1824, "embed", 0}};
+    Shape shapes[] = {{512, 512, "attn-out", 1}, {2048, 512, "ffn-up", 0}, {512, 2048, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 1824, "embed", 0}};
     int Ms[] = {7440, 22320, 22320, 22320, 29760};
     const int layouts[] = {8, 1, 13, 12};   // round-4 kernel (8 waves) | gemm_f32.hip (tiles up to 128 rows) | up to 96 | up to 64
-    const size_t maxA = (size_t)29760 * 1824, maxB = (size_t)1536 * 1824, maxC = (size_t)29760 * 1536;
+    const size_t maxA = (size_t)29760 * 2048, maxB = (size_t)2048 * 1824, maxC = (size_t)29760 * 2048;
     float *A, *B, *C, *R;
     hipMalloc(&A, maxA * 4); hipMalloc(&B, maxB * 4 + 4096); hipMalloc(&C, maxC * 4); hipMalloc(&R, maxC * 4);
     std::vector<float> h(maxA);
@@ -88,9 +88,14 @@ int main(int argc, char** argv) {
             if (only && !strstr(sh.name, only)) continue;
             printf("%-9s M=%6d N=%5d K=%5d :", sh.name, M, sh.N, sh.K);
             int li = 0;
+            static float* Bf = nullptr;   // GEMM_BENCH_FRAG=1: the weights in fragment order for gemm_f32.hip (GemmArgs::b_frag32), as the library runs it
+            if (!Bf) hipMalloc(&Bf, maxB * 4 + 4096);
+            const bool fragw = getenv("GEMM_BENCH_FRAG") != nullptr;
+            if (fragw) launch_f32_fragments(B, sh.K, Bf, sh.N, sh.K, st);
             for (int layout : layouts) {
                 GemmArgs g{};
                 g.A = A; g.lda = sh.K; g.B = B; g.ldb = sh.K; g.C = C; g.ldc = sh.N; g.M = M; g.N = sh.N; g.K = sh.K; g.batch = 1; g.alpha = 1.f;
+                if (fragw && layout != 8) { g.B = Bf; g.b_frag32 = 1; }
                 g.bias = A;
                 if (sh.mode == 1) { g.residual = R; g.ldr = sh.N; g.alpha = 0.5f; }
                 g.layout = layout;
