@@ -268,7 +268,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=60.0, help="N = 1: length of the headline meeting (configs[1])")
     ap.add_argument("--long-seconds", type=float, default=1800.0, help="the strong-scaling meeting (configs[3])")
-    ap.add_argument("--max-batch", type=int, default=128, help="segments per batched mask-estimator pass")
+    ap.add_argument("--max-batch", type=int, default=256,
+                    help="segments per batched mask-estimator pass (the split-f16 mode keeps its batches to 128 segments of 3 s "
+                         "by itself: css_set_tuning split_batch_rows)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long", action="store_true", help="N = 1: skip the 30-min meeting")
@@ -607,7 +609,15 @@ def main():
     wav_dev = torch.empty((S, plan.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     group_limit = args.queue_group if args.queue_group else 8
-    sessions_per_batch = max(1, min(group_limit, args.max_batch // int(plan.num_segments), args.steps))
+    split_rows = dict(kv.partition("=")[::2] for kv in args.tune).get("split_batch_rows")
+    split_rows = int(split_rows) if split_rows is not None else 24576
+
+    def sessions_in_a_batch(mode):
+        """sessions whose segments share one estimator batch in this arithmetic mode (api.hip batch_cap)"""
+        cap = args.max_batch
+        if mode == "split_f16" and split_rows > 0:
+            cap = min(cap, max(1, split_rows // T))
+        return max(1, min(group_limit, cap // int(plan.num_segments), args.steps))
 
     def queued(k_steps):
         for k in range(k_steps):
@@ -684,6 +694,7 @@ def main():
         same sessions as synchronous calls and device-resident; the dominant kernel's roofline on the headline's own
         schedule (the shared estimator batch) and on one session alone."""
         h.set_linear_mode(mode)
+        sessions_per_batch = sessions_in_a_batch(mode)
         h.run(pcm_pin, run_cfg, out=out_pin)   # initialisation, not a step: the handle sizes its device buffers on first use
         queued(args.warmup)
         runs = [timed_region()]
@@ -721,12 +732,14 @@ def main():
         roof["sclk_mhz_after_the_profiled_passes"] = sclk_mhz()
         out["roofline"] = attach_traffic(roof, mode)
         out["kernel_family_ms"] = {k: round(v[0], 4) for k, v in ks1.items() if k != "event_pair_overhead"}
+        out["sessions_per_estimator_batch"] = sessions_per_batch
         out["_ks_single"] = ks1
         return out
 
     # ---- the headline: the reference's own arithmetic (float32 operands on the float32 matrix instruction) ...
     head = headline("exact_f32", args.min_seconds)
     ks_single = head.pop("_ks_single")
+    sessions_per_batch = head["sessions_per_estimator_batch"]
     result.update(head)
     result.update({
         "scaling": "strong",

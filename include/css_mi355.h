@@ -216,7 +216,11 @@ enum css_tuning {
                                            * tile heights balanced over the CUs; 1: the round-4 kernel (gemm.hip); 2..5: gemm_f32.hip with
                                            * every tile 32 / 64 / 96 / 128 rows; 6: gemm_f32.hip with the weights row-major through LDS
                                            * (the default reads them as register fragments).  Same bits whichever                  */
-    CSS_TUNE_COUNT = 10
+    CSS_TUNE_SPLIT_BATCH_ROWS = 10,       /* split-f16 mode: token rows (segments x frames) per estimator batch, whatever max_batch_segments
+                                           * allows (default 24576 = 128 segments of 3 s: beyond it a batch's activations leave the
+                                           * Infinity Cache between producer and consumer); 0: no such bound.  The exact float32 mode
+                                           * always batches up to max_batch_segments                                               */
+    CSS_TUNE_COUNT = 11
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

@@ -147,7 +147,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1, 0};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1, 0, 24576};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -525,6 +525,19 @@ MvdrArgs mvdr_args(css_ctx* h, int64_t lo, int nseg) {
     a.mask_floor = h->cfg.mask_floor;
     a.use_mvdr = (h->n_ch > 1 && h->cfg.mc_mvdr) ? 1 : 0;
     return a;
+}
+
+// Segments per estimator batch.  max_batch_segments is the caller's bound (and the size of the workspace); in the split-f16
+// mode a batch is also kept to CSS_TUNE_SPLIT_BATCH_ROWS token rows (24 576 = 128 segments of 3 s): its kernels are paced by
+// the memory system, and beyond that the activations of a batch no longer pass from producer to consumer inside the 256 MB
+// Infinity Cache (six 60 s sessions per batch instead of three: - 2 %, four: - 4.5 %).  The exact float32 mode is bound by
+// its matrix products and gains from every row a launch adds (six sessions per batch: + 2.7 %).  Results do not depend on
+// the batch (every kernel is batch invariant).
+static int64_t batch_cap(const css_ctx* h, int T) {
+    int64_t cap = h->max_batch;
+    const int rows = h->tune[CSS_TUNE_SPLIT_BATCH_ROWS];
+    if (h->split && rows > 0 && T > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(1, rows / T));
+    return cap;
 }
 
 // activation workspace of the mask estimator for batches of up to `nb` segments of T frames
@@ -1303,7 +1316,7 @@ int css_stage_masknet(css_handle_t h, int64_t seg_lo, int64_t seg_hi) {
     if (seg_lo < 0 || seg_hi > h->plan.num_segments || seg_lo > seg_hi) return fail(h, CSS_ERR_INVALID_ARG, "segment range out of bounds");
     HIPCHK(h, hipSetDevice(h->device));
     const int T = h->cfg.segment_frames;
-    const int64_t cap = batch_len(seg_hi - seg_lo, std::min<int64_t>(h->max_batch, h->plan.num_segments));
+    const int64_t cap = batch_len(seg_hi - seg_lo, std::min<int64_t>(batch_cap(h, T), h->plan.num_segments));
     MaskIo io{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, h->cfg.hop_frames, T, h->masks_v, h->mask_ld_v};
     io.PH = h->ph_valid ? (const float*)h->X.p + (int64_t)h->n_ch * 2 * h->d.num_bins * h->T_ld : nullptr;
     for (int64_t s0 = seg_lo; s0 < seg_hi; s0 += cap) {
@@ -1692,7 +1705,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     // ---- units, their frames and samples
     struct Unit { int64_t seg_lo; int n; int64_t f_lo, f_hi, s_lo, s_hi; hipEvent_t up, x, v, m; };   // pieces landed, planes, beamformer, costs
     std::vector<Unit> units;
-    const int64_t cap = batch_len(nseg, std::min<int64_t>(h->max_batch, nseg));
+    const int64_t cap = batch_len(nseg, std::min<int64_t>(batch_cap(h, h->cfg.segment_frames), nseg));
     int64_t f_prev = 0, s_prev = 0;
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         const int nb = (int)std::min<int64_t>(cap, nseg - s0);
@@ -2212,7 +2225,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     float* mapped = nullptr;
     if (h->mapped_key != wav_host) { h->mapped_key = wav_host; h->mapped_val = mapped_host(wav_host); }
     mapped = (float*)h->mapped_val;
-    const bool groupable = h->fft512 && h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= h->max_batch;
+    const bool groupable = h->fft512 && h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= batch_cap(h, cfg->segment_frames);
     if (!groupable) {
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
         RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
@@ -2227,7 +2240,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
                           std::memcmp(f.w.data(), cfg->w_first, T * sizeof(float)) == 0 &&
                           std::memcmp(f.w.data() + T, cfg->w_mid, T * sizeof(float)) == 0 &&
                           std::memcmp(f.w.data() + 2 * T, cfg->w_last, T * sizeof(float)) == 0;
-        if (!same || h->pending_segments + pl.num_segments > h->max_batch || (int)h->pending.size() >= h->group_limit)
+        if (!same || h->pending_segments + pl.num_segments > batch_cap(h, T) || (int)h->pending.size() >= h->group_limit)
             if ((rc = flush_pending(h)) != CSS_OK) return rc;
     }
     css_ctx::Pending q{pcm_host, n_samples, n_ch, *cfg, {}, wav_host, cap, mapped, pl.num_segments};
@@ -2245,7 +2258,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
     // no session of this length would still fit, or the group is full: off it goes -- nothing waits for a css_wait that
     // could already run
-    if (h->pending_segments + pl.num_segments > h->max_batch || (int)h->pending.size() >= h->group_limit) return flush_pending(h);
+    if (h->pending_segments + pl.num_segments > batch_cap(h, cfg->segment_frames) || (int)h->pending.size() >= h->group_limit) return flush_pending(h);
     return CSS_OK;
 }
 
@@ -2336,7 +2349,8 @@ int css_set_lanes(css_handle_t h, int lanes) {
 int css_get_lanes(css_handle_t h) { return h ? h->lanes : (int)CSS_ERR_INVALID_ARG; }
 
 int css_set_tuning(css_handle_t h, int which, int value) {
-    if (!h || which < 0 || which >= CSS_TUNE_COUNT || value < 0 || value > 16) return fail(h, CSS_ERR_INVALID_ARG, "unknown tuning option / value");
+    if (!h || which < 0 || which >= CSS_TUNE_COUNT || value < 0 || (value > 16 && which != CSS_TUNE_SPLIT_BATCH_ROWS))
+        return fail(h, CSS_ERR_INVALID_ARG, "unknown tuning option / value");
     h->tune[which] = value;
     return CSS_OK;
 }
