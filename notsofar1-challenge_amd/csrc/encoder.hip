@@ -954,8 +954,12 @@ void launch_pe_fragments(const float* pe, float* frag, int T, int maxlen, int sp
     hipLaunchKernelGGL(pe_fragments_kernel, dim3((ntiles * 8 * 64 + 255) / 256), dim3(256), 0, s, pe, frag, T, maxlen, ntiles, split);
 }
 
+// waves (items) per block of the tuned instantiations (NJT <= 7).  Four: consecutive items are the query tiles of one (segment,
+// head) and land on one CU together (A/B of 1 / 2 / 4 / 8 on one box, libraries differing in this constant only: the float32
+// step 8.82 / 8.75 / 8.80 / 8.93 ms, the split-f16 step 4.63 / 4.54 / 4.48 / 4.45-4.50 ms; eight make a 100 KB block that
+// shares its CU with nothing else)
 #ifndef CSS_ATT_WAVES
-#define CSS_ATT_WAVES 1   // waves (items) per block of the tuned instantiations (NJT <= 7)
+#define CSS_ATT_WAVES 4
 #endif
 void launch_relpos_attention(const float* qkv, const float* qk_frag, const float* pe_frag, float* ctx, int nseg, int T, int D,
                              int H, int maxlen, int qk_split, int split_out, hipStream_t s) {
