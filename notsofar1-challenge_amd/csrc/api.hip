@@ -553,8 +553,8 @@ int ensure_activations(css_ctx* h, int64_t nb, int T) {
     // q and k in the attention kernel's operand order (split mode); zeroed once: rows past T of a last tile are never written
     if ((rc = ensure(h, h->qkf, (size_t)qk_fragment_floats(nb, T, h->d.attention_heads) * sizeof(float), true)) != CSS_OK) return rc;
     if ((rc = ensure(h, h->ctxb, (size_t)Mb * D * sizeof(float))) != CSS_OK) return rc;
-    for (int l = 1; l < h->lanes; ++l) {   // lanes 1.. hold at most ceil(nb / lanes) segments
-        const int64_t M2 = ((nb + h->lanes - 1) / h->lanes) * T;
+    for (int l = 1; l < h->lanes; ++l) {   // lanes 1.. hold at most ceil(nb / 2) segments (lane_split may use fewer lanes than h->lanes)
+        const int64_t M2 = ((nb + 1) / 2) * T;
         if ((rc = ensure(h, h->lfeat[l], (size_t)M2 * h->Kp * sizeof(float), true)) != CSS_OK) return rc;
         if ((rc = ensure(h, h->lhx[l], (size_t)M2 * D * sizeof(float))) != CSS_OK) return rc;
         if ((rc = ensure(h, h->lhu[l], (size_t)M2 * D * sizeof(float))) != CSS_OK) return rc;
@@ -1242,9 +1242,15 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
 
 // How a batch of `nb` segments is cut into lanes: `nl` chains of `per` segments (the last one shorter).
 struct LaneSplit { int nl, per; };
-static LaneSplit lane_split(const css_ctx* h, int nb) {
-    if (h->lanes < 2 || h->profile_gemm || nb < 4 * h->lanes) return {1, nb};   // the per-launch profile needs one ordered stream
-    return {h->lanes, (nb + h->lanes - 1) / h->lanes};
+static LaneSplit lane_split(const css_ctx* h, int nb, int T) {
+    int nl = h->lanes;
+    // Exact float32: the pass is its matrix products, and those want rows per launch more than they want a second chain to
+    // fill their gaps -- a lane is worth it from ~14 000 token rows (75 segments of 3 s) per lane, and never a third.  One box,
+    // A/B: a 60 s meeting (40 segments) 11.05 ms on one lane, 11.8 on two, 12.4 on three; a shared batch of 128 segments
+    // 8.93 ms per session on one lane, 9.06 on two; of 256 segments 8.93 on one, 8.81 on two, 9.07 on three.
+    if (!h->split) nl = std::min(nl, std::min(2, std::max(1, (int)((int64_t)nb * T / 14000))));
+    if (nl < 2 || h->profile_gemm || nb < 4 * nl) return {1, nb};   // the per-launch profile needs one ordered stream
+    return {nl, (nb + nl - 1) / nl};
 }
 // A recording's segments [seg_lo, seg_hi) in batches of at most `cap`, equally long (9 x 128 + 57 becomes 10 x 121).
 static int64_t batch_len(int64_t n, int64_t cap) {
@@ -1269,7 +1275,7 @@ static int masknet_batch(css_ctx* h, const MaskIo& io, int64_t s0, int nb, const
                             sp, h->stream);
         h->pe_frag_T[sp] = io.T;
     }
-    const LaneSplit ls = lane_split(h, nb);
+    const LaneSplit ls = lane_split(h, nb, io.T);
     if (ls.nl == 1) {
         if ((rc = prep(s0, nb, h->stream)) != CSS_OK) return rc;
         if (before_head) {   // the mask head and what follows write buffers an earlier pass's tail may still read
@@ -1709,7 +1715,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     int64_t f_prev = 0, s_prev = 0;
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
         const int nb = (int)std::min<int64_t>(cap, nseg - s0);
-        const LaneSplit ls = lane_split(h, nb);
+        const LaneSplit ls = lane_split(h, nb, T);
         for (int l = 0; l < ls.nl; ++l) {
             const int lo = l * ls.per, cnt = std::min(ls.per, nb - lo);
             if (cnt <= 0) continue;
@@ -2101,7 +2107,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     hipStream_t ts = h->tail_stream;
     HIPCHK(h, hipStreamWaitEvent(ts, masks_ready, 0));
     if (mvdr_lanes) {   // (A/B: covariances / MVDR / costs dealt over the lanes' streams, the main stream waits for them)
-        const LaneSplit ls = lane_split(h, (int)total);
+        const LaneSplit ls = lane_split(h, (int)total, T);
         for (int l = 1; l < ls.nl && l < G; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l], masks_ready, 0));
         for (int j = 0; j < G; ++j) {
             Active act(h, j, G);

@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of the queue's schedule knobs (run on the GPU box): lanes of a shared batch, sessions per batch, in both arithmetic modes
+# A/B of the schedule knobs (run on the GPU box) in both arithmetic modes: lanes of one session's pass (css_run), of a shared batch, sessions per batch
 cd "$GRAFT_REPO_ROOT" || exit 1
-run() { python bench.py --no-cpu-baseline --no-long --min-seconds 3 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-40s f32 %.3f ms (%.0f x, frac %.3f, %d sessions / batch)   split %.3f ms (%d)' % ('$*', d['ms_per_step'], d['value'], d['roofline']['frac'], d['sessions_per_estimator_batch'], d['split_f16']['ms_per_step'], d['split_f16']['sessions_per_estimator_batch']))"; }
+run() { python bench.py --no-cpu-baseline --no-long --min-seconds 2 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['split_f16']; print('%-28s f32: queue %.3f ms, css_run %.3f ms, device-resident %.3f ms   split: queue %.3f, css_run %.3f, device-resident %.3f' % ('$*', d['ms_per_step'], d['synchronous_call']['ms_per_step'], d['device_resident']['ms_per_step'], s['ms_per_step'], s['synchronous_call']['ms_per_step'], s['device_resident']['ms_per_step']))"; }
 for rep in 1 2; do
 run
-run --max-batch 128
-run --tune split_batch_rows=0
-run --queue-group 3
+run --lanes 1
+run --lanes 2
+run --lanes 4
 done
