@@ -727,6 +727,7 @@ def main():
             out["roofline_single_session"] = roof_single
             out["kernel_family_ms_per_session_in_a_shared_batch"] = {k: round(v[0] / sessions_per_batch, 4) for k, v in ksq.items()
                                                                      if k != "event_pair_overhead"}
+            out["_ks_queue"] = {k: (v[0] / sessions_per_batch, v[1]) for k, v in ksq.items()}
         else:
             roof = roof_single
         roof["sclk_mhz_after_the_profiled_passes"] = sclk_mhz()
@@ -739,6 +740,7 @@ def main():
     # ---- the headline: the reference's own arithmetic (float32 operands on the float32 matrix instruction) ...
     head = headline("exact_f32", args.min_seconds)
     ks_single = head.pop("_ks_single")
+    ks_queue = head.pop("_ks_queue", None)
     sessions_per_batch = head["sessions_per_estimator_batch"]
     result.update(head)
     result.update({
@@ -771,6 +773,8 @@ def main():
         return rows
 
     result["roofline_hbm"] = hbm_table(hbm_kernel_bytes(plan, desc, T, hop, n), ks_single, hbm_kernel_bytes(plan, desc, T, hop, n, True))
+    if ks_queue:   # the same families inside the headline's queue: a session's bytes over its share of the group's launches
+        result["roofline_hbm_in_a_shared_batch"] = hbm_table(hbm_kernel_bytes(plan, desc, T, hop, n), ks_queue)
     result["roofline_hbm_bytes_are"] = ("SURVEY.md 8(d)'s compulsory bytes: operands the reference's own stages exchange (PCM, spectra, masks, "
                                         "features, covariances, weights, separated spectra, waveforms); planes the implementation adds for "
                                         "itself (the analysis transform's phase planes) are NOT counted")
@@ -783,7 +787,7 @@ def main():
 
     # ---- ... and the library's default, faster mode: same workload, same timing rules, its own roofline
     fast = headline("split_f16", min(args.min_seconds, 3.0))
-    fast.pop("_ks_single")
+    fast.pop("_ks_single"); fast.pop("_ks_queue", None)
     result["split_f16"] = fast
     result["value_split_f16"] = fast["value"]
     result["dtype_split_f16"] = fast["dtype"]

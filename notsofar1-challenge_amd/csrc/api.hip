@@ -2119,16 +2119,48 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         for (int j = 0; j < G; ++j)
             if (ls.nl > 1 && j % ls.nl) HIPCHK(h, hipStreamWaitEvent(h->stream, done[(size_t)j], 0));
     }
+    if (!mvdr_lanes) {
+        // Stage by stage over the group's sessions, so that the two stages that are chains per thread or per block -- the 7 x 7
+        // solves (one thread per system, ~20 us whatever the launch holds) and the stitching costs -- are ONE launch for the
+        // group instead of one per session (bit for bit the per-session launches' results: every system / boundary is computed
+        // by the same code on the same operands).
+        std::vector<MvdrArgs> ma((size_t)G), solve;
+        for (int j = 0; j < G; ++j) {
+            Active act(h, j, G);
+            ma[(size_t)j] = mvdr_args(h, 0, (int)h->plan.num_segments);
+            if (!ma[(size_t)j].use_mvdr || ma[(size_t)j].nseg <= 0) continue;
+            CSS_PROF(CSS_PROF_SCM, ts);
+            if (!launch_scm(ma[(size_t)j], ts)) return fail(h, CSS_ERR_HIP, "the covariance kernel's LDS could not be reserved");
+            solve.push_back(ma[(size_t)j]);
+        }
+        if (!solve.empty()) { CSS_PROF(CSS_PROF_MVDR_SOLVE, ts); launch_mvdr_solve_multi(solve.data(), (int)solve.size(), ts); }
+        std::vector<StitchArgs> sas((size_t)G);
+        std::vector<double*> scr((size_t)G), cst((size_t)G);
+        bool one_loss = true;
+        int loss0 = 0, input0 = 0;
+        for (int j = 0; j < G; ++j) {
+            Active act(h, j, G);
+            if (ma[(size_t)j].nseg > 0) {
+                CSS_PROF(CSS_PROF_BEAMFORM, ts);
+                launch_beamform(ma[(size_t)j], ts);
+                if (h->cfg.normalize_segment_power) launch_segment_power_norm(ma[(size_t)j], (double*)h->pnorm.p, ts);
+            }
+            sas[(size_t)j] = stitch_args(h); scr[(size_t)j] = (double*)h->pit_part.p; cst[(size_t)j] = (double*)h->costs.p;
+            if (j == 0) { loss0 = h->cfg.stitching_loss; input0 = h->cfg.stitching_input; }
+            else one_loss = one_loss && loss0 == h->cfg.stitching_loss && input0 == h->cfg.stitching_input;
+        }
+        if (one_loss) {
+            CSS_PROF(CSS_PROF_PIT, ts);
+            launch_pit_costs_multi(sas.data(), scr.data(), cst.data(), G, loss0, input0, ts);
+        } else {   // (sessions of one group with different stitching losses: their costs per session)
+            for (int j = 0; j < G; ++j) { Active act(h, j, G); pit_costs_on(h, 0, h->plan.num_segments - 1, ts); }
+        }
+    }
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         const css_ctx::Pending& q = grp[(size_t)j];
         const int64_t nseg = h->plan.num_segments, TL = h->plan.mix_frames;
-        if (mvdr_lanes) {
-            HIPCHK(h, hipStreamWaitEvent(ts, done[(size_t)j], 0));
-        } else {
-            if ((rc = mvdr_on(h, 0, nseg, ts)) != CSS_OK) return rc;
-            pit_costs_on(h, 0, nseg - 1, ts);
-        }
+        if (mvdr_lanes) HIPCHK(h, hipStreamWaitEvent(ts, done[(size_t)j], 0));
         pit_scan_on(h, 0, nseg - 1, ts);
         const StitchArgs sa = stitch_args(h);
         { CSS_PROF(CSS_PROF_OLA_MASKS, ts); launch_ola_masks(sa, 0, TL, ts); }

@@ -223,6 +223,9 @@ struct MvdrArgs {
 };
 bool launch_scm(const MvdrArgs& a, hipStream_t s);   // false: the LDS of a long-segment launch could not be reserved
 void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s);
+// the same for n sessions' argument sets in one launch (a queue group's sessions; each result is the per-session launch's)
+constexpr int MVDR_MULTI_MAX = 8;
+void launch_mvdr_solve_multi(const MvdrArgs* a, int n, hipStream_t s);
 void launch_beamform(const MvdrArgs& a, hipStream_t s);
 // optional power normalisation (css.py:233-247): scales sep of each segment in place
 void launch_segment_power_norm(const MvdrArgs& a, double* scratch, hipStream_t s);
@@ -249,6 +252,9 @@ struct StitchArgs {
 size_t pit_cost_scratch_bytes(int64_t n_boundaries);
 void launch_pit_costs(const StitchArgs& a, int loss, int input, int64_t b_lo, int64_t b_hi, double* scratch, double* costs,
                       hipStream_t s);
+// every boundary of n sessions (a queue group: same S) in one pair of launches; scratch[i] / costs[i] as above per session
+constexpr int PIT_MULTI_MAX = 8;
+void launch_pit_costs_multi(const StitchArgs* a, double* const* scratch, double* const* costs, int n, int loss, int input, hipStream_t s);
 // permutations of segments b_lo + 1 .. b_hi from the raw costs of boundaries [b_lo, b_hi), continuing from the
 // permutation of segment b_lo already in perms (b_lo == 0: the identity, written here)
 void launch_pit_scan(const double* costs, int64_t b_lo, int64_t b_hi, int S, int32_t* perms, hipStream_t s);

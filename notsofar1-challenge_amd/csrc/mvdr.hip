@@ -363,8 +363,7 @@ __device__ __forceinline__ cplx herm_at(const double* __restrict__ m, int r, int
     return {m[p], r < c ? m[p + 1] : -m[p + 1]};
 }
 
-__global__ __launch_bounds__(64) void mvdr_solve_kernel(MvdrArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void mvdr_solve_body(const MvdrArgs& a, const int64_t gid) {
     const int F = a.F, S = a.S, nm = S + 1;
     const int64_t total = (int64_t)a.nseg * S * F;
     if (gid >= total) return;
@@ -460,9 +459,24 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(MvdrArgs a) {
     }
 }
 
+__global__ __launch_bounds__(64) void mvdr_solve_kernel(MvdrArgs a) { mvdr_solve_body(a, (int64_t)blockIdx.x * 64 + threadIdx.x); }
+// The sessions of a queue group in ONE launch (blockIdx.y = session): a thread is a chain of ~20 us whatever the launch
+// holds, and a 60 s meeting's 30 840 systems are 482 waves for 1 024 SIMDs -- three or six sessions still fit one round.
+struct MvdrMulti { MvdrArgs a[MVDR_MULTI_MAX]; };
+__global__ __launch_bounds__(64) void mvdr_solve_multi_kernel(MvdrMulti m) { mvdr_solve_body(m.a[blockIdx.y], (int64_t)blockIdx.x * 64 + threadIdx.x); }
+
 void launch_mvdr_solve(const MvdrArgs& a, hipStream_t s) {
     const int64_t total = (int64_t)a.nseg * a.S * a.F;
     hipLaunchKernelGGL(mvdr_solve_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, a);
+}
+void launch_mvdr_solve_multi(const MvdrArgs* a, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += MVDR_MULTI_MAX) {
+        const int cnt = std::min(MVDR_MULTI_MAX, n - i0);
+        MvdrMulti m{};
+        int64_t most = 0;
+        for (int i = 0; i < cnt; ++i) { m.a[i] = a[i0 + i]; most = std::max<int64_t>(most, (int64_t)a[i0 + i].nseg * a[i0 + i].S * a[i0 + i].F); }
+        if (most > 0) hipLaunchKernelGGL(mvdr_solve_multi_kernel, dim3((unsigned)((most + 63) / 64), cnt), dim3(64), 0, s, m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

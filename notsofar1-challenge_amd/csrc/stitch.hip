@@ -57,11 +57,9 @@ __host__ __device__ inline int pit_chunks(int64_t num_segments) { return num_seg
 
 // One block per (boundary, frequency chunk) -> partial[b][chunk][16]; a second kernel adds the chunks in a fixed
 // order, so the cost is the same bit pattern whatever boundary range or GPU computes it.
-__global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, int input, int64_t b_lo,
-                                                       double* __restrict__ partial) {
+__device__ __forceinline__ void pit_cost_body(const StitchArgs& a, int loss, int input, const int64_t b, const int ch, const int nch,
+                                              double* __restrict__ partial) {
     __shared__ double red[4][SMAX * SMAX];
-    const int64_t b = b_lo + blockIdx.x;
-    const int ch = blockIdx.y, nch = (int)gridDim.y;
     const int S = a.S, F = a.F, T = a.T, ov = a.T - a.hop;
     const int f_lo = (int)((int64_t)F * ch / nch), f_hi = (int)((int64_t)F * (ch + 1) / nch);
     double acc[SMAX * SMAX];
@@ -105,9 +103,13 @@ __global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, i
     }
 }
 
-__global__ __launch_bounds__(64) void pit_cost_final_kernel(const double* __restrict__ partial, int S, int F, int ov,
-                                                            int64_t b_lo, int64_t b_hi, double* __restrict__ costs, int nch) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void pit_cost_kernel(StitchArgs a, int loss, int input, int64_t b_lo,
+                                                       double* __restrict__ partial) {
+    pit_cost_body(a, loss, input, b_lo + blockIdx.x, blockIdx.y, (int)gridDim.y, partial);
+}
+
+__device__ __forceinline__ void pit_cost_final_body(const double* __restrict__ partial, int S, int F, int ov, int64_t b_lo, int64_t b_hi,
+                                                    double* __restrict__ costs, int nch, const int64_t i) {
     const int ss = S * S;
     if (i >= (b_hi - b_lo) * ss) return;
     const int64_t b = b_lo + i / ss;
@@ -120,6 +122,42 @@ __global__ __launch_bounds__(64) void pit_cost_final_kernel(const double* __rest
 #pragma unroll
     for (int ch = 0; ch < PIT_CH; ++ch) v += part[ch];   // (the unused chunks add + 0.0 to a non-negative sum: the same bits)
     costs[b * ss + e] = v / ((double)F * ov);
+}
+
+__global__ __launch_bounds__(64) void pit_cost_final_kernel(const double* __restrict__ partial, int S, int F, int ov,
+                                                            int64_t b_lo, int64_t b_hi, double* __restrict__ costs, int nch) {
+    pit_cost_final_body(partial, S, F, ov, b_lo, b_hi, costs, nch, (int64_t)blockIdx.x * 64 + threadIdx.x);
+}
+
+// All boundaries of the sessions of a queue group in one pair of launches (blockIdx.z / .y = session); every session keeps
+// its own chunk count, scratch and cost matrix, so each cost is the bit pattern the per-session launch gives.
+struct PitMulti { StitchArgs a[PIT_MULTI_MAX]; double* partial[PIT_MULTI_MAX]; double* costs[PIT_MULTI_MAX]; int loss, input; };
+__global__ __launch_bounds__(256) void pit_cost_multi_kernel(PitMulti m) {
+    const StitchArgs& a = m.a[blockIdx.z];
+    const int nch = pit_chunks(a.num_segments);
+    if ((int64_t)blockIdx.x >= a.num_segments - 1 || (int)blockIdx.y >= nch) return;
+    pit_cost_body(a, m.loss, m.input, blockIdx.x, blockIdx.y, nch, m.partial[blockIdx.z]);
+}
+__global__ __launch_bounds__(64) void pit_cost_final_multi_kernel(PitMulti m) {
+    const StitchArgs& a = m.a[blockIdx.y];
+    pit_cost_final_body(m.partial[blockIdx.y], a.S, a.F, a.T - a.hop, 0, a.num_segments - 1, m.costs[blockIdx.y], pit_chunks(a.num_segments),
+                        (int64_t)blockIdx.x * 64 + threadIdx.x);
+}
+void launch_pit_costs_multi(const StitchArgs* a, double* const* scratch, double* const* costs, int n, int loss, int input, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += PIT_MULTI_MAX) {
+        const int cnt = std::min(PIT_MULTI_MAX, n - i0);
+        PitMulti m{};
+        m.loss = loss; m.input = input;
+        int64_t nb = 0; int nch = 0;
+        for (int i = 0; i < cnt; ++i) {
+            m.a[i] = a[i0 + i]; m.partial[i] = scratch[i0 + i]; m.costs[i] = costs[i0 + i];
+            nb = std::max<int64_t>(nb, a[i0 + i].num_segments - 1);
+            nch = std::max(nch, pit_chunks(a[i0 + i].num_segments));
+        }
+        if (nb <= 0) continue;
+        hipLaunchKernelGGL(pit_cost_multi_kernel, dim3((unsigned)nb, nch, cnt), dim3(256), 0, s, m);
+        hipLaunchKernelGGL(pit_cost_final_multi_kernel, dim3((unsigned)((nb * a[i0].S * a[i0].S + 63) / 64), cnt), dim3(64), 0, s, m);
+    }
 }
 
 size_t pit_cost_scratch_bytes(int64_t n_boundaries) { return (size_t)std::max<int64_t>(n_boundaries, 1) * PIT_CH * SMAX * SMAX * sizeof(double); }
