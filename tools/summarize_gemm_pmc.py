@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counter passes of tools/profile_r05.sh -> a table per arithmetic mode (mean per launch of the mode's Linear-layer kernel
-in the shared batch, M = 22 320) + <tag>_gemm_traffic[_exact_f32].json for bench.py's roofline.traffic (FETCH_SIZE doubled
+in the headline's shared batch: M = 44 640 rows in the exact float32 mode, 22 320 in the split-f16 mode) + <tag>_gemm_traffic[_exact_f32].json for bench.py's roofline.traffic (FETCH_SIZE doubled
 as MI355X_MICROARCH.md prescribes for gfx950's wide reads, + WRITE_SIZE; KiB units).
     python tools/summarize_gemm_pmc.py gpurun_out r05 > gpurun_out/r05_gemm_pmc.md"""
 import glob
@@ -12,7 +12,7 @@ import pandas as pd
 
 o, tag = sys.argv[1], sys.argv[2]
 KERNEL = {"exact_f32": "gemm_f32_kernel", "split_f16": "gemm_split_wd_kernel"}
-print("# Counters of the Linear-layer launches of the headline's shared batch (three queued 60 s sessions, M = 22 320 rows per launch)\n")
+print("# Counters of the Linear-layer launches of the headline's shared batch (queued 60 s sessions: six = M 44 640 rows per launch in the exact float32 mode, three = 22 320 in the split-f16 mode)\n")
 print("`rocprofv3 --kernel-trace --pmc <set> -- python tools/gemm_traffic.py <mode> 3`, one counter set per run; mean per launch of the")
 print("mode's kernel (exact_f32: css::gemm_f32_kernel incl. the mask head; split_f16: css::gemm_split_wd_kernel incl. the transposed head).\n")
 for mode, kern in KERNEL.items():
@@ -64,7 +64,7 @@ for mode, kern in KERNEL.items():
         traffic = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
         alg = meta.get("algorithmic_bytes_per_launch")
         print(f"HBM traffic per launch: FETCH_SIZE x 2 + WRITE_SIZE = {traffic / 1e6:.1f} MB" + (f" against {alg / 1e6:.1f} MB algorithmic = {traffic / alg:.2f} x" if alg else ""))
-        out = {"M22320": {"traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"],
+        out = {f"M{meta.get('rows_per_launch', 22320)}": {"traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"],
                           "launches": n, "mean_us_under_counters": dur}}
         suffix = "" if mode == "split_f16" else "_exact_f32"
         with open(f"{o}/{tag}_gemm_traffic{suffix}.json", "w") as fjs:
