@@ -193,7 +193,8 @@ int css_destroy(css_handle_t h);
 int css_get_stream(css_handle_t h, void** stream_out);
 /* Number of independent kernel chains ("lanes", 1..4, default 3) a batch of segments is cut into inside the mask
  * estimator (segments are independent through the network, css.py:182-250 carries no state between them).  Results do
- * not depend on it, bit for bit. */
+ * not depend on it, bit for bit.  It is an upper bound: the exact float32 mode takes a second lane only from ~14 000 token
+ * rows per lane and never a third (its matrix products want rows per launch more than a chain beside them). */
 int css_set_lanes(css_handle_t h, int lanes);
 int css_get_lanes(css_handle_t h);
 /* Schedule choices of the css_run* pipeline.  They change WHEN work is enqueued, never a result bit; the defaults are what
@@ -258,8 +259,9 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
 /* Queued sessions SHARE mask-estimator batches (round 4).  Segments are independent through the network
  * (css/css.py:182-250 carries no state between them) and every kernel of it is batch invariant, so css_run_enqueue merges
  * the segments of consecutive queued sessions -- same segmentation and windows, page-locked output -- into one
- * [segments x T, .] problem for as long as they fit max_batch_segments (three 60 s meetings at the bench's 128): every
- * Linear-layer launch then has M >= 22 k rows instead of 7 k.  Everything outside the estimator stays per session; each
+ * [segments x T, .] problem for as long as they fit max_batch_segments (exact float32 mode: six 60 s meetings at the bench's
+ * 256) and, in the split-f16 mode, CSS_TUNE_SPLIT_BATCH_ROWS token rows (three such meetings): every Linear-layer launch then
+ * has M >= 22 k rows instead of 7 k.  Everything outside the estimator stays per session; each
  * session's result is bit for bit its css_run result (tests/test_hip_schedules.py).  A session is accepted (arguments
  * checked, CSS_ERR_* returned at once) and may be held back until its group is full, a session that cannot join arrives, or
  * css_wait / any other call on the handle: LIFETIME -- pcm_host, wav_host AND the recording they describe must stay
