@@ -221,7 +221,9 @@ enum css_tuning {
                                            * allows (default 24576 = 128 segments of 3 s: beyond it a batch's activations leave the
                                            * Infinity Cache between producer and consumer); 0: no such bound.  The exact float32 mode
                                            * always batches up to max_batch_segments                                               */
-    CSS_TUNE_COUNT = 11
+    CSS_TUNE_F32_LANE_ROWS = 11,          /* exact float32 mode: token rows per lane from which a batch takes a second lane (default
+                                           * 14000 = 75 segments of 3 s; never a third); 1: as many lanes as css_set_lanes gives (tests) */
+    CSS_TUNE_COUNT = 12
 };
 int css_set_tuning(css_handle_t h, int which, int value);
 /* Page-locked host memory for PCM / waveform buffers: css_run* on such buffers moves the samples over PCIe by DMA,

@@ -335,7 +335,7 @@ class Handle:
     def set_tuning(self, which, value: int):
         """which: "tail_pieces" | "out_mapped" | "tail_per_unit" | "mvdr_on_lanes" | "pipeline_device" (include/css_mi355.h css_tuning)"""
         idx = {"tail_pieces": 0, "out_mapped": 1, "tail_per_unit": 2, "mvdr_on_lanes": 3, "pipeline_device": 4,
-               "group_lanes": 5, "group_transform_on_main": 6, "group_mvdr_on_lanes": 7, "group_out_dma": 8, "f32_gemm": 9, "split_batch_rows": 10}[which] if isinstance(which, str) else int(which)
+               "group_lanes": 5, "group_transform_on_main": 6, "group_mvdr_on_lanes": 7, "group_out_dma": 8, "f32_gemm": 9, "split_batch_rows": 10, "f32_lane_rows": 11}[which] if isinstance(which, str) else int(which)
         check(self.h, self.lib.css_set_tuning(self.h, idx, int(value)))
 
     def set_queue_group(self, max_sessions: int):

@@ -147,7 +147,7 @@ struct css_ctx : SessState {
     // by unit instead of waiting for the last segment of the recording
     hipStream_t tail_stream = nullptr;
     // schedule choices of that pipeline (css_set_tuning; defaults = what measured best, A/B on one box: tools/ab_tuning.py)
-    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1, 0, 24576};
+    int tune[CSS_TUNE_COUNT] = {1, 0, 0, 1, 0, 2, 1, 0, 1, 0, 24576, 14000};
     const void* mapped_key = nullptr;   // last page-locked output buffer looked up, and its device address
     void* mapped_val = nullptr;
     // css_upload_range: further pieces of the recording on their way over PCIe (copy stream); css_stage_stft_range makes
@@ -1248,7 +1248,8 @@ static LaneSplit lane_split(const css_ctx* h, int nb, int T) {
     // fill their gaps -- a lane is worth it from ~14 000 token rows (75 segments of 3 s) per lane, and never a third.  One box,
     // A/B: a 60 s meeting (40 segments) 11.05 ms on one lane, 11.8 on two, 12.4 on three; a shared batch of 128 segments
     // 8.93 ms per session on one lane, 9.06 on two; of 256 segments 8.93 on one, 8.81 on two, 9.07 on three.
-    if (!h->split) nl = std::min(nl, std::min(2, std::max(1, (int)((int64_t)nb * T / 14000))));
+    const int lane_rows = h->tune[CSS_TUNE_F32_LANE_ROWS];
+    if (!h->split && lane_rows > 1) nl = std::min(nl, std::min(2, std::max(1, (int)((int64_t)nb * T / lane_rows))));
     if (nl < 2 || h->profile_gemm || nb < 4 * nl) return {1, nb};   // the per-launch profile needs one ordered stream
     return {nl, (nb + nl - 1) / nl};
 }
@@ -2387,7 +2388,7 @@ int css_set_lanes(css_handle_t h, int lanes) {
 int css_get_lanes(css_handle_t h) { return h ? h->lanes : (int)CSS_ERR_INVALID_ARG; }
 
 int css_set_tuning(css_handle_t h, int which, int value) {
-    if (!h || which < 0 || which >= CSS_TUNE_COUNT || value < 0 || (value > 16 && which != CSS_TUNE_SPLIT_BATCH_ROWS))
+    if (!h || which < 0 || which >= CSS_TUNE_COUNT || value < 0 || (value > 16 && which != CSS_TUNE_SPLIT_BATCH_ROWS && which != CSS_TUNE_F32_LANE_ROWS))
         return fail(h, CSS_ERR_INVALID_ARG, "unknown tuning option / value");
     h->tune[which] = value;
     return CSS_OK;

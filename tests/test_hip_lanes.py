@@ -54,14 +54,47 @@ def test_lanes_in_exact_mode(mc_state, mix60):
     run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
     mix = np.ascontiguousarray(mix60[0, :int(15.0 * 16000)])
     out = []
-    for lanes in (1, 2):
+    for lanes, lane_rows in ((1, 14000), (2, 1), (3, 1), (2, 14000)):
         sep = _separator(mc_state, lanes, 64)
         try:
             sep.handle.set_linear_mode("exact_f32")
+            # (by default the exact mode takes a second lane only from 14 000 token rows per lane: 1 = as many as set_lanes gives)
+            sep.handle.set_tuning("f32_lane_rows", lane_rows)
             out.append(sep.handle.run(mix, run_cfg))
         finally:
             sep.close()
-    assert np.array_equal(out[0], out[1])
+    for o in out[1:]:
+        assert np.array_equal(out[0], o)
+
+
+def test_split_mode_batch_cap_is_bit_invariant(mc_state, mix60):
+    """css_set_tuning split_batch_rows (the split-f16 mode's own bound on an estimator batch) changes the batches, never a bit:
+    one pass and a queue of sessions, capped at 4 / 9 segments and uncapped."""
+    CSS, L = pkg("css"), pkg("_lib")
+    cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
+    run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
+    T = int(run_cfg.c.segment_frames)
+    mix = np.ascontiguousarray(mix60[0, :int(21.2 * 16000)])
+    pcm = L.pinned_copy(mix)
+    ref = None
+    for rows in (0, 4 * T, 9 * T + 5, 24576):
+        sep = _separator(mc_state, 2, 64)
+        try:
+            h = sep.handle
+            h.set_tuning("split_batch_rows", rows)
+            wav = h.run(mix, run_cfg)
+            n_out = int(h.get_plan().n_out)
+            outs = [L.pinned_empty((3, n_out), np.float32) for _ in range(3)]
+            for o in outs:
+                h.run_enqueue(pcm, run_cfg, o)
+            h.wait()
+        finally:
+            sep.close()
+        if ref is None:
+            ref = wav
+        assert np.array_equal(wav, ref), rows
+        for o in outs:
+            assert np.array_equal(o[:, :wav.shape[1]], ref), rows
 
 
 def test_long_meeting_multi_batch_is_lane_invariant(mc_state):
