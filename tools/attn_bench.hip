@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
 using namespace css;
@@ -24,9 +25,11 @@ int main(int argc, char** argv) {
         for (int i = 0; i < it; ++i) launch_relpos_attention(qkv, qks ? qkv : nullptr, pe, ctx, nseg, T, D, H, maxlen, qks, 0, st);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        std::vector<float> o(64); hipMemcpy(o.data(), ctx + 12345, 64 * 4, hipMemcpyDeviceToHost);
-        double cs = 0; for (int i = 0; i < 64; ++i) cs += o[i] * (i + 1);
-        printf("attention %d seg, %s scores: %.2f us per launch, checksum %.9g\n", nseg, qks ? "split-f16" : "float32", 1e3 * ms / it, cs);
+        std::vector<float> o(nc); hipMemcpy(o.data(), ctx, nc * 4, hipMemcpyDeviceToHost);
+        double cs = 0; for (int i = 0; i < 64; ++i) cs += o[12345 + i] * (i + 1);
+        unsigned long long hsh = 1469598103934665603ull;   // FNV-1a over every output bit: builds of the same arithmetic must agree
+        for (size_t i = 0; i < nc; ++i) { unsigned u; memcpy(&u, &o[i], 4); hsh = (hsh ^ u) * 1099511628211ull; }
+        printf("attention %d seg, %s scores: %.2f us per launch, checksum %.9g, hash of all outputs %016llx\n", nseg, qks ? "split-f16" : "float32", 1e3 * ms / it, cs, hsh);
     }
     return 0;
 }
