@@ -1,10 +1,10 @@
 // Micro-benchmark (tools only): v_mfma_f32_32x32x2_f32 issued as ONE dependent accumulator chain per wave (what the float32
 // attention does) against 2 / 4 independent chains, with 1, 2 or 4 waves per SIMD, with and without memory instructions
 // between the MFMAs -- what does a second resident wave buy, and what does a load cost?
-//   mode bit 0..1: chains per wave (1, 2, 4)
-//   mode bit 4   : one global_load_dwordx4 (1 KiB per wave, L1-resident) per 4 MFMAs, consumed 32 MFMAs later
-//   mode bit 5   : one ds_read_b32 + one ds_write_b32 per 2 MFMAs
+//   tools/bin/mfma_f32_chain [kinds|density|valu|chains]   (outputs: profiles/r05_mfma_f32_chain_*.txt, read in
+//   profiles/r05_attention_f32.md and DESIGN.md 3.1c / 3.2)
 #include <cstdio>
+#include <cstring>
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MF(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
@@ -157,17 +157,22 @@ void runm(float* o, const float* src, const char* name) {
         printf("%-44s %d waves/SIMD: %7.1f us, %.1f cycles per MFMA, %.1f per memory instruction beyond 73.0\n", name, wps, ms * 1e3, cyc, (cyc - 73.0) * 32 / NL);
     }
 }
-int main() {
-    {
-        float* o; hipMalloc(&o, 4);
-        float* src; hipMalloc(&src, 64 * 64 * 16); hipMemset(src, 0, 64 * 64 * 16);
+int main(int argc, char** argv) {
+    // sections: kinds (one memory instruction kind at a time, 8 / 16 per 32 MFMAs) | density (the P.V phase's load densities) |
+    // valu (VALU instructions behind the MFMAs) | chains (dependent chains, loads and LDS traffic per wave); default: all
+    const char* only = argc > 1 ? argv[1] : nullptr;
+    auto want = [&](const char* n) { return !only || !strcmp(only, n); };
+    float* o; hipMalloc(&o, 4);
+    float* src; hipMalloc(&src, 64 * 64 * 16); hipMemset(src, 0, 64 * 64 * 16);
+    if (want("density")) {
         runm<2, 32>(o, src, "32 global_load_dword / 32 MFMA");
         runm<3, 32>(o, src, "32 buffer_load_dword / 32 MFMA");
         runm<6, 16>(o, src, "16 buffer_load_dwordx2 / 32 MFMA");
         runm<1, 8>(o, src, "8 buffer_load_dwordx4 / 32 MFMA");
         runm<7, 32>(o, src, "4 DMA x4 + 32 ds_read_b32 / 32 MFMA");
         runm<3, 16>(o, src, "16 buffer_load_dword / 32 MFMA");
-        return 0;
+    }
+    if (want("kinds")) {
         runm<0, 8>(o, src, "8 global_load_dwordx4 / 32 MFMA");
         runm<1, 8>(o, src, "8 buffer_load_dwordx4 / 32 MFMA");
         runm<2, 8>(o, src, "8 global_load_dword / 32 MFMA");
@@ -177,24 +182,22 @@ int main() {
         runm<0, 16>(o, src, "16 global_load_dwordx4 / 32 MFMA");
         runm<1, 16>(o, src, "16 buffer_load_dwordx4 / 32 MFMA");
         runm<5, 16>(o, src, "16 ds_read_b128 / 32 MFMA");
-        return 0;
     }
-    {
-        float* o; hipMalloc(&o, 4);
-        float* src; hipMalloc(&src, 64 * 64 * 16); hipMemset(src, 0, 64 * 64 * 16);
+    if (want("valu")) {
         runv<0, 0>(o, src, "32 MFMA");
         runv<64, 0>(o, src, "32 MFMA then 64 VALU");
         runv<256, 0>(o, src, "32 MFMA then 256 VALU");
         runv<0, 32>(o, src, "32 MFMA + 32 dword loads");
     }
-    float* o; hipMalloc(&o, 4);
-    float4* src; hipMalloc(&src, 16 * 64 * 16); hipMemset(src, 0, 16 * 64 * 16);
-    run<1, false, false>(o, src, "1 chain");
-    run<2, false, false>(o, src, "2 chains");
-    run<4, false, false>(o, src, "4 chains");
-    run<1, true, false>(o, src, "1 chain + 8 loads / 32 MFMA");
-    run<4, true, false>(o, src, "4 chains + 8 loads / 32 MFMA");
-    run<1, false, true>(o, src, "1 chain + LDS rw / 2 MFMA");
-    run<1, true, true>(o, src, "1 chain + loads + LDS");
+    if (want("chains")) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        run<1, false, false>(o, s4, "1 chain");
+        run<2, false, false>(o, s4, "2 chains");
+        run<4, false, false>(o, s4, "4 chains");
+        run<1, true, false>(o, s4, "1 chain + 8 loads / 32 MFMA");
+        run<4, true, false>(o, s4, "4 chains + 8 loads / 32 MFMA");
+        run<1, false, true>(o, s4, "1 chain + LDS rw / 2 MFMA");
+        run<1, true, true>(o, s4, "1 chain + loads + LDS");
+    }
     return 0;
 }
