@@ -67,6 +67,12 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
     const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
     const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
+#ifndef F32_PROBE
+#define F32_PROBE 0   // tools: wave 0 of every block adds up where its slabs' clocks go (issue of the 32 MFMAs incl. operand reads | LDS stores incl. the wait for the global loads | barrier) into the census buffer
+#endif
+#ifndef F32_FAST_EPILOGUE
+#define F32_FAST_EPILOGUE 1   // 0: the general epilogue for every launch (A/B, tools)
+#endif
 #ifndef F32_SPREAD
 #define F32_SPREAD 1   // the next slab's global loads one per two MFMA groups of this slab instead of as a burst in front of it
 #endif
@@ -133,6 +139,9 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[i] = f32x16{0};
     const int nk = g.K / F_BK;
+#if F32_PROBE
+    const unsigned long long t_in_ = (w == 0) ? __builtin_readcyclecounter() : 0;
+#endif
     F32_GLOAD(0, 0)
     F32_LSTORE(0)
     if constexpr (BD) { wc[0] = wn[0]; wc[1] = wn[1]; }
@@ -156,7 +165,24 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const float alpha = g.alpha;
     const bool wide = (ldc % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                       (!has_res || ((ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0)));
+    // The fast form of the epilogue (round 5): a wave in its epilogue shares its SIMD with three waves issuing MFMAs back to
+    // back, and EVERY instruction it issues waits for a slot between them -- the slab-clock probe (tools, F32_PROBE) put the
+    // last slab + epilogue at 15 k clocks of a K = 512 tile's 100 k and at 37 k of 162 k for the QKV tiles, ~220 vector-ALU
+    // instructions per 32 x 32 tile (64-bit row addresses, row / column bound compares, exec masks, the bias_m select).  With
+    // the rows addressed through buffer descriptors -- one per-lane offset per tile, the row piece as a SCALAR offset, rows
+    // past M dropped (stores) or read as zero (residual) by the bounds check -- a row piece costs its arithmetic and nothing
+    // else.  Conditions: 16-byte pieces, whole 128-column panels, column bias or none, no sigmoid, operands below 2 GiB.
+    const bool fast = F32_FAST_EPILOGUE && wide && !bias_m && (N % BN == 0) && act != ACT_SIGMOID &&
+                      (int64_t)M * ldc * 4 < ((int64_t)1 << 31) && (!has_res || (int64_t)M * ldr * 4 < ((int64_t)1 << 31));
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, fast ? (int)((int64_t)M * ldc * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res), 0, (fast && has_res) ? (int)((int64_t)M * ldr * 4) : 0, 0x00020000);
     f32x4 rv[2][4];   // residual pieces of the tile being written and of the next one
+    auto prefetch_fast = [&](int i, int slot, int lane_) {
+        const int vo_ = (int)((((int64_t)m0 + (lane_ >> 3)) * ldr + n0 + 32 * w + (lane_ & 7) * 4) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            rv[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_, (int)((32 * i + 8 * j) * ldr * 4), 0));
+    };
     // (lane_ is `lane` behind a compiler barrier at the call sites below: the 64-bit row addresses of the epilogue must
     // not be formed before the K loop and carried through it -- the loop has no registers to spare)
     auto prefetch = [&](int i, int slot, int lane_) {
@@ -206,21 +232,57 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
         }                                                                                                        \
     }
     // slabs 0 .. nk - 2: the next slab travels global -> registers under this slab's MFMAs, then registers -> LDS
+#if F32_PROBE
+    const bool probe = w == 0 && g.narrow_epilogue == 77 && g.range_flag;
+    unsigned long long pc_ = 0, pl_ = 0, pb_ = 0, pt_ = 0;
+    const unsigned long long t_loop_ = probe ? __builtin_readcyclecounter() : 0;
+#define F32_CLK(var) if (probe) var = __builtin_readcyclecounter();
+#else
+#define F32_CLK(var)
+#endif
     int spread_k0 = -1;
     for (int kt = 0; kt + 1 < nk; ++kt) {
+#if F32_PROBE
+        unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
+#endif
+        F32_CLK(t0_)
         if (F32_SPREAD) spread_k0 = (kt + 1) * F_BK;
         else if (!(F32_ABLATE & 2)) { F32_GLOAD((kt + 1) * F_BK, (kt + 1) & 1) }
         __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the loads below the MFMAs, next to their LDS stores)
         F32_COMPUTE(kt & 1)
+        F32_CLK(t1_)
         if (!(F32_ABLATE & 2)) { F32_LSTORE((kt + 1) & 1) }
         if constexpr (BD) { wc[0] = wn[0]; wc[1] = wn[1]; }
+        F32_CLK(t2_)
         if (!(F32_ABLATE & 1)) __syncthreads();
+        F32_CLK(t3_)
+#if F32_PROBE
+        pc_ += t1_ - t0_; pl_ += t2_ - t1_; pb_ += t3_ - t2_; pt_ += 1;
+#endif
     }
+#if F32_PROBE
+    if (probe && lane == 0) {
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(g.range_flag) + 4096 + 4 * blockIdx.x;
+        atomicAdd(pr + 0, pc_); atomicAdd(pr + 1, pl_); atomicAdd(pr + 2, pb_); atomicAdd(pr + 3, pt_);
+        atomicAdd(pr + 4096 + 0, t_loop_ - t_in_);   // prologue: first slab global -> LDS, barrier
+        atomicAdd(pr + 4096 + 1, 1ull);              // tiles
+    }
+    const unsigned long long t_out_ = probe ? __builtin_readcyclecounter() : 0;
+#define F32_EPILOGUE_PROBE                                                                                       \
+    if (probe && lane == 0) {                                                                                    \
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(g.range_flag) + 4096 + 4 * blockIdx.x;    \
+        atomicAdd(pr + 4096 + 2, __builtin_readcyclecounter() - t_out_);   /* the last slab + the epilogue */     \
+    }
+#else
+#define F32_EPILOGUE_PROBE
+#endif
+#undef F32_CLK
     // the last slab: the first tile's epilogue operands travel under its MFMAs
     {
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
-        prefetch(0, 0, lane_);
+        if (fast) { if (has_res) prefetch_fast(0, 0, lane_); }
+        else prefetch(0, 0, lane_);
     }
     spread_k0 = -1;
     F32_COMPUTE((nk - 1) & 1)
@@ -242,6 +304,32 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     if (bias_n) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bn[e] = bias[n + e < N ? n + e : N - 1];
+    }
+    if (fast) {
+        const int voC = (int)((((int64_t)m0 + erow) * ldc + n) * 4);
+        const bool relu = act == ACT_RELU;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * F_PATCH_LD + c] = acc[i][r];
+            if (i + 1 < TM && has_res) prefetch_fast(i + 1, (i + 1) & 1, lane_e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (erow + 8 * j) * F_PATCH_LD + col4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e] + bn[e];                      // (epi_value's arithmetic with bm = 0: acc + bn is never -0, so the
+                    if (relu) t = fmaxf(t, 0.f);                 //  dropped "+ 0.f" changes no bit)
+                    if (has_res) t = rv[i & 1][j][e] + alpha * t;
+                    o[e] = t;
+                }
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voC, (int)((32 * i + 8 * j) * ldc * 4), 0);
+            }
+        }
+        F32_EPILOGUE_PROBE
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -268,6 +356,8 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
             }
         }
     }
+    F32_EPILOGUE_PROBE
+#undef F32_EPILOGUE_PROBE
 }
 
 }  // namespace

@@ -58,18 +58,30 @@ int main(int argc, char** argv) {
         }
     }
     {   // census of the persistent blocks of one launch: start / end (100 MHz wall clock), shader cycles, physical CU
-        unsigned long long* dbg; hipMalloc(&dbg, 1024 * 32);
+        unsigned long long* dbg; hipMalloc(&dbg, 1024 * 96);   // [1024][4] census + [1024][4] slab-clock sums of wave 0 (builds with -DF32_PROBE=1)
+        float* Bfc = nullptr; hipMalloc(&Bfc, maxB * 4 + 4096);
         struct Cs { int M, N, K; } cases[] = {{22320, 512, 1824}, {22320, 512, 512}, {22320, 1536, 512}, {7440, 512, 512}};
         for (auto& cs : cases) {
             GemmArgs g{};
             g.A = A; g.lda = cs.K; g.B = B; g.ldb = cs.K; g.C = C; g.ldc = cs.N; g.M = cs.M; g.N = cs.N; g.K = cs.K; g.batch = 1; g.alpha = 1.f;
             g.layout = 1; g.narrow_epilogue = 77; g.range_flag = (unsigned int*)dbg;
+            if (getenv("GEMM_BENCH_FRAG")) { launch_f32_fragments(B, cs.K, Bfc, cs.N, cs.K, st); g.B = Bfc; g.b_frag32 = 1; }
             for (int i = 0; i < 3; ++i) launch_gemm(g, st);
+            hipMemsetAsync(dbg + 4096, 0, 1024 * 64, st);
             hipEventRecord(e0, st);
             for (int i = 0; i < 10; ++i) launch_gemm(g, st);
             hipEventRecord(e1, st); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            std::vector<unsigned long long> d(4096); hipMemcpy(d.data(), dbg, 1024 * 32, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> d(12288); hipMemcpy(d.data(), dbg, 1024 * 96, hipMemcpyDeviceToHost);
+            {   // -DF32_PROBE=1: where wave 0's slab clocks went, summed over the blocks (10 launches)
+                double pc = 0, pl = 0, pb = 0, pn = 0;
+                for (int b = 0; b < 1024; ++b) { pc += d[4096 + 4 * b]; pl += d[4096 + 4 * b + 1]; pb += d[4096 + 4 * b + 2]; pn += d[4096 + 4 * b + 3]; }
+                double pp = 0, ptl = 0, pe = 0;
+                for (int b = 0; b < 1024; ++b) { pp += d[8192 + 4 * b]; ptl += d[8192 + 4 * b + 1]; pe += d[8192 + 4 * b + 2]; }
+                if (ptl > 0) printf("   per tile of wave 0 (mean over %.0f tiles): prologue %.0f clocks, %.1f counted slabs x %.0f, last slab + epilogue %.0f\n", ptl, pp / ptl, pn / ptl, (pc + pl + pb) / pn, pe / ptl);
+                if (pn > 0) printf("   slab clocks of wave 0 (mean over %.0f slabs): %.0f issuing the slab's MFMAs (operand reads, loads) + %.0f LDS stores (wait for the global loads) + %.0f barrier = %.0f per slab; 32 MFMAs x 4 waves per SIMD = 8192\n",
+                                   pn, pc / pn, pl / pn, pb / pn, (pc + pl + pb) / pn);
+            }
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int b = 0; b < 1024; ++b) { t0 = std::min(t0, d[4 * b]); t1 = std::max(t1, d[4 * b + 1]); }
             printf("census M=%d N=%d K=%d: %.1f us per launch (events), first start -> last end %.1f us\n", cs.M, cs.N, cs.K, 1e3 * ms / 10, (t1 - t0) / 100.0);
