@@ -171,7 +171,8 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     // instructions per 32 x 32 tile (64-bit row addresses, row / column bound compares, exec masks, the bias_m select).  With
     // the rows addressed through buffer descriptors -- one per-lane offset per tile, the row piece as a SCALAR offset, rows
     // past M dropped (stores) or read as zero (residual) by the bounds check -- a row piece costs its arithmetic and nothing
-    // else.  Conditions: 16-byte pieces, whole 128-column panels, column bias or none, no sigmoid, operands below 2 GiB.
+    // else.  (The scalar offset takes part in the bounds check on gfx950: tools/buffer_bounds_probe.hip, loads and stores.)
+    // Conditions: 16-byte pieces, whole 128-column panels, column bias or none, no sigmoid, operands below 2 GiB.
     const bool fast = F32_FAST_EPILOGUE && wide && !bias_m && (N % BN == 0) && act != ACT_SIGMOID &&
                       (int64_t)M * ldc * 4 < ((int64_t)1 << 31) && (!has_res || (int64_t)M * ldr * 4 < ((int64_t)1 << 31));
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, fast ? (int)((int64_t)M * ldc * 4) : 0, 0x00020000);

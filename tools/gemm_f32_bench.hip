@@ -123,9 +123,15 @@ int main(int argc, char** argv) {
                     static std::vector<float> ref, got;
                     const size_t ne = (size_t)M * sh.N;
                     got.resize(ne);
+                    if (getenv("GEMM_BENCH_NAN")) {   // which elements does one launch write?  (C poisoned first)
+                        hipMemsetAsync(C, 0xFF, maxC * 4, st); launch_gemm(g, st); hipStreamSynchronize(st);
+                        hipMemcpy(got.data(), C, ne * 4, hipMemcpyDeviceToHost);
+                        size_t nan = 0, firstbad = 0; for (size_t q = 0; q < ne; ++q) if (got[q] != got[q]) { if (!nan) firstbad = q; ++nan; }
+                        if (nan) printf(" UNWRITTEN %zu (first at row %zu col %zu) |", nan, firstbad / sh.N, firstbad % sh.N);
+                    }
                     hipMemcpy(got.data(), C, ne * 4, hipMemcpyDeviceToHost);
                     if (li == 0) ref = got;
-                    else if (memcmp(ref.data(), got.data(), ne * 4) != 0) { size_t bad = 0; for (size_t q = 0; q < ne; ++q) bad += memcmp(&ref[q], &got[q], 4) != 0; printf(" BITS DIFFER (%zu) |", bad); }
+                    else if (memcmp(ref.data(), got.data(), ne * 4) != 0) { size_t bad = 0; for (size_t q = 0; q < ne; ++q) { const bool d_ = memcmp(&ref[q], &got[q], 4) != 0; if (d_ && bad < 6 && getenv("GEMM_BENCH_NAN")) printf(" [r %zu c %zu: %.9g vs %.9g]", q / sh.N, q % sh.N, ref[q], got[q]); bad += d_; } printf(" BITS DIFFER (%zu) |", bad); }
                 }
                 const int mult = (sh.name[0] == 'e') ? 1 : (sh.name[0] == 'f' ? 36 : 18);
                 tot[mi][li++] += us * mult;
