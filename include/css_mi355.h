@@ -294,11 +294,13 @@ int css_set_profile(css_handle_t h, int enable);
 typedef struct CssKernelStat { char name[32]; float ms; int32_t launches; } CssKernelStat;
 int css_get_kernel_stats(css_handle_t h, CssKernelStat* out, int32_t cap, int32_t* count);
 /* Arithmetic of the Conformer's Linear layers (torch.nn.Linear in conformer.py:49-53,139-142,206,285):
- *   CSS_LINEAR_SPLIT_F16 (default)  operands carried as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product,
- *                                   float32 accumulation: float32-grade accuracy at 5.3x the float32 matrix rate;
- *   CSS_LINEAR_EXACT_F32            the exact float32 MFMA chain (bit-identical to an fmaf loop over k).
- * The default of a new handle is CSS_LINEAR_SPLIT_F16 (css_create falls to CSS_LINEAR_EXACT_F32 by itself when a weight of
- * the blob is outside the float16 range).  May be switched between runs; no environment variable is read. */
+ *   CSS_LINEAR_EXACT_F32 (default)  float32 operands on the float32 matrix instruction (bit-identical to an fmaf loop over
+ *                                   k): the reference's own operand precision (its Linear layers run in float32);
+ *   CSS_LINEAR_SPLIT_F16 (opt-in)   operands carried as hi + 2^-11 lo float16 pairs (22 significant bits), three f16 MFMAs per
+ *                                   product, float32 accumulation: ~2x the throughput, operands NARROWER than the reference's.
+ * A new handle is in CSS_LINEAR_EXACT_F32 (round 6; css_inference / separate_and_stitch / HipSeparator never leave it unless
+ * asked to: HipSeparator(..., linear_mode="split_f16")).  CSS_LINEAR_SPLIT_F16 is refused for a model with a weight outside the
+ * float16 range.  May be switched between runs; no environment variable is read. */
 enum css_linear_mode { CSS_LINEAR_SPLIT_F16 = 0, CSS_LINEAR_EXACT_F32 = 1 };
 int css_set_linear_mode(css_handle_t h, int mode);
 int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css_status */
@@ -306,7 +308,7 @@ int css_get_linear_mode(css_handle_t h);   /* css_linear_mode, or a negative css
  * inf / NaN, the GEMM that consumes it raises a device flag, and css_run* then repeats the whole pass on the exact
  * float32 kernels (enable = 1, the default) or returns CSS_ERR_RANGE (enable = 0).  css_range_status: passes repeated
  * so far, and whether the last pass was one.  css_check_range does the same test after a staged (css_stage_*) run.
- * A model with a WEIGHT outside the range starts in, and stays in, CSS_LINEAR_EXACT_F32. */
+ * A model with a WEIGHT outside the range cannot leave CSS_LINEAR_EXACT_F32 (css_set_linear_mode returns CSS_ERR_RANGE). */
 int css_set_range_fallback(css_handle_t h, int enable);
 int css_range_status(css_handle_t h, int64_t* fallbacks, int32_t* last_hit);
 int css_check_range(css_handle_t h);

@@ -418,7 +418,8 @@ class Handle:
         check(self.h, self.lib.css_set_profile(self.h, int(enable)))
 
     def set_linear_mode(self, mode):
-        """"split_f16" (default: float32-grade accuracy on the f16 matrix cores) or "exact_f32"."""
+        """"exact_f32" (the default of a new handle: float32 operands, the reference's own precision) or "split_f16" (opt-in:
+        22-bit operands as float16 pairs on the f16 matrix cores, ~2x the throughput)."""
         check(self.h, self.lib.css_set_linear_mode(self.h, {"split_f16": 0, "exact_f32": 1}[mode]))
 
     def set_feature_options(self, log_spectrogram=False, mvn_spectrogram=True, ipd_mean_normalize=True,

@@ -94,9 +94,10 @@ struct css_ctx : SessState {
     int Kp = 0, KIp = 0;
     float* blob = nullptr;
     Weights w;
-    // Linear-layer arithmetic: split-f16 operands on the f16 matrix cores (float32-grade accuracy, gemm_split.hip) or,
-    // after css_set_linear_mode(h, CSS_LINEAR_EXACT_F32), the exact float32 MFMA chain of gemm.hip.
-    bool split = true;
+    // Linear-layer arithmetic.  Default (round 6): float32 operands on the float32 matrix instruction (gemm_f32.hip) -- the
+    // reference's own operand precision (conformer.py:137-150 runs torch.nn.Linear in float32).  Opt-in, after
+    // css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16): split-f16 operands on the f16 matrix cores (22-bit operands, gemm_split*.hip).
+    bool split = false;
     bool split_ok = true;        // false: a weight lies outside the split-f16 operand range, CSS_LINEAR_SPLIT_F16 is refused
     float* wsplit = nullptr;     // split-f16 images of the Linear weights, at the blob's own offsets
     float* dft_split = nullptr;  // split-f16 image of dft_inv_t (row-major)
@@ -792,12 +793,14 @@ int css_create(const CssModelDesc* desc, const float* blob_host, int64_t blob_fl
         if (upload_analysis_matrix(h, CSS_WINDOW_HANN) != CSS_OK) return bail(CSS_ERR_HIP, "analysis matrix upload failed");
     }
     // a weight beyond the split-f16 operand range (never seen in a trained checkpoint; weights are O(1)): this model
-    // runs on the exact float32 kernels
-    for (int64_t i = 0; i < need && h->split; ++i)
-        if (!(std::fabs(blob_host[i]) <= 65504.f)) h->split = false;
-    h->split_ok = h->split;
-    if (h->split && make_split_weights(h) != CSS_OK) return bail(CSS_ERR_HIP, "");
-    if (!h->split && make_frag_weights(h) != CSS_OK) { (void)hipGetLastError(); if (h->wfrag) { hipFree(h->wfrag); h->wfrag = nullptr; } }
+    // runs on the exact float32 kernels only, css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16) is refused
+    h->split_ok = true;
+    for (int64_t i = 0; i < need && h->split_ok; ++i)
+        if (!(std::fabs(blob_host[i]) <= 65504.f)) h->split_ok = false;
+    // the handle starts in the reference's arithmetic (float32 operands); the split-f16 images of the weights are built by the
+    // first css_set_linear_mode(h, CSS_LINEAR_SPLIT_F16)
+    h->split = false;
+    if (make_frag_weights(h) != CSS_OK) { (void)hipGetLastError(); if (h->wfrag) { hipFree(h->wfrag); h->wfrag = nullptr; } }
     *out = h;
     return CSS_OK;
 }
@@ -1122,6 +1125,7 @@ static int masknet_lane(css_ctx* h, const MaskIo& io, int64_t s0, int nb, int la
         GemmArgs g = linear(A, lda, frag ? h->wfrag + (Wt - h->blob) : WS(Wt), lda, bias, C, ldc, M, n, k, act);
         g.split_in = sp; g.split_out = sp ? split_out : 0; g.b_tiled = sp; g.concurrent = concurrent ? 1 : 0;
         g.b_frag32 = frag ? 1 : 0;
+        g.B_rows = frag ? Wt : nullptr;   // (the row-major weight, should gemm_f32.hip decline the launch: launch_gemm)
         g.range_flag = sp ? h->range_flag_dev : nullptr;
         return g;
     };
@@ -2265,6 +2269,13 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
     if (h->mapped_key != wav_host) { h->mapped_key = wav_host; h->mapped_val = mapped_host(wav_host); }
     mapped = (float*)h->mapped_val;
     const bool groupable = h->fft512 && h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= batch_cap(h, cfg->segment_frames);
+    if (!h->fft512) {
+        // Frame sizes other than 512 / 256 run the plain stage sequence to its end inside the call (run_once): nothing stays
+        // queued, so css_wait would never look at the range word.  The pass therefore takes css_run's own rule here -- queued
+        // passes first, then this one, repeated in float32 or refused with CSS_ERR_RANGE when it left the split-f16 range.
+        RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap;
+        return run_impl(h, n_samples, n_ch, cfg, io);
+    }
     if (!groupable) {
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
         RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
@@ -2990,16 +3001,18 @@ int css_write_buffer(css_handle_t h, int which, const void* host, int64_t nbytes
     DevBuf* b;
     int64_t dims[4];
     int32_t el;
-    if (which == CSS_BUF_MASKS) {   // written masks are the session's own [(S+1) F][nseg T] matrix (also after a grouped pass)
-        h->masks_v = (float*)h->masks.p;
-        h->mask_ld_v = h->plan.num_segments * h->cfg.segment_frames;
-    }
     if (!host) return fail(h, CSS_ERR_INVALID_ARG, "null host pointer");
-    if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer");
+    // written masks are the session's own [(S+1) F][nseg T] matrix (also after a grouped pass, whose sessions see columns of the
+    // group's buffer): the size is checked against THAT shape, and the session's view moves only once the call can no longer fail
+    const float* keep_v = h->masks_v;
+    const int64_t keep_ld = h->mask_ld_v;
+    if (which == CSS_BUF_MASKS) { h->masks_v = (float*)h->masks.p; h->mask_ld_v = h->plan.num_segments * h->cfg.segment_frames; }
+    auto restore = [&](int code) { if (which == CSS_BUF_MASKS) { h->masks_v = const_cast<float*>(keep_v); h->mask_ld_v = keep_ld; } return code; };
+    if ((rc = buffer_info(h, which, &b, dims, &el)) != CSS_OK) return restore(rc == CSS_ERR_STATE ? rc : fail(h, CSS_ERR_INVALID_ARG, "unknown buffer"));
     const int64_t need = dims[0] * dims[1] * dims[2] * dims[3] * el;
-    if (nbytes != need) return fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes");
-    HIPCHK(h, hipSetDevice(h->device));
-    if ((rc = ensure(h, *b, (size_t)need)) != CSS_OK) return rc;
+    if (nbytes != need) return restore(fail(h, CSS_ERR_INVALID_ARG, "buffer size mismatch: expected " + std::to_string(need) + " bytes"));
+    if (hipSetDevice(h->device) != hipSuccess) return restore(fail(h, CSS_ERR_HIP, "hipSetDevice failed"));
+    if ((rc = ensure(h, *b, (size_t)need)) != CSS_OK) return restore(rc);
     if (which == CSS_BUF_MASKS) h->masks_v = (float*)h->masks.p;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(b->p, host, (size_t)need, hipMemcpyHostToDevice));
@@ -3079,6 +3092,11 @@ int css_comm_init(css_handle_t h, const void* id, int32_t nranks, int32_t rank) 
     if (h->comm) return fail(h, CSS_ERR_STATE, "the handle already has a communicator (css_comm_destroy first)");
     Rccl& r = rccl();
     if (!r.why.empty()) return fail(h, CSS_ERR_STATE, r.why);
+    {   // the entry points are bound by hand (ncclUniqueId = 128 opaque bytes by value, ncclInt8 = 0): the ABI of NCCL / RCCL 2.x
+        int v = 0;
+        if (r.GetVersion(&v) != 0 || v < 20000 || v >= 30000)
+            return fail(h, CSS_ERR_STATE, "librccl.so reports version code " + std::to_string(v) + ": the hand-bound ABI is that of RCCL 2.x");
+    }
     HIPCHK(h, hipSetDevice(h->device));
     ncclUniqueId_bytes uid;
     std::memcpy(&uid, id, CSS_COMM_ID_BYTES);

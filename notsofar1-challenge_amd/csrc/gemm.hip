@@ -19,6 +19,8 @@
 // one 16-byte LDS read.  A and B use the same permutation, so the dot product is unchanged.
 #include <cstdlib>
 
+#include <cstdio>
+
 #include "gemm_common.hpp"
 
 namespace css {
@@ -170,13 +172,25 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmArgs g, int tiles
 //   128 x 128, 4 waves (each 64x64)  fewest LDS reads per MFMA; ~3 % ahead once >= 4 blocks per CU are queued
 //    64 x 128, 4 waves (each 32x64)  twice the blocks: independent 4-wave blocks drift out of phase
 // GemmArgs::layout = 8 | 4 | 64 forces one (unit tests, tools/gemm_bench.hip); every layout gives the same bits.
-void launch_gemm(const GemmArgs& g, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
-    if (g.split_in) return g.b_tiled ? launch_gemm_split_wd(g, s) : launch_gemm_split(g, s);
+void launch_gemm(const GemmArgs& g_in, hipStream_t s) {
+    if (g_in.M <= 0 || g_in.N <= 0 || g_in.batch <= 0 || g_in.K <= 0) return;
+    if (g_in.split_in) return g_in.b_tiled ? launch_gemm_split_wd(g_in, s) : launch_gemm_split(g_in, s);
+    GemmArgs g = g_in;
     int forced = g.layout;
     if (forced == 0 || forced == 1 || (forced >= 11 && forced <= 14)) {
         if (launch_gemm_f32(g, s, forced >= 11 ? forced - 10 : 0)) return;
         forced = 0;   // (an operand of 2 GiB and more: the kernel below addresses with 64-bit pointers)
+    }
+    if (g.b_frag32) {
+        // the kernel below reads B row-major: a fragment-ordered weight image would be garbage without any error.  The caller
+        // hands the row-major weight along (GemmArgs::B_rows); without it the launch is refused loudly instead of computed wrongly.
+        if (!g.B_rows) {
+            fprintf(stderr, "css_mi355: launch_gemm: a fragment-ordered weight (b_frag32) reached the row-major kernel without B_rows "
+                            "(M %d N %d K %d layout %d): launch dropped\n", g.M, g.N, g.K, g.layout);
+            return;
+        }
+        g.B = g.B_rows;
+        g.b_frag32 = 0;
     }
     if (forced == 2) forced = 0;   // layout 2: this file's kernel with its own choice of tile (the round-4 default; A/B, tests)
     const int tiles_n = (g.N + BN - 1) / BN;

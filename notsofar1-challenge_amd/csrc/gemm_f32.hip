@@ -8,8 +8,11 @@
 //     while both store the next slab, meet and wait for their first operand reads (a slab takes 2 680 cycles for 2 048 of
 //     MFMA issue with one wave per SIMD, tools/gemm_f32_bench.hip).  Here a wave owns 32 COLUMNS of the block's tile and all
 //     of its rows (TM row tiles of 32: at most 64 accumulator registers), the slab is 16 deep and double buffered
-//     (2 x (128 + 128) rows x 20 floats = 40 960 B: exactly a quarter of the CU's 160 KB), and the kernel stays
-//     under 128 registers -- four waves per SIMD from four blocks that fill each other's bubbles.
+//     (2 x (128 + 128) rows x 20 floats = 40 960 B: exactly a quarter of the CU's 160 KB), and the kernel is held to
+//     128 registers (__launch_bounds__(256, 4)) -- four waves per SIMD from four blocks that fill each other's bubbles.
+//     The cap is met by SPILLING: hipcc -Rpass-analysis=kernel-resource-usage reports scratch for both instantiations
+//     (the epilogue's descriptors, offsets and the switch over four tile heights live across the K loop); the reloads sit
+//     outside the slab loop except for a handful in the TM = 3 / 4 tiles (DESIGN.md 3.1c records the counts per round).
 //   * PERSISTENT blocks over a balanced cut of the work.  The launch is 1 024 blocks (4 x 256 CUs); the output is
 //     counted in UNITS of 32 rows x 128 columns, the units of a launch are a line (batch entry, column panel, row unit --
 //     row unit fastest), every "virtual CU" takes an equal contiguous piece of that line and each of its four blocks a
@@ -67,6 +70,10 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const int voA = (int)(((int64_t)(m0 + srow) * g.lda + sk) * 4), voB = (int)(((int64_t)(n0 + srow) * g.ldb + sk) * 4);
     const int passA = (int)(64 * g.lda * 4), passB = (int)(64 * g.ldb * 4);
     const bool a1_on = (BM % 64 == 0) || srow < BM % 64;   // the last A pass of an odd TM covers 32 rows only
+#ifndef F32_TOOLS
+#define F32_TOOLS 0   // tools/gemm_f32_bench.hip only (-DF32_TOOLS=1): the block census below (GemmArgs::narrow_epilogue == 77 turns
+                      // GemmArgs::range_flag into a census buffer).  The library never compiles that path: range_flag there is ONE word.
+#endif
 #ifndef F32_PROBE
 #define F32_PROBE 0   // tools: wave 0 of every block adds up where its slabs' clocks go (issue of the 32 MFMAs incl. operand reads | LDS stores incl. the wait for the global loads | barrier) into the census buffer
 #endif
@@ -365,7 +372,12 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 
 // The work of a launch as a line of units (32 rows x 128 columns): index = (batch entry * tiles_n + column panel) * u + row
 // unit.  Virtual CU v of `ncu` takes [v U / ncu, (v + 1) U / ncu), its block j of four a quarter of that.
-struct F32Plan { int u, tiles_n, ncu, max_tm; int64_t U; unsigned long long* dbg; };   // dbg (tools): block 0 records shader / wall clocks
+struct F32Plan {
+    int u, tiles_n, ncu, max_tm; int64_t U;
+#if F32_TOOLS
+    unsigned long long* dbg;   // every block records where and when it ran (shader / wall clocks)
+#endif
+};
 
 template <bool BD>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p) {
@@ -378,11 +390,13 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p)
     // dispatcher puts on one CU; afterwards the tallest tile that fits
     int want = std::min(1 + (b + j) % 4, p.max_tm);
     bool first = true;
-    if (p.dbg && threadIdx.x == 0) {   // (tools: a census of the blocks -- where and when each ran)
+#if F32_TOOLS
+    if (p.dbg && threadIdx.x == 0) {   // (a census of the blocks -- where and when each ran)
         p.dbg[4 * b + 0] = wall_clock64();
         p.dbg[4 * b + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID | HW_ID
         p.dbg[4 * b + 3] = __builtin_readcyclecounter();
     }
+#endif
     while (pos < end) {
         const int64_t panel = pos / p.u;
         const int r = (int)(pos - panel * p.u);
@@ -402,13 +416,15 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g, F32Plan p)
         pos += tm;
         want = p.max_tm;
     }
+#if F32_TOOLS
     if (p.dbg && threadIdx.x == 0) { p.dbg[4 * b + 1] = wall_clock64(); p.dbg[4 * b + 3] = __builtin_readcyclecounter() - p.dbg[4 * b + 3]; }
+#endif
 }
 
 // false: an operand the 32-bit buffer offsets cannot address, or a K that is not a multiple of 16 (use gemm_kernel)
 bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return true;
-    if (g.K % F_BK) return false;
+    if (g.K <= 0 || g.K % F_BK) return false;
     const int64_t lim = (int64_t)1 << 31;
     if ((((int64_t)g.M + 128) * g.lda + g.K) * 4 >= lim || (((int64_t)g.N + 128) * g.ldb + g.K) * 4 >= lim) return false;
     if (g.b_frag32 && (g.N % 32 || g.K % 16 || g.batch != 1 || ((int64_t)g.N * g.K * 4 >= lim))) return false;
@@ -420,7 +436,9 @@ bool launch_gemm_f32(const GemmArgs& g, hipStream_t s, int forced_tm) {
     p.ncu = NCU;
     p.max_tm = (forced_tm >= 1 && forced_tm <= 4) ? forced_tm : 4;
     p.U = (int64_t)p.u * p.tiles_n * g.batch;
+#if F32_TOOLS
     p.dbg = g.narrow_epilogue == 77 ? reinterpret_cast<unsigned long long*>(g.range_flag) : nullptr;   // (tools/gemm_f32_bench.hip)
+#endif
     if (g.b_frag32) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(4 * NCU), dim3(256), 0, s, g, p);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(4 * NCU), dim3(256), 0, s, g, p);
     return true;

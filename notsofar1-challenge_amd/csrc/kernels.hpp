@@ -34,6 +34,8 @@ struct GemmArgs {
     int b_tiled;
     // b_frag32 (exact float32, gemm_f32.hip): B is a weight in float32 FRAGMENT order (launch_f32_fragments); batch 1, N % 32 == 0
     int b_frag32;
+    const float* B_rows;   // with b_frag32: the same weight row-major (ld = ldb), for the launches gemm_f32.hip does not take
+                           // (an operand of 2 GiB and more, a misaligned A): launch_gemm then runs gemm.hip's kernel on it
     // hint: other kernels run beside this launch (two-lane mask estimator): prefer 4-wave 64-row tiles, two of which
     // -- from different launches -- share a CU, over one 8-wave 128-row tile per CU
     int concurrent;

@@ -140,10 +140,16 @@ def _device_index(device) -> int:
 
 
 class HipSeparator:
-    """ConformerCssWrapper counterpart (conformer_wrapper.py:51-146) backed by the HIP library."""
+    """ConformerCssWrapper counterpart (conformer_wrapper.py:51-146) backed by the HIP library.
+
+    ``linear_mode``: arithmetic of the Conformer's Linear layers and matrix products.  "exact_f32" (default) keeps the
+    reference's own operand precision (torch.nn.Linear in float32, conformer.py:137-150) on the float32 matrix instruction;
+    "split_f16" is the explicit opt-in to 22-bit operands on the f16 matrix cores (about twice the throughput)."""
 
     def __init__(self, state_dict: Dict[str, "np.ndarray"], cfg: Optional[ConformerCssCfg] = None,
-                 device=0, max_batch_segments: int = 64, stream: int = 0):
+                 device=0, max_batch_segments: int = 64, stream: int = 0, linear_mode: str = "exact_f32"):
+        if linear_mode not in ("exact_f32", "split_f16"):
+            raise ValueError(f"linear_mode must be 'exact_f32' or 'split_f16', got {linear_mode!r}")
         st = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))
               for k, v in strip_module_prefix(state_dict).items()}
         desc = desc_from_cfg(cfg) if cfg is not None else None
@@ -153,6 +159,7 @@ class HipSeparator:
         self._device = _device_index(device)
         self._max_batch = max_batch_segments
         self._stream = stream
+        self._linear_mode = linear_mode
         self._handle: Optional[_lib.Handle] = None
 
     # ---- nn.Module surface used by the driver (css.py:88,141,176,178,318)
@@ -182,6 +189,8 @@ class HipSeparator:
     def handle(self) -> _lib.Handle:
         if self._handle is None:
             self._handle = _lib.Handle(self.desc, self.blob, self._device, self._stream, self._max_batch)
+            if self._linear_mode != self._handle.linear_mode():   # (a new handle is in "exact_f32")
+                self._handle.set_linear_mode(self._linear_mode)
             if self.cfg is not None and self.cfg.extractor_conf != _SUPPORTED_EXTRACTOR:
                 self._handle.set_feature_options(**feature_options(self.cfg.extractor_conf))
                 self._handle.set_analysis_window(self.cfg.extractor_conf.window)
@@ -283,9 +292,9 @@ def _cfg_from_yaml(path: str) -> Optional[ConformerCssCfg]:
     return build(ConformerCssCfg, node)
 
 
-def load_css_model(model_dir, device=0, max_batch_segments: int = 64):
+def load_css_model(model_dir, device=0, max_batch_segments: int = 64, linear_mode: str = "exact_f32"):
     """Counterpart of css/helpers.py:14-37: a directory with exactly one ``*.yaml`` (TrainCfg) and one
-    ``*.pt`` (``ckpt['model']``, keys prefixed ``module.``) -> (separator, cfg)."""
+    ``*.pt`` (``ckpt['model']``, keys prefixed ``module.``) -> (separator, cfg).  ``linear_mode``: see HipSeparator."""
     def one(suffix):
         files = glob.glob(os.path.join(str(model_dir), suffix))
         if len(files) == 0:
@@ -298,4 +307,4 @@ def load_css_model(model_dir, device=0, max_batch_segments: int = 64):
     torch = _torch()
     ckpt = torch.load(ckpt_path, map_location="cpu")
     state = {k[len("module."):]: v for k, v in ckpt["model"].items() if k.startswith("module.")}
-    return HipSeparator(state, cfg, device=device, max_batch_segments=max_batch_segments), cfg
+    return HipSeparator(state, cfg, device=device, max_batch_segments=max_batch_segments, linear_mode=linear_mode), cfg

@@ -27,6 +27,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# the two arithmetic modes of the Linear layers (include/css_mi355.h css_set_linear_mode); a new handle is in the first
+MODES = ("exact_f32", "split_f16")
+
+
 def pkg(name=""):
     return importlib.import_module("notsofar1_challenge_amd" + ("." + name if name else ""))
 
@@ -35,6 +39,21 @@ def rel_rms(a, b):
     a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(a) else np.float64)
     b = np.asarray(b, dtype=a.dtype)
     return float(np.sqrt(np.mean(np.abs(a - b) ** 2)) / (np.sqrt(np.mean(np.abs(b) ** 2)) + 1e-300))
+
+
+def reference_noise(g6):
+    """e2e60_r6_self.npz (tests/golden/gen_golden_r6.py: the reference on one input at 8 / 4 / 2 / 1 torch threads) -> (the reference's own mask noise between thread counts, its worst whole-meeting free-running self-distance per stream)"""
+    thr = [int(t) for t in g6["threads"][1:]]
+    mask_noise = max(float(g6[f"masks_max_abs_t{t}"]) for t in thr)
+    self_dist = np.max(np.stack([g6[f"wav_rel_rms_dec64_t{t}"] for t in thr]), axis=0)
+    return mask_noise, self_dist
+
+
+def margins_at(g6, points):
+    """top-2 margin of the REFERENCE's masks at (segment, bin, frame) points; inf where the point is not in the fixture's
+    near list (i.e. the reference's margin there is >= 2e-5)"""
+    near = {tuple(int(v) for v in p): float(m) for p, m in zip(g6["near_points"], g6["near_margin"])}
+    return [near.get(tuple(int(v) for v in p), float("inf")) for p in points]
 
 
 def window_starts(n, k=8, win=2048):

@@ -109,7 +109,7 @@ def test_hip_path_vs_reference(golden, mc_state, name):
             if sum(per_seg) == 0 and not cut:
                 for k in range(S):
                     assert rel_rms(free[k, :n_ok:64], g[name + "_wav_dec64"][k][:n_ok // 64 + (n_ok % 64 > 0)]) < 1e-4, (mode, k)
-        h.set_linear_mode("split_f16")
+        h.set_linear_mode("exact_f32")
         # the Python drop-in on the same separator object
         wavs, side = CSS.separate_and_stitch(mix, sep, 16000, "cuda:0", css_cfg)
         assert int(side["segment_frames"]) == Ts and np.array_equal(np.stack(wavs), h.run(pcm, run_cfg))

@@ -117,7 +117,7 @@ def test_recording_level_does_not_reach_the_operand_range(mc_state, mix60):
     to that factor: the features are level-invariant, the beamformer linear, and the one level-dependent split operand
     (the stitched spectra) is brought to unit peak by a power of two -- no overflow, no 11-bit regime, no fallback."""
     CSS = pkg("css")
-    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0)
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0, linear_mode="split_f16")   # (the mode with an operand range)
     try:
         h = sep.handle
         run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
@@ -141,12 +141,12 @@ def test_out_of_range_pass_is_repeated_in_float32(mc_state, mix60):
     st = dict(mc_state[0])
     key = pkg("weights").PREFIX + "conformer.encoders.0.feed_forward_in.net.0.weight"
     st[key] = np.asarray(st[key], np.float32) * np.float32(3e5)
-    sep = pkg("separator").HipSeparator(st, None, device=0)
+    sep = pkg("separator").HipSeparator(st, None, device=0, linear_mode="split_f16")
     try:
         h = sep.handle
         run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
         mix = np.ascontiguousarray(mix60[0, :12 * 16000])
-        assert h.range_status() == (0, False)
+        assert h.range_status() == (0, False) and h.linear_mode() == "split_f16"
         got = h.run(mix, run_cfg)
         assert h.range_status() == (1, True) and np.isfinite(got).all() and h.linear_mode() == "split_f16"
         h.set_linear_mode("exact_f32")

@@ -2,8 +2,9 @@
 
   * BASELINE.json configs[1] on a SCREENED recording -- no segment whose IPD features land on the other side of the atan2
     branch cut, a (nearly) full last segment -- so that the WHOLE meeting is compared with the reference: on the reference's
-    decisions on 100 % of the frames, free-running on every frame outside the one segment with a flipped decision, in both
-    arithmetic modes; every mask value within the survey's 5e-6;
+    decisions on 100 % of the frames, free-running on every frame outside the segments with a differing decision AND on the
+    whole meeting against what the reference's own rounding-level flips cost it (e2e60_r6_self.npz: the reference at 8 / 4 /
+    2 / 1 threads), in both arithmetic modes; every mask value within the survey's 5e-6;
   * a state dict that behaves like a trained model (peaky attention, saturated masks with exact winner-take-all ties, a
     feed-forward operand at ~1e3) through the reference, both modes held to it.
 
@@ -11,7 +12,7 @@ Needs an MI355X."""
 import numpy as np
 import pytest
 
-from conftest import pkg, rel_rms, take_windows
+from conftest import margins_at, pkg, reference_noise, rel_rms, take_windows
 from test_hip_golden_r2 import staged_run
 from test_hip_long import _report
 from test_oracle_golden_r2 import unpack2, unpack_bits
@@ -19,7 +20,7 @@ from test_oracle_golden_r2 import unpack2, unpack_bits
 pytestmark = pytest.mark.gpu
 
 F, S, T = 257, 3, 186
-MODES = ("split_f16", "exact_f32")
+MODES = ("exact_f32", "split_f16")
 
 
 @pytest.fixture(scope="module")
@@ -93,15 +94,23 @@ def test_config2_screened_60s_whole_meeting_vs_reference(L, sep_mc, golden, mode
             "waveform_rel_rms_free_running_windows": win_err,
             "segment_masks_max_abs": float(md.max()), "stitched_masks_max_abs": float(ms.max()),
             "segment_masks_within_5e-6": round(float((md <= 5e-6).mean()), 6), "stitched_masks_within_5e-6": round(float((ms <= 5e-6).mean()), 6)})
-        assert md.max() < 6e-6 and ms.max() < 6e-6, (md.max(), ms.max())      # SURVEY.md 8(d)'s 5e-6 bar: measured 4.6e-6 / 4.4e-6
+        assert md.max() < 5e-6 and ms.max() < 5e-6, (md.max(), ms.max())      # SURVEY.md 8(d)'s bar as it stands (measured 4.6e-6 / 4.4e-6)
         for k in range(S):
             assert forced_err[k] < 1e-4, (mode, k, forced_err)
-        # free-running: one (split_f16) or two (exact_f32) winner-take-all decisions of 1.9 million differ -- a rounding-level
-        # flip in segment 4, an exact tie of two of OUR masks in segment 32 (60 - 90 of the reference's decisions have a top-2
-        # margin below 1e-5 in every recording tried: twelve seeds, none without a difference, hazard 1) -- and a differing
-        # decision re-solves its bin's beamformers for its whole segment: the frames of those segments are compared on the
-        # reference's decisions above, every other frame free-running
-        assert sum(per_seg) <= 2, per_seg
+        # free-running: one (split_f16) or two (exact_f32) winner-take-all decisions of 1.9 million differ -- segment 4, bin 132,
+        # frame 145 and (exact_f32) an exact tie of two of OUR masks at segment 32, bin 41, frame 20.  Round 6 looked at why
+        # (tests/golden/gen_golden_r6.py, e2e60_r6_self.npz): the REFERENCE's own top-2 margins there are 3.6e-7 and 4.2e-7,
+        # its masks move by 2.1e-6 between its own thread counts, at the first point its 2-thread run ties EXACTLY, its
+        # 8-thread winner there is not the float64 network's, and that one flip costs the reference 1.0e-4 whole-meeting
+        # against itself.  So: a differing decision is accepted only where the reference's margin is inside twice its own mask
+        # noise, and the whole-meeting bar is 1e-4 plus what the reference's own flip costs per differing decision.  A
+        # differing decision re-solves its bin's beamformers for its whole segment: the frames of those segments are compared
+        # on the reference's decisions above, every other frame free-running at 1e-4.
+        g6 = golden("e2e60_r6_self.npz")
+        mask_noise, self_dist = reference_noise(g6)
+        differ = np.argwhere(np.moveaxis(np.any(ours_win != ref_win, axis=0), 1, 0))     # (segment, bin, frame)
+        mg = margins_at(g6, differ) if int(g6["mix_seed"]) == int(g["mix_seed"]) else []
+        assert sum(per_seg) <= 2 and all(x <= 2 * mask_noise for x in mg), (per_seg, differ.tolist(), mg)
         clean = np.ones(TL, bool)
         for i, nflip in enumerate(per_seg):
             if nflip:
@@ -109,12 +118,16 @@ def test_config2_screened_60s_whole_meeting_vs_reference(L, sep_mc, golden, mode
         idx = np.flatnonzero(np.repeat(clean, 4))            # wav_dec64 holds four samples per frame
         idx = idx[idx < g["wav_dec64"].shape[1]]
         clean_err = [rel_rms(free[k, ::64][idx], g["wav_dec64"][k][idx]) for k in range(S)]
+        bar = [1e-4 + len(differ) * float(self_dist[k]) for k in range(S)]
         _report(f"config2_screened_60s_{mode}_free_running", {"fraction_of_frames_outside_flipped_segments": round(float(clean.mean()), 4),
-                                                              "waveform_rel_rms_there": clean_err, "waveform_rel_rms_whole_meeting": free_err})
+                                                              "waveform_rel_rms_there": clean_err, "waveform_rel_rms_whole_meeting": free_err,
+                                                              "whole_meeting_bar": bar, "winner_sets_that_differ_at": differ.tolist(),
+                                                              "reference_top2_margin_there": mg, "reference_mask_noise": mask_noise,
+                                                              "reference_free_running_self_distance": [float(x) for x in self_dist]})
         for k in range(S):
-            assert clean_err[k] < 1e-4 and free_err[k] < 5e-4, (mode, k, clean_err, free_err)
+            assert clean_err[k] < 1e-4 and free_err[k] < bar[k], (mode, k, clean_err, free_err, bar)
     finally:
-        h.set_linear_mode("split_f16")
+        h.set_linear_mode("exact_f32")
 
 
 @pytest.fixture(scope="module")
@@ -201,7 +214,7 @@ def test_trained_like_weights_vs_reference(L, sep_trained, mix60, golden, mc_sta
             assert ferr[k] < 1e-4, (mode, ferr)
             assert err[k] < 3e-3, (mode, err)   # free-running: 22 differing winner sets move their bins' beamformers (hazard 1)
     finally:
-        h.set_linear_mode("split_f16")
+        h.set_linear_mode("exact_f32")
 
 
 def test_config2_nontrivial_decisions_from_the_estimators_own_masks(L, sep_mc, golden):

@@ -5,20 +5,23 @@ import os
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import MODES, pkg
 
 pytestmark = pytest.mark.gpu
 
 
-def _separator(mc_state, lanes, max_batch):
-    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=max_batch)
+def _separator(mc_state, lanes, max_batch, mode="exact_f32"):
+    sep = pkg("separator").HipSeparator(mc_state[0], None, device=0, max_batch_segments=max_batch, linear_mode=mode)
     sep.handle.set_lanes(lanes)
-    assert sep.handle.lanes() == lanes
+    assert sep.handle.lanes() == lanes and sep.handle.linear_mode() == mode
+    if mode == "exact_f32":   # (by default the exact mode takes a second lane only from 14 000 token rows per lane: 1 = as many as set_lanes gives)
+        sep.handle.set_tuning("f32_lane_rows", 1)
     return sep
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("seconds", [15.0, 21.2])     # 9 and 13 segments (plus a ragged last one)
-def test_lanes_and_batching_are_bit_invariant(mc_state, mix60, seconds):
+def test_lanes_and_batching_are_bit_invariant(mc_state, mix60, seconds, mode):
     if pkg("_lib").load().css_device_count() < 1:
         pytest.fail("no HIP device visible")
     CSS, L = pkg("css"), pkg("_lib")
@@ -27,7 +30,7 @@ def test_lanes_and_batching_are_bit_invariant(mc_state, mix60, seconds):
     mix = np.ascontiguousarray(mix60[0, :int(seconds * 16000)])
     ref = None
     for lanes, mb in [(1, 64), (2, 64), (3, 64), (2, 6), (2, 7), (4, 5), (2, 12)]:
-        sep = _separator(mc_state, lanes, mb)
+        sep = _separator(mc_state, lanes, mb, mode)
         try:
             h = sep.handle
             wav = h.run(mix, run_cfg)
@@ -78,7 +81,7 @@ def test_split_mode_batch_cap_is_bit_invariant(mc_state, mix60):
     pcm = L.pinned_copy(mix)
     ref = None
     for rows in (0, 4 * T, 9 * T + 5, 24576):
-        sep = _separator(mc_state, 2, 64)
+        sep = _separator(mc_state, 2, 64, "split_f16")
         try:
             h = sep.handle
             h.set_tuning("split_batch_rows", rows)

@@ -1,11 +1,11 @@
 """The two arithmetic modes of the Conformer's Linear layers (include/css_mi355.h css_set_linear_mode):
 
-  split_f16 (default)  operands as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product, float32 accumulation
-  exact_f32            the exact float32 MFMA chain
+  exact_f32 (default)  float32 operands on the float32 matrix instruction: the reference's own operand precision
+  split_f16 (opt-in)   operands as hi + 2^-11 lo float16 pairs, three f16 MFMAs per product, float32 accumulation
 
 Both must meet the SAME parity bars against the oracle and the reference fixtures (the rest of the `-m gpu` suite
-runs in the default mode); this module runs the key checks in both modes on one handle and bounds the distance
-between the two.  Needs an MI355X.
+runs in the default mode unless a test names the other); this module runs the key checks in both modes on one handle and
+bounds the distance between the two.  Needs an MI355X.
 """
 import numpy as np
 import pytest
@@ -38,15 +38,25 @@ def _masks(h, L, nseg):
     return h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
 
 
-def test_default_mode_and_switching(L, sep):
+def test_default_mode_and_switching(L, sep, mc_state):
     h = sep.handle
-    assert h.linear_mode() == "split_f16"
-    h.set_linear_mode("exact_f32")
+    # a new handle computes in the reference's own operand precision (css_create; conformer.py:137-150 is float32)
     assert h.linear_mode() == "exact_f32"
     h.set_linear_mode("split_f16")
     assert h.linear_mode() == "split_f16"
+    h.set_linear_mode("exact_f32")
+    assert h.linear_mode() == "exact_f32"
     with pytest.raises(Exception):
         L.check(h.h, h.lib.css_set_linear_mode(h.h, 7))
+    # the opt-in at the separator level (what css_inference / separate_and_stitch users pass)
+    SEP = pkg("separator")
+    s2 = SEP.HipSeparator(mc_state[0], None, device=0, linear_mode="split_f16")
+    try:
+        assert s2.handle.linear_mode() == "split_f16"
+    finally:
+        s2.close()
+    with pytest.raises(ValueError):
+        SEP.HipSeparator(mc_state[0], None, device=0, linear_mode="bf16")
 
 
 def test_masks_and_hidden_in_both_modes(L, sep, mc_state, mix_stage, golden):
@@ -64,7 +74,7 @@ def test_masks_and_hidden_in_both_modes(L, sep, mc_state, mix_stage, golden):
     g = golden("stage_mc.npz")
     fd, td = int(g["fdec"]), int(g["tdec"])
     got = {}
-    for mode in ("exact_f32", "split_f16", "exact_f32", "split_f16"):   # switching back and forth is part of the test
+    for mode in ("split_f16", "exact_f32", "split_f16", "exact_f32"):   # switching back and forth is part of the test (ends in the default)
         h.set_linear_mode(mode)
         wav = h.run(mix_stage[0], run_cfg)
         nseg = h.get_plan().num_segments
@@ -95,15 +105,15 @@ def test_masks_and_hidden_in_both_modes(L, sep, mc_state, mix_stage, golden):
         assert rel_rms(got["split_f16"][1][k], got["exact_f32"][1][k]) < 1e-4
 
 
-def test_e2e_waveform_vs_reference_exact_mode(L, sep, mix60, golden):
-    """The 20 s end-to-end fixture in exact_f32 mode (test_hip_parity.py runs it in the default split_f16 mode)."""
+def test_e2e_waveform_vs_reference_split_mode(L, sep, mix60, golden):
+    """The 20 s end-to-end fixture in split_f16 mode (test_hip_parity.py runs it in the default exact_f32 mode)."""
     CSS = pkg("css")
     g = golden("e2e_mc.npz")
     mix = mix60[:, :20 * 16000]
     cfg = CSS.CssCfg(activity_th=0.3, show_progressbar=False)
     run_cfg = CSS.make_run_cfg(cfg, 16000, 7)
     h = sep.handle
-    h.set_linear_mode("exact_f32")
+    h.set_linear_mode("split_f16")
     try:
         nseg = int(g["num_segments"])
         h.begin(mix[0], mix.shape[1], 7, run_cfg)
@@ -121,7 +131,7 @@ def test_e2e_waveform_vs_reference_exact_mode(L, sep, mix60, golden):
         flips = int((np.argmax(m, axis=0).transpose(1, 0, 2) != g["wta_index"]).sum())
         assert flips <= 1e-5 * g["wta_index"].size + 3
     finally:
-        h.set_linear_mode("split_f16")
+        h.set_linear_mode("exact_f32")
 
 
 def test_exact_mode_is_bit_identical_on_either_float32_gemm(L, sep, mix_stage):
@@ -145,4 +155,3 @@ def test_exact_mode_is_bit_identical_on_either_float32_gemm(L, sep, mix_stage):
                     assert np.array_equal(a, b), tune
     finally:
         h.set_tuning("f32_gemm", 0)
-        h.set_linear_mode("split_f16")

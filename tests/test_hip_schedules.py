@@ -5,13 +5,14 @@ batch sizes and lane counts, ragged tails included.  A 2-block model keeps it to
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import MODES, pkg
 from test_hip_parity import virtual_rank_run
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(3.02, 64, 3), (3.6, 64, 3), (7.7, 4, 2), (11.3, 64, 3), (19.01, 5, 3), (26.5, 7, 4), (33.3, 64, 1), (47.9, 16, 3),
-         (61.7, 13, 2), (95.2, 32, 3)]
+# (seconds, max_batch_segments, lanes, arithmetic mode: the default exact_f32 and the opt-in split_f16 take turns)
+CASES = [(3.02, 64, 3, 0), (3.6, 64, 3, 1), (7.7, 4, 2, 0), (11.3, 64, 3, 1), (19.01, 5, 3, 0), (26.5, 7, 4, 1), (33.3, 64, 1, 0),
+         (47.9, 16, 3, 1), (61.7, 13, 2, 0), (95.2, 32, 3, 1), (26.5, 7, 4, 0), (61.7, 13, 2, 1)]
 
 
 @pytest.fixture(scope="module")
@@ -21,18 +22,20 @@ def model():
     return W.apply_golden_recipe(W.portable_state_dict(desc, 21)), desc
 
 
-@pytest.mark.parametrize("seconds,max_batch,lanes", CASES)
-def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes):
+@pytest.mark.parametrize("seconds,max_batch,lanes,mode_ix", CASES)
+def test_all_schedules_give_the_same_bits(model, seconds, max_batch, lanes, mode_ix):
     import torch
     L, CSS, PAR = pkg("_lib"), pkg("css"), pkg("parallel")
     st, desc = model
     mix = pkg("synth").synth_meeting(seconds, 7, seed=int(seconds * 10))
     n = mix.shape[1] - (int(seconds * 1000) % 200)          # ragged: not a whole number of frames
     pcm = np.ascontiguousarray(mix[0, :n])
-    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch, linear_mode=MODES[mode_ix])
     try:
         h = sep.handle
         h.set_lanes(lanes)
+        if MODES[mode_ix] == "exact_f32":
+            h.set_tuning("f32_lane_rows", 1)      # (as many lanes as set_lanes gives: the float32 mode would keep short batches on one)
         run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
         plan = L.plan(desc, run_cfg, n)
         ref = h.run(pcm, run_cfg).copy()                                         # pageable host memory
@@ -118,15 +121,16 @@ def test_dense_and_long_segmentations_every_schedule(model, seg, hop, seconds, m
         sep.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("lanes,max_batch,pinned", [(3, 64, True), (2, 7, True), (1, 64, True), (3, 16, False)])
-def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinned):
+def test_queued_sessions_equal_synchronous_passes(model, lanes, max_batch, pinned, mode):
     """css_run_enqueue / css_wait: sessions of different lengths and contents queued back to back (page-locked buffers:
     neighbouring passes overlap -- uploads under the previous estimator, stitching / synthesis / download beside the next
     one; pageable output: the passes just queue up) give, each, the bits of its own synchronous css_run."""
     L, CSS = pkg("_lib"), pkg("css")
     st, desc = model
     run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
-    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=max_batch, linear_mode=mode)
     try:
         h = sep.handle
         h.set_lanes(lanes)
@@ -252,8 +256,8 @@ def test_queued_long_segment_sessions_share_estimator_batches(mc_state):
         sep.close()
 
 
-@pytest.mark.parametrize("group", [1, 2, 3, 8])
-def test_queued_sessions_share_estimator_batches(mc_state, group):
+@pytest.mark.parametrize("group,mode", [(1, "exact_f32"), (2, "exact_f32"), (3, "exact_f32"), (8, "exact_f32"), (3, "split_f16"), (8, "split_f16")])
+def test_queued_sessions_share_estimator_batches(mc_state, group, mode):
     """css_run_enqueue merges the segments of consecutive queued sessions into ONE mask-estimator batch (run_group:
     M = 22 k rows per Linear-layer launch for three 60 s meetings): sessions of different lengths, levels and CssCfg
     (threshold, mask floor, stitching loss -- everything but the segmentation may differ inside a group), a session of
@@ -265,7 +269,7 @@ def test_queued_sessions_share_estimator_batches(mc_state, group):
     mk = lambda **kw: CSS.make_run_cfg(CSS.CssCfg(show_progressbar=False, **kw), 16000, 7)
     cfgs = [mk(activity_th=0.3), mk(activity_th=0.45), mk(activity_th=0.3, mc_mask_floor_db=-6.0), mk(activity_th=0.3, stitching_loss="mse"),
             mk(activity_th=0.3, segment_size_sec=4.0, hop_size_sec=2.0), mk(activity_th=0.3), mk(activity_th=0.5), mk(activity_th=0.3)]
-    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128, linear_mode=mode)
     try:
         h = sep.handle
         sessions = []
