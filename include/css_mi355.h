@@ -284,6 +284,15 @@ int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int3
  * of each stream before normalisation. */
 int css_run_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                   int16_t* wav_pcm16_host, int64_t wav_capacity_per_stream, float* peaks_host);
+/* css_run_pcm16 as a QUEUED session (round 6): the session loop of inference_pipeline/inference.py:59-63 -- one css_inference
+ * per session: css/css.py:51-107 load_audio -> separate_and_stitch -> write_wav -- with both wav edges on the device AND
+ * the sessions sharing mask-estimator batches like css_run_enqueue's (same queue: float and PCM16 sessions may alternate).
+ * The n_ch plane pointers are copied at the call; the planes, wav_pcm16_host [S][cap] and peaks_host (NULL or S floats) must
+ * stay valid and untouched until css_wait.  With page-locked planes / output (css_host_alloc) the session joins a shared
+ * batch and its PCIe legs hide under its neighbours' kernels; with pageable output it runs as a pass of its own.  Results
+ * are bit for bit css_run_pcm16's (tests/test_hip_session.py).  frame_len 512 / frame_hop 256 only, like css_run_pcm16. */
+int css_run_enqueue_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                          int16_t* wav_pcm16_host, int64_t wav_capacity_per_stream, float* peaks_host);
 int css_get_timings(css_handle_t h, CssTimings* out);
 /* enable != 0: bracket every MFMA GEMM launch of the mask estimator with HIP events on the handle's
  * stream, so that CssTimings.gemm_ms / gemm_launches report the live average launch duration. */
@@ -363,6 +372,20 @@ int css_stage_stitch_gate(css_handle_t h, int64_t t_lo, int64_t t_hi);
  * last block hold one frame's contribution each; adding the overlapping blocks of adjacent shards
  * reproduces css_stage_istft bit for bit (a two-term float sum commutes). */
 int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* shard_dev, int64_t shard_ld);
+/* The seam for ANY frame geometry (round 6; ExtractorCfg.frame_len / frame_hop, feature.py:19-45,138-167).  With
+ * ovl = ceil(frame_len / frame_hop) > 2 frames over an output sample the overlap-add is an ORDERED float sum (oldest frame
+ * first) and partial blocks of two ranks do not compose bit for bit; the ranks exchange the synthesis rows of their last
+ * ovl - 1 frames instead and the receiver runs the single-GPU overlap-add over them:
+ *   css_stage_synthesis    frames [t_lo, t_hi) of the gated spectra -> their rows G[s][t][frame_len] (feature.py:162 without
+ *                          the overlap-add); after css_stage_stitch_gate of those frames;
+ *   css_stage_seam_rows    write == 0: G rows of frames [t_lo, t_hi) -> rows_dev [S][t_hi - t_lo][frame_len] (the piece a rank
+ *                          sends); write == 1: the reverse (a left neighbour's rows take their place in G);
+ *   css_stage_overlap_add  output blocks [q_lo, q_hi) (one hop each; q_hi <= mix_frames - 1 + ovl) from the frames
+ *                          [f_lo, f_hi) of G into out_dev [S][out_ld], block q at column (q - out_q0) * hop. */
+int css_stage_synthesis(css_handle_t h, int64_t t_lo, int64_t t_hi);
+int css_stage_seam_rows(css_handle_t h, int64_t t_lo, int64_t t_hi, float* rows_dev, int32_t write);
+int css_stage_overlap_add(css_handle_t h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out_dev, int64_t out_ld,
+                          int64_t out_q0);
 /* Exchange 3 of a segment-sharded meeting (parallel.py): gathered_dev [world][S][shard_ld] holds every rank's
  * css_stage_istft_partial shard (rank r: output blocks t_lo[r] .. t_hi[r]); out_dev [S][out_ld] receives the stitched
  * streams -- a rank's inner blocks as they are, the block at a seam as the sum of its two neighbours' partial blocks. */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "css_wait": (C.c_int, [_P]),
     "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
+    "css_run_enqueue_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
     "css_get_timings": (C.c_int, [_P, C.POINTER(CssTimings)]),
     "css_set_profile": (C.c_int, [_P, C.c_int]),
     "css_get_kernel_stats": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
@@ -126,6 +127,9 @@ SIGNATURES = {
     "css_stage_stitch": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_istft": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "css_stage_join_shards": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int64]),
+    "css_stage_synthesis": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "css_stage_seam_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32]),
+    "css_stage_overlap_add": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
     "css_sync": (C.c_int, [_P]),
     "css_stft_host": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int64]),
     "css_separate_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -402,6 +406,25 @@ class Handle:
                                              peaks.ctypes.data_as(C.c_void_p)))
         return out, peaks
 
+    def run_enqueue_pcm16(self, planes, cfg: RunCfg, out16: np.ndarray, peaks: Optional[np.ndarray] = None) -> np.ndarray:
+        """run_pcm16 as a queued session (css_run_enqueue_pcm16): `planes` = C mono int16 arrays of equal length, `out16` an
+        int16 [S, >= n_out] array, `peaks` None or a float32 [S] array -- all of them must stay alive and untouched until
+        wait(); page-locked buffers (pinned_empty / pinned_copy) let the session share an estimator batch with its neighbours
+        in the queue and hide its PCIe legs.  Returns the view of `out16` that wait() makes valid."""
+        n = planes[0].shape[0]
+        for p in planes:
+            assert p.dtype == np.int16 and p.ndim == 1 and p.shape[0] == n and p.flags.c_contiguous
+        c = len(planes)
+        pl = plan(self.desc, cfg, n)
+        S = int(self.desc.num_spks)
+        assert out16.dtype == np.int16 and out16.ndim == 2 and out16.shape[0] == S and out16.shape[1] >= pl.n_out and out16.strides[1] == 2
+        assert peaks is None or (peaks.dtype == np.float32 and peaks.shape == (S,) and peaks.flags.c_contiguous)
+        ptrs = (C.c_void_p * c)(*[p.ctypes.data for p in planes])
+        self._queued_keep = getattr(self, "_queued_keep", []) + [(planes, out16, peaks, cfg)]
+        check(self.h, self.lib.css_run_enqueue_pcm16(self.h, ptrs, n, c, C.byref(cfg.c), out16.ctypes.data_as(C.c_void_p), out16.strides[0] // 2,
+                                                     peaks.ctypes.data_as(C.c_void_p) if peaks is not None else None))
+        return out16[:, :pl.n_out]
+
     def timings(self) -> dict:
         t = CssTimings()
         check(self.h, self.lib.css_get_timings(self.h, C.byref(t)))
@@ -539,6 +562,15 @@ class Handle:
 
     def stage_istft_partial(self, lo, hi, shard_ptr: int, shard_ld: int):
         check(self.h, self.lib.css_stage_istft_partial(self.h, lo, hi, C.c_void_p(shard_ptr), shard_ld))
+
+    def stage_synthesis(self, lo, hi):
+        check(self.h, self.lib.css_stage_synthesis(self.h, lo, hi))
+
+    def stage_seam_rows(self, lo, hi, rows_ptr: int, write: bool):
+        check(self.h, self.lib.css_stage_seam_rows(self.h, lo, hi, C.c_void_p(rows_ptr), int(bool(write))))
+
+    def stage_overlap_add(self, f_lo, f_hi, q_lo, q_hi, out_ptr: int, out_ld: int, out_q0: int):
+        check(self.h, self.lib.css_stage_overlap_add(self.h, f_lo, f_hi, q_lo, q_hi, C.c_void_p(out_ptr), int(out_ld), int(out_q0)))
 
     def stage_join_shards(self, gathered_ptr: int, world: int, shard_ld: int, t_lo, t_hi, out_ptr: int, out_ld: int):
         lo = np.ascontiguousarray(t_lo, dtype=np.int64)

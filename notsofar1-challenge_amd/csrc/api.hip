@@ -78,6 +78,7 @@ struct SessState {
     DevBuf X_alt;   // run_group: consecutive grouped passes alternate between X and X_alt (the beamformer of pass P reads its
                     // planes on the tail stream while pass P + 1's transform already writes the other set)
     const float* pcm_src = nullptr;       // sample-major PCM on the device for the current session
+    bool src16 = false;                   // run_group: pcm_src holds the session's n_ch mono PCM16 planes [C][n] instead (css_run_enqueue_pcm16)
     unsigned int* peak_dev = nullptr;     // max |sample| of the session's PCM as float bits (split_f16.hpp level_gain)
     // the session's masks [(S+1)F][mask_ld], segment s at column s*T: the handle's mask buffer, or -- inside a group -- this
     // session's columns of the group's buffer (the mask head of the shared estimator batch writes all of them at once)
@@ -170,6 +171,7 @@ struct css_ctx : SessState {
     // them on the exact float32 kernels (the caller keeps pcm_host valid and wav_host untouched until css_wait anyway)
     struct QueuedPass {
         const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; float* wav; int64_t cap;
+        std::vector<const int16_t*> planes; int16_t* wav16 = nullptr; float* peaks = nullptr;   // css_run_enqueue_pcm16 (pcm == wav == nullptr)
         std::vector<float> w;   // the three stitching windows of cfg, copied at css_run_enqueue (the caller may free its own)
         QueuedPass(const float* pcm_, int64_t n_, int32_t n_ch_, const CssRunCfg& c, float* wav_, int64_t cap_)
             : pcm(pcm_), n(n_), n_ch(n_ch_), cfg(c), wav(wav_), cap(cap_) {
@@ -192,7 +194,8 @@ struct css_ctx : SessState {
     // css_run_enqueue: sessions accepted and not yet on the streams -- they wait for company: sessions of one segment
     // length are merged into ONE estimator batch (run_group) as long as their segments fit max_batch_segments
     struct Pending { const float* pcm; int64_t n; int32_t n_ch; CssRunCfg cfg; std::vector<float> w; float* wav; int64_t cap;
-                     float* wav_mapped; int64_t nseg; };
+                     float* wav_mapped; int64_t nseg;
+                     std::vector<const int16_t*> planes; int16_t* wav16 = nullptr; float* peaks = nullptr; };   // PCM16 edges: pcm == wav == nullptr
     std::vector<Pending> pending;
     int64_t pending_segments = 0;
     void* comm = nullptr;          // ncclComm_t of css_comm_init (RCCL, loaded lazily)
@@ -914,6 +917,7 @@ static int begin_impl(css_handle_t h, int64_t n_samples, int32_t n_ch, const Css
     h->prof_reduced = 0;
     h->gemm_flops = 0.0;
     h->pcm_src = nullptr;
+    h->src16 = false;
 
     const int F = h->d.num_bins, S = h->d.num_spks;
     const int64_t nseg = p.num_segments, TL = p.mix_frames;
@@ -1495,9 +1499,52 @@ int css_stage_istft_partial(css_handle_t h, int64_t t_lo, int64_t t_hi, float* s
     int rc = check_frames(h, t_lo, t_hi);
     if (rc) return rc;
     if (h->d.frame_len != 2 * h->d.frame_hop)
-        return fail(h, CSS_ERR_INVALID_ARG, "the sharded schedules (seam = one hop block) are built for frame_len = 2 * frame_hop");
+        return fail(h, CSS_ERR_INVALID_ARG, "partial output blocks compose only for frame_len = 2 * frame_hop (a two-term sum): other geometries exchange "
+                                            "synthesis rows (css_stage_synthesis / css_stage_seam_rows / css_stage_overlap_add)");
     if (!shard_dev || shard_ld < (t_hi - t_lo + 1) * h->d.frame_hop) return fail(h, CSS_ERR_INVALID_ARG, "shard buffer too small");
     return istft_impl(h, t_lo, t_hi, t_lo, t_hi + 1, shard_dev, shard_ld, t_lo, h->stream);
+}
+
+// ---- the seam of a frame-sharded meeting for ANY frame geometry (round 6).  With frame_len = 2 hop an output block sums two
+// frames and the two-term sum commutes, so ranks exchange partial BLOCKS (css_stage_istft_partial).  With ceil(frame_len / hop)
+// = ovl > 2 frames over a sample the float sum is ordered (oldest frame first, wave_ola_kernel) and partial sums do not
+// compose: the ranks exchange the synthesis ROWS of their last ovl - 1 frames instead (frame_len floats per frame and stream),
+// the receiver puts them where its left neighbour's frames belong and runs the very overlap-add of the single-GPU pass.
+int css_stage_synthesis(css_handle_t h, int64_t t_lo, int64_t t_hi) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    istft_gemm_on(h, t_lo, t_hi, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
+}
+
+int css_stage_seam_rows(css_handle_t h, int64_t t_lo, int64_t t_hi, float* rows_dev, int32_t write) {
+    int rc = check_frames(h, t_lo, t_hi);
+    if (rc) return rc;
+    if (!rows_dev) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    if (t_hi == t_lo) return CSS_OK;
+    const int S = h->d.num_spks, L = h->d.frame_len;
+    const int64_t TL = h->plan.mix_frames, nf = t_hi - t_lo;
+    // G [S][TL][L]  <->  rows_dev [S][nf][L]
+    float* g = (float*)h->G.p + t_lo * L;
+    const size_t row = (size_t)nf * L * sizeof(float);
+    if (write) HIPCHK(h, hipMemcpy2DAsync(g, (size_t)TL * L * sizeof(float), rows_dev, row, row, (size_t)S, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemcpy2DAsync(rows_dev, row, g, (size_t)TL * L * sizeof(float), row, (size_t)S, hipMemcpyDeviceToDevice, h->stream));
+    return CSS_OK;
+}
+
+int css_stage_overlap_add(css_handle_t h, int64_t f_lo, int64_t f_hi, int64_t q_lo, int64_t q_hi, float* out_dev, int64_t out_ld,
+                          int64_t out_q0) {
+    int rc = check_frames(h, f_lo, f_hi);
+    if (rc) return rc;
+    const int64_t TL = h->plan.mix_frames;
+    if (!out_dev || q_lo < 0 || q_hi < q_lo || q_hi > TL - 1 + h->ovl || out_q0 > q_lo) return fail(h, CSS_ERR_INVALID_ARG, "output block range out of bounds");
+    // (the last block may be a short one: n_out = (TL - 1) hop + frame_len; the kernel stops at out_ld)
+    if (out_ld < std::min<int64_t>((q_hi - out_q0) * h->d.frame_hop, h->plan.n_out - out_q0 * h->d.frame_hop))
+        return fail(h, CSS_ERR_INVALID_ARG, "out_ld shorter than the blocks asked for");
+    wave_ola_on(h, f_lo, f_hi, q_lo, q_hi, out_dev, out_ld, out_q0, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return CSS_OK;
 }
 
 int css_stage_join_shards(css_handle_t h, const float* gathered_dev, int32_t world, int64_t shard_ld, const int64_t* t_lo,
@@ -1662,15 +1709,25 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     if (!h->fft512) {
         // Other frame sizes (ExtractorCfg.frame_len / frame_hop): the plain stage sequence on one stream, samples up and
         // waveforms down as whole copies -- the pipelined schedules below are built around frame_len = 2 hop
-        if (io.planes_host || io.wav16_host)
-            return fail(h, CSS_ERR_INVALID_ARG, "the PCM16 edges are built for frame_len 512 / frame_hop 256: use css_run with float PCM");
         if (io.pcm_host) {
             if ((rc = ensure(h, h->pcm_in, (size_t)n * n_ch * sizeof(float))) != CSS_OK) return rc;
             h->pcm_src = (const float*)h->pcm_in.p;
             HIPCHK(h, hipMemcpyAsync(h->pcm_in.p, io.pcm_host, (size_t)n * n_ch * sizeof(float), hipMemcpyHostToDevice, h->stream));
         }
-        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->stream);
-        if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
+        if (io.planes_host) {   // the first wav edge (round 6: any frame geometry): int16 planes up, scaled by 2^-15 on the way to channel-major
+            for (int c = 0; c < n_ch; ++c) {
+                HIPCHK(h, hipMemcpyAsync((int16_t*)h->in16.p + (size_t)c * n, io.planes_host[c], (size_t)n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+                launch_pcm_peak_i16(planes_dev + (size_t)c * n, peak_len(h, 0, n), h->peak_dev, h->stream);
+            }
+            if (pl.stft_frames < TL)   // short input: zero-padded frames (css.py:159-164)
+                HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->stream));
+            if ((rc = stft_frames(h, 0, TL, planes_dev, h->stream)) != CSS_OK) return rc;
+            hipEventRecord(h->ev[2], h->stream);
+            h->stft_done = true;
+        } else {
+            launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, n) * n_ch, h->peak_dev, h->stream);
+            if ((rc = css_stage_stft(h)) != CSS_OK) return rc;
+        }
         if ((rc = css_stage_masknet(h, 0, nseg)) != CSS_OK) return rc;
         if ((rc = css_stage_mvdr(h, 0, nseg)) != CSS_OK) return rc;
         if ((rc = css_stage_pit_costs(h, 0, nseg - 1)) != CSS_OK) return rc;
@@ -1683,6 +1740,15 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
             dst = (float*)h->wav.p; dst_ld = pl.n_out;
         }
         if ((rc = istft_impl(h, 0, TL, 0, TL - 1 + h->ovl, dst, dst_ld, 0, h->stream)) != CSS_OK) return rc;
+        if (io.wav16_host) {    // the second wav edge: peak normalisation + PCM16 encoding on the device (utils/audio_utils.py:37-49)
+            const int64_t n_out = pl.n_out;
+            unsigned int* pk = (unsigned int*)h->enc.p;
+            int16_t* o16 = (int16_t*)((char*)h->enc.p + 64);
+            { CSS_PROF(CSS_PROF_ENCODE, h->stream); launch_encode_pcm16(dst, S, n_out, pk, o16, n_out, h->stream); }
+            HIPCHK(h, hipMemcpy2DAsync(io.wav16_host, (size_t)io.cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
+                                       (size_t)n_out * sizeof(int16_t), S, hipMemcpyDeviceToHost, h->stream));
+            if (io.peaks_host) HIPCHK(h, hipMemcpyAsync(io.peaks_host, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        }
         if (io.wav_host)
             for (int sp = 0; sp < S; ++sp)
                 HIPCHK(h, hipMemcpyAsync(io.wav_host + (size_t)sp * io.cap, dst + (size_t)sp * dst_ld, (size_t)pl.n_out * sizeof(float),
@@ -2017,7 +2083,9 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         off[(size_t)j] = total;
         total += h->plan.num_segments;
         pcm_off[(size_t)j] = (int64_t)pcm_bytes;
-        pcm_bytes += ((size_t)grp[(size_t)j].n * grp[(size_t)j].n_ch * sizeof(float) + 255) / 256 * 256;
+        const bool s16 = !grp[(size_t)j].planes.empty();
+        pcm_bytes += ((size_t)grp[(size_t)j].n * grp[(size_t)j].n_ch * (s16 ? sizeof(int16_t) : sizeof(float)) + 255) / 256 * 256;
+        if (grp[(size_t)j].wav16 && (rc = ensure(h, h->enc, (size_t)h->d.num_spks * h->plan.n_out * sizeof(int16_t) + 64)) != CSS_OK) return rc;
     }
     const int T = grp[0].cfg.segment_frames, hop = grp[0].cfg.hop_frames;
     // a shared batch runs on at most TWO lanes: measured equal to three (profiles/r04_queue_group_ab.md), and it leaves the
@@ -2033,6 +2101,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         h->pcm_src = (const float*)(pcm_base + pcm_off[(size_t)j]);
+        h->src16 = !grp[(size_t)j].planes.empty();
         h->masks_v = (float*)h->masks.p + off[(size_t)j] * T;
         h->mask_ld_v = total * T;
         gs[(size_t)j] = GroupSess{(const float*)h->X.p, h->T_ld, h->plan.stft_frames, off[(size_t)j], (int)h->plan.num_segments,
@@ -2072,16 +2141,24 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
     for (int j = 0; j < G; ++j) {
         Active act(h, j, G);
         const css_ctx::Pending& q = grp[(size_t)j];
-        HIPCHK(h, hipMemcpyAsync(const_cast<float*>(h->pcm_src), q.pcm, (size_t)q.n * q.n_ch * sizeof(float), hipMemcpyHostToDevice,
-                                 h->copy_stream));
-        launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, q.n) * q.n_ch, h->peak_dev, h->copy_stream);
+        if (h->src16) {   // the session's mono PCM16 planes, half the PCIe bytes (css_run_enqueue_pcm16)
+            int16_t* dst16 = (int16_t*)const_cast<float*>(h->pcm_src);
+            for (int c = 0; c < q.n_ch; ++c) {
+                HIPCHK(h, hipMemcpyAsync(dst16 + (size_t)c * q.n, q.planes[(size_t)c], (size_t)q.n * sizeof(int16_t), hipMemcpyHostToDevice, h->copy_stream));
+                launch_pcm_peak_i16(dst16 + (size_t)c * q.n, peak_len(h, 0, q.n), h->peak_dev, h->copy_stream);
+            }
+        } else {
+            HIPCHK(h, hipMemcpyAsync(const_cast<float*>(h->pcm_src), q.pcm, (size_t)q.n * q.n_ch * sizeof(float), hipMemcpyHostToDevice,
+                                     h->copy_stream));
+            launch_pcm_peak_f32(h->pcm_src, peak_len(h, 0, q.n) * q.n_ch, h->peak_dev, h->copy_stream);
+        }
         if (xf_main) {   // (A/B: the transforms as a prefix of the main stream)
             HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
             continue;
         }
         if (h->plan.stft_frames < h->plan.mix_frames)   // short input: zero-padded frames (css.py:159-164)
             HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->copy_stream));
-        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->copy_stream)) != CSS_OK) return rc;
+        if ((rc = stft_frames(h, 0, h->plan.mix_frames, h->src16 ? (const int16_t*)h->pcm_src : nullptr, h->copy_stream)) != CSS_OK) return rc;
         h->stft_done = true;
         HIPCHK(h, hipEventRecord(planes[(size_t)j], h->copy_stream));
     }
@@ -2093,7 +2170,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         Active act(h, j, G);
         if (h->plan.stft_frames < h->plan.mix_frames)
             HIPCHK(h, hipMemsetAsync(h->X.p, 0, (size_t)h->n_ch * X_ROWS_PER_BIN * F * h->T_ld * sizeof(float), h->stream));
-        if ((rc = stft_frames(h, 0, h->plan.mix_frames, nullptr, h->stream)) != CSS_OK) return rc;
+        if ((rc = stft_frames(h, 0, h->plan.mix_frames, h->src16 ? (const int16_t*)h->pcm_src : nullptr, h->stream)) != CSS_OK) return rc;
         h->stft_done = true;
     }
     if (xf_main) HIPCHK(h, hipEventRecord(h->pcm_free[par], h->stream));
@@ -2173,7 +2250,19 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         { CSS_PROF(CSS_PROF_OLA_STFT, ts); launch_ola_stft(sa, 0, TL, ts); }
         if (j == G - 1) hipEventRecord(h->ev[5], ts);
         istft_gemm_on(h, 0, TL, ts);
-        if (h->tune[CSS_TUNE_GROUP_OUT_DMA]) {
+        if (q.wav16) {
+            // the second wav edge on the device (utils/audio_utils.py:37-49 write_wav): peak normalisation and PCM16 encoding of
+            // the session's streams, then half the PCIe bytes back -- css_run_pcm16's arithmetic, launch for launch
+            const int64_t n_out = h->plan.n_out;
+            if ((rc = ensure(h, h->wav, (size_t)S * n_out * sizeof(float))) != CSS_OK) return rc;
+            wave_ola_on(h, 0, TL, 0, TL + 1, (float*)h->wav.p, n_out, 0, ts);
+            unsigned int* pk = (unsigned int*)h->enc.p;
+            int16_t* o16 = (int16_t*)((char*)h->enc.p + 64);
+            { CSS_PROF(CSS_PROF_ENCODE, ts); launch_encode_pcm16((const float*)h->wav.p, S, n_out, pk, o16, n_out, ts); }
+            HIPCHK(h, hipMemcpy2DAsync(q.wav16, (size_t)q.cap * sizeof(int16_t), o16, (size_t)n_out * sizeof(int16_t),
+                                       (size_t)n_out * sizeof(int16_t), S, hipMemcpyDeviceToHost, ts));
+            if (q.peaks) HIPCHK(h, hipMemcpyAsync(q.peaks, pk, (size_t)S * sizeof(float), hipMemcpyDeviceToHost, ts));
+        } else if (h->tune[CSS_TUNE_GROUP_OUT_DMA]) {
             // the PCIe leg as copies behind a 12 us kernel: written by the kernel itself the same samples keep 11 250
             // workgroups resident for 0.21 ms per session, beside the next pass's estimator (profiles/r04_queue_group_ab.md)
             const int64_t n_out = h->plan.n_out;
@@ -2210,6 +2299,7 @@ static int flush_pending(css_handle_t h) {
     int rc;
     if (grp.size() == 1) {
         RunIo io; io.pcm_host = grp[0].pcm; io.wav_host = grp[0].wav; io.cap = grp[0].cap; io.enqueue_only = true;
+        if (!grp[0].planes.empty()) { io.planes_host = grp[0].planes.data(); io.wav16_host = grp[0].wav16; io.peaks_host = grp[0].peaks; }
         rc = run_once(h, grp[0].n, grp[0].n_ch, &grp[0].cfg, io);
     } else {
         rc = run_group(h, grp);
@@ -2255,32 +2345,43 @@ int css_run(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_
     return run_impl(h, n_samples, n_ch, cfg, io);
 }
 
-int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
-                    float* wav_host, int64_t cap) {
-    if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+// css_run_enqueue (float PCM -> float waveforms) and css_run_enqueue_pcm16 (PCM16 planes -> peak-normalised PCM16 streams): one
+// queue, one grouping rule; a session is one or the other (planes == nullptr: float)
+static int enqueue_impl(css_handle_t h, const float* pcm_host, const int16_t* const* planes, int64_t n_samples, int32_t n_ch,
+                        const CssRunCfg* cfg, float* wav_host, int16_t* wav16, float* peaks, int64_t cap) {
     CssPlan pl{};
     int rc = check_run_args(h, n_samples, n_ch, cfg, &pl);
     if (rc != CSS_OK) return rc;
     if (cap < pl.n_out) return fail(h, CSS_ERR_INVALID_ARG, "output buffer too small: need " + std::to_string(pl.n_out) + " samples per stream");
+    if (planes)
+        for (int c = 0; c < n_ch; ++c)
+            if (!planes[c]) return fail(h, CSS_ERR_INVALID_ARG, "null channel plane");
     // Can the session share an estimator batch with its neighbours in the queue?  It must take the overlapping form of a
     // queued pass (page-locked output, beamformer on the lanes) and fit a batch; sessions of another segmentation or
     // window start a new group.  A pass under the per-launch profile stays alone only when grouping is off.
-    float* mapped = nullptr;
-    if (h->mapped_key != wav_host) { h->mapped_key = wav_host; h->mapped_val = mapped_host(wav_host); }
-    mapped = (float*)h->mapped_val;
+    const void* out_key = wav16 ? (const void*)wav16 : (const void*)wav_host;
+    if (h->mapped_key != out_key) { h->mapped_key = out_key; h->mapped_val = mapped_host(out_key); }
+    float* mapped = (float*)h->mapped_val;   // (PCM16 output: only WHETHER it is page-locked matters -- it leaves by DMA)
     const bool groupable = h->fft512 && h->group_limit > 1 && mapped && h->tune[CSS_TUNE_MVDR_ON_LANES] && pl.num_segments <= batch_cap(h, cfg->segment_frames);
+    auto log_entry = [&]() {
+        h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
+        if (planes) { css_ctx::QueuedPass& e = h->queue_log.back(); e.planes.assign(planes, planes + n_ch); e.wav16 = wav16; e.peaks = peaks; }
+    };
+    auto io_of = [&](bool enqueue_only) {
+        RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = enqueue_only;
+        if (planes) { io.planes_host = planes; io.wav16_host = wav16; io.peaks_host = peaks; }
+        return io;
+    };
     if (!h->fft512) {
         // Frame sizes other than 512 / 256 run the plain stage sequence to its end inside the call (run_once): nothing stays
         // queued, so css_wait would never look at the range word.  The pass therefore takes css_run's own rule here -- queued
         // passes first, then this one, repeated in float32 or refused with CSS_ERR_RANGE when it left the split-f16 range.
-        RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap;
-        return run_impl(h, n_samples, n_ch, cfg, io);
+        return run_impl(h, n_samples, n_ch, cfg, io_of(false));
     }
     if (!groupable) {
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
-        RunIo io; io.pcm_host = pcm_host; io.wav_host = wav_host; io.cap = cap; io.enqueue_only = true;
-        rc = run_once(h, n_samples, n_ch, cfg, io);
-        if (rc == CSS_OK) h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
+        rc = run_once(h, n_samples, n_ch, cfg, io_of(true));
+        if (rc == CSS_OK) log_entry();
         return rc;
     }
     const int T = cfg->segment_frames;
@@ -2294,6 +2395,7 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
             if ((rc = flush_pending(h)) != CSS_OK) return rc;
     }
     css_ctx::Pending q{pcm_host, n_samples, n_ch, *cfg, {}, wav_host, cap, mapped, pl.num_segments};
+    if (planes) { q.planes.assign(planes, planes + n_ch); q.wav16 = wav16; q.peaks = peaks; }
     q.w.resize(3 * (size_t)T);
     std::memcpy(q.w.data(), cfg->w_first, T * sizeof(float));
     std::memcpy(q.w.data() + T, cfg->w_mid, T * sizeof(float));
@@ -2305,11 +2407,23 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
         }
     }
     h->pending_segments += pl.num_segments;
-    h->queue_log.emplace_back(pcm_host, n_samples, n_ch, *cfg, wav_host, cap);
+    log_entry();
     // no session of this length would still fit, or the group is full: off it goes -- nothing waits for a css_wait that
     // could already run
     if (h->pending_segments + pl.num_segments > batch_cap(h, cfg->segment_frames) || (int)h->pending.size() >= h->group_limit) return flush_pending(h);
     return CSS_OK;
+}
+
+int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                    float* wav_host, int64_t cap) {
+    if (!h || !pcm_host || !wav_host) return fail(h, CSS_ERR_INVALID_ARG, "null argument");
+    return enqueue_impl(h, pcm_host, nullptr, n_samples, n_ch, cfg, wav_host, nullptr, nullptr, cap);
+}
+
+int css_run_enqueue_pcm16(css_handle_t h, const int16_t* const* planes_host, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
+                          int16_t* wav_pcm16_host, int64_t cap, float* peaks_host) {
+    if (!h || !planes_host || !wav_pcm16_host || n_samples < 1 || n_ch < 1) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    return enqueue_impl(h, nullptr, planes_host, n_samples, n_ch, cfg, nullptr, wav_pcm16_host, peaks_host, cap);
 }
 
 int css_set_queue_group(css_handle_t h, int max_sessions) {
@@ -2355,6 +2469,7 @@ int css_wait(css_handle_t h) {
         for (; repeated < log.size() && rc == CSS_OK; ++repeated) {
             const css_ctx::QueuedPass& q = log[repeated];
             RunIo io; io.pcm_host = q.pcm; io.wav_host = q.wav; io.cap = q.cap;
+            if (!q.planes.empty()) { io.planes_host = q.planes.data(); io.wav16_host = q.wav16; io.peaks_host = q.peaks; }
             const CssRunCfg own = q.own_cfg();
             rc = run_once(h, q.n, q.n_ch, &own, io);
         }

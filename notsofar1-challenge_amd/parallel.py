@@ -24,6 +24,12 @@ Exchanges (all tiny; `torch.distributed`, backend "nccl" = RCCL on ROCm, "gloo" 
      all-gathers the whole shards instead (3 x 4 B per sample) and every rank assembles the full waveforms, as
      css.py:110 returns them.
 
+Frame geometries other than frame_len = 2 hop (ExtractorCfg.frame_len / frame_hop, round 6): ovl = ceil(frame_len / hop)
+frames overlap on an output sample and the overlap-add is an ORDERED float sum (oldest frame first), so partial blocks of
+two ranks no longer compose bit for bit.  Exchange 3 then carries the synthesis ROWS of a rank's last ovl - 1 frames
+(frame_len floats per frame and stream) and the right neighbour runs the single-GPU overlap-add over them; `gather="all"`
+all-gathers the FINISHED ranges and places them (no sums).  Same bits as the single-GPU pass for any world.
+
 Nothing of this touches the host between the upload of a rank's samples and the download of the result: the
 pieces are zero-copy torch views of the handle's own device buffers (costs, activity bits), the collectives and
 the few packing / unpacking copies are enqueued on the handle's HIP stream (wrapped as a torch ExternalStream),
@@ -213,6 +219,18 @@ class HipShardBackend:
     def istft_partial(self, lo, hi, out):
         self.h.stage_istft_partial(lo, hi, out.data_ptr(), out.stride(0))
 
+    # the seam of the general frame geometries (css_stage_synthesis / css_stage_seam_rows / css_stage_overlap_add)
+    def synthesis(self, lo, hi):
+        self.h.stage_synthesis(lo, hi)
+
+    def seam_rows(self, lo, hi, rows, write):
+        assert rows.is_contiguous() and tuple(rows.shape[1:2]) == (hi - lo,)
+        self.h.stage_seam_rows(lo, hi, rows.data_ptr(), write)
+
+    def overlap_add(self, f_lo, f_hi, q_lo, q_hi, out, out_q0):
+        assert out.stride(1) == 1
+        self.h.stage_overlap_add(f_lo, f_hi, q_lo, q_hi, out.data_ptr(), out.stride(0), out_q0)
+
     def join_shards(self, all_shards, plans, out):
         """gathered [world, S, ld] -> out [S, n_out] in one launch (css_stage_join_shards)"""
         assert all_shards.is_contiguous() and out.stride(1) == 1
@@ -247,7 +265,7 @@ class ShardedSession:
     chains them over torch.distributed; tests chain them for several virtual ranks in one process."""
 
     def __init__(self, backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int, rank: int,
-                 world: int, segment_groups=None):
+                 world: int, segment_groups=None, frame_len=None):
         import torch
         self.torch = torch
         self.be, self.S, self.rank, self.world = backend, num_spks, rank, world
@@ -260,6 +278,13 @@ class ShardedSession:
         self.max_b = max(max(p.b_hi - p.b_lo for p in self.plans), 1)
         self.max_t = max(max(p.num_frames for p in self.plans), 1)
         self.max_len = max(p.shard_len for p in self.plans)
+        # frame geometry: frame_len = 2 hop (every shipped model) exchanges partial blocks; anything else synthesis rows
+        self.frame_len = int(frame_len) if frame_len else 2 * hop_samples
+        self.ovl = -(-self.frame_len // hop_samples)          # frames over an output sample
+        self.general = self.frame_len != 2 * hop_samples
+        self.K = self.ovl - 1                                  # frames of the left neighbour(s) a rank's first blocks read
+        if self.general:
+            self.max_len = max((p.num_frames + self.K) * hop_samples for p in self.plans)
 
     def _ctx(self):
         return self.be.on_stream() if hasattr(self.be, "on_stream") else contextlib.nullcontext()
@@ -328,6 +353,18 @@ class ShardedSession:
                 idx = self._gather_index("idx_act", [(p.t_lo, p.t_hi) for p in self.plans], self.max_t, self.TL)
                 be.act_view().copy_(all_act.permute(1, 0, 2).reshape(self.S, -1).index_select(1, idx))
             be.stitch_gate(me.t_lo, me.t_hi)
+            if self.general:
+                # the synthesis rows of the owned frames stay in the handle; the last K of them are what the right neighbour
+                # needs (right-aligned in the piece: a rank with fewer than K frames passes on what it has)
+                be.synthesis(me.t_lo, me.t_hi)
+                send = be.scratch("send_rows", (self.S, max(self.K, 1), self.frame_len), torch.float32)
+                send.zero_()
+                cnt = min(self.K, me.num_frames)
+                if cnt:
+                    tmp = be.scratch(("rows", cnt), (self.S, cnt, self.frame_len), torch.float32)
+                    be.seam_rows(me.t_hi - cnt, me.t_hi, tmp, False)
+                    send[:, self.K - cnt:, :].copy_(tmp)
+                return send
             shard = be.scratch("send_wav", (self.S, self.max_len), torch.float32)
             be.istft_partial(me.t_lo, me.t_hi, shard)
             return shard
@@ -342,6 +379,8 @@ class ShardedSession:
     def seam_piece(self, shard):
         """The block past this rank's own range -- its last frame's second half, which the next rank adds [S, hop]."""
         torch, hop, me = self.torch, self.hop_samples, self.me
+        if self.general:
+            return shard      # (gate_and_istft returned the rows piece itself)
         with self._ctx():
             send = self.be.scratch("send_seam", (self.S, hop), torch.float32)
             if me.num_frames:
@@ -355,6 +394,8 @@ class ShardedSession:
         own_range() as a view of the shard [S, hi - lo]."""
         hop, me = self.hop_samples, self.me
         lo, hi = self.own_range()
+        if self.general:
+            return self._finish_range_general(all_seams)
         with self._ctx():
             left = [p for p in self.plans[:self.rank] if p.num_frames > 0]
             if me.num_frames and left:
@@ -362,13 +403,47 @@ class ShardedSession:
                 shard[:, :hop].add_(all_seams[left[-1].rank])
             return shard[:, :hi - lo]
 
+    def _finish_range_general(self, all_rows):
+        """General frame geometry: the left neighbours' last K synthesis rows [world, S, K, frame_len] take their place in the
+        handle's row buffer, then the single-GPU overlap-add runs over this rank's output blocks -- frames oldest first,
+        exactly as the unsharded pass adds them.  Returns the finished samples of own_range() [S, hi - lo]."""
+        torch, me, K, be = self.torch, self.me, self.K, self.be
+        lo, hi = self.own_range()
+        with self._ctx():
+            out = be.scratch("own_wav", (self.S, self.max_len), torch.float32)
+            if me.num_frames == 0:
+                return out[:, :0]
+            need_lo = max(me.t_lo - K, 0)
+            edge = me.t_lo                      # frames [edge, t_lo) are in place
+            for p in reversed([p for p in self.plans[:self.rank] if p.num_frames > 0]):
+                if edge <= need_lo:
+                    break
+                cnt = min(K, p.num_frames)
+                a, b = max(p.t_hi - cnt, need_lo), min(p.t_hi, edge)
+                if b > a:
+                    assert tuple(all_rows.shape) == (self.world, self.S, max(K, 1), self.frame_len), all_rows.shape
+                    piece = all_rows[p.rank][:, K - (p.t_hi - a):K - (p.t_hi - b), :].contiguous()
+                    be.seam_rows(a, b, piece, True)
+                    edge = a
+            q_hi = self.TL - 1 + self.ovl if me.t_hi == self.TL else me.t_hi
+            be.overlap_add(edge, me.t_hi, me.t_lo, q_hi, out, me.t_lo)
+            return out[:, :hi - lo]
+
     def join_shards(self, all_shards, out=None):
         """Place every rank's shard at its sample offset: a rank's inner output blocks are its own, the block at a seam
-        is the sum of the left rank's last and the right rank's first block (one frame's contribution each)."""
+        is the sum of the left rank's last and the right rank's first block (one frame's contribution each).  General frame
+        geometry: `all_shards` holds the ranks' FINISHED ranges, placed as they are."""
         torch, hop = self.torch, self.hop_samples
         with self._ctx():
             if out is None:
                 out = torch.empty((self.S, self.n_out), dtype=all_shards.dtype, device=all_shards.device)
+            if self.general:
+                for p in self.plans:
+                    if p.num_frames > 0:
+                        a = p.sample_lo
+                        b = self.n_out if p.t_hi == self.TL else p.t_hi * hop
+                        out[:, a:b].copy_(all_shards[p.rank][:, :b - a])
+                return out
             if hasattr(self.be, "join_shards"):      # the HIP backend: one kernel over the output
                 self.be.join_shards(all_shards, self.plans, out)
                 return out
@@ -406,7 +481,7 @@ def _all_gather(dist, send, world, comm_dev, cabi=None):
 
 def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_frames: int, hop_samples: int,
                                 rank: int, world: int, dist=None, out=None, gather: str = "all", segment_groups=None,
-                                trace=None, check_range: bool = True):
+                                trace=None, check_range: bool = True, frame_len=None):
     """Runs one rank's share of a session that `backend.begin(...)` has opened.
 
     gather="all" (default): returns the full separated waveforms [S, n_out] (a tensor on the backend's device),
@@ -429,7 +504,7 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
     asynchronous on the backend's stream: the CALLER then checks once it has synchronised (bench.py does, at its barrier).
     trace: optional callable(label), called on the host between the phases (bench.py records an event on the stream)."""
     assert gather in ("all", "range"), gather
-    ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world, segment_groups)
+    ss = ShardedSession(backend, num_spks, seg_frames, hop_frames, hop_samples, rank, world, segment_groups, frame_len)
     comm_dev = getattr(backend, "comm_dev", None)
     cabi = getattr(backend, "cabi_comm", None)   # HipShardBackend(cabi_comm=True): the handle, its RCCL communicator initialised
     mark = trace if trace is not None else (lambda label: None)
@@ -473,6 +548,33 @@ def sharded_separate_and_stitch(backend, num_spks: int, seg_frames: int, hop_fra
         mark("exchange_activity")
         shard = ss.gate_and_istft(act)
         mark("gate_istft")
+        if ss.general:
+            # frame_len != 2 hop: the synthesis rows of the last ovl - 1 frames cross the seam, every rank finishes its own range
+            # with the single-GPU overlap-add; gather="all" then all-gathers the finished ranges and places them
+            rows = shard
+            if world > 1:
+                rows = _all_gather(dist, rows, world, comm_dev if comm_dev is not None else rows.device, cabi)
+            else:
+                rows = rows[None]
+            own, rng = ss.finish_range(None, rows), ss.own_range()
+            if gather == "range":
+                if out is not None:
+                    out[:, :rng[1] - rng[0]].copy_(own)
+                    own = out[:, :rng[1] - rng[0]]
+                mark("exchange_waveforms")
+                return finish((own, rng))
+            if world == 1:
+                res = own[:, :ss.n_out]
+                if out is not None:
+                    out.copy_(res)
+                    res = out
+                mark("exchange_waveforms")
+                return finish(res)
+            full = backend.scratch("own_wav", (ss.S, ss.max_len), own.dtype)      # (the tensor `own` is a view of)
+            shards = _all_gather(dist, full, world, comm_dev if comm_dev is not None else full.device, cabi)
+            res = ss.join_shards(shards, out)
+            mark("exchange_waveforms")
+            return finish(res)
         if gather == "range":
             seams = None
             if world > 1:

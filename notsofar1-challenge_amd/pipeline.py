@@ -1,16 +1,23 @@
-"""Session loop around the CSS stage: the thin counterpart of the CSS leg of
+"""Session loop around the CSS stage: the counterpart of the CSS leg of
 ``inference_pipeline/inference.py:37-107``.
 
 The reference iterates the sessions of ``all_session_df`` one by one in a single process
-(``inference.py:59``: "sessions are independent by challenge rule") and reloads the checkpoint for every
-session (``css.py:85``).  Here
+(``inference.py:59-63``: "sessions are independent by challenge rule"), reloads the checkpoint for every
+session (``css.py:85``) and, per session, reads 7 wav files, separates, writes 4 (``css.py:51-107``).  Here
 
 * a rank takes every ``world``-th session (the scheme of the reference's unused ``DDPRowIterator``,
   ``utils/torch_utils.py:48-99``) -- dev-set-1 has 106 multi-channel sessions of ~6 min, which shard better
   by session than by segment;
 * the separator of each model kind (multi-/single-channel) is loaded once per process and stays resident
   in HBM across sessions;
-* everything else -- directory layout, wav naming, cache rule, ``pass_through_ch0`` -- is ``css_inference``.
+* the sessions of a rank go through the library's QUEUE (round 6): ``css_run_enqueue_pcm16`` / ``css_wait``,
+  i.e. the schedule ``bench.py`` times -- queued sessions share mask-estimator batches, a session's PCIe legs
+  hide under its neighbours' kernels, both wav edges (int16 -> float scaling; peak normalisation and PCM16
+  encoding, ``utils/audio_utils.py:37-49``) run on the device -- while worker threads decode the NEXT
+  sessions' wav files into page-locked memory and write the PREVIOUS sessions' four files.  Every file holds
+  what ``css_inference`` writes for that session, bit for bit (``tests/test_hip_session.py``);
+* everything else -- directory layout, wav naming, cache rule, ``pass_through_ch0``, sessions whose files are
+  not mono 16-bit PCM -- is ``css_inference`` itself, one synchronous call per such session.
 
 ASR, diarization and scoring are not part of this package: their inputs are the wav files and the
 ``sep_wav_file_names`` column this loop produces.
@@ -19,11 +26,17 @@ from __future__ import annotations
 
 import logging
 import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
-from .css import CssCfg, css_inference
+import numpy as np
+
+from . import _lib
+from .css import CssCfg, _SessionOutput, css_inference, make_run_cfg
 from .separator import _device_index, load_css_model
+from .wavio import NUM_MICS_MC, read_wav_pcm16, write_pcm16_samples, write_wav
 
 _LOG = logging.getLogger('css')
 
@@ -37,10 +50,84 @@ def _rank_world(rank: Optional[int], world: Optional[int]):
     return rank, world
 
 
+class _PinnedPool:
+    """Page-locked blocks (css_host_alloc) re-used across sessions: allocating 13 MB of page-locked memory takes
+    milliseconds, a session of the queue about nine."""
+
+    def __init__(self):
+        self._free: List[np.ndarray] = []
+        self._lock = threading.Lock()
+
+    def take(self, nbytes: int) -> np.ndarray:
+        with self._lock:
+            fit = [b for b in self._free if b.nbytes >= nbytes]
+            if fit:
+                best = min(fit, key=lambda b: b.nbytes)
+                self._free = [b for b in self._free if b is not best]
+                return best
+        return _lib.pinned_empty((max(int(nbytes * 1.1), 1 << 16),), np.uint8)   # (10 % head room: sessions of similar lengths re-use it)
+
+    def give(self, block: np.ndarray):
+        with self._lock:
+            self._free.append(block)
+            if len(self._free) > 64:
+                self._free.pop(0)
+
+
+class _Loaded:
+    """One session decoded for the queue: its mono PCM16 planes in ONE page-locked block ([C][n] int16)."""
+    __slots__ = ("pos", "session", "where", "sr", "block", "planes", "out_block", "out16", "peaks", "fallback")
+
+
+def _decode_session(pos, session, where, cfg: CssCfg, pool: _PinnedPool) -> _Loaded:
+    ld = _Loaded()
+    ld.pos, ld.session, ld.where, ld.fallback = pos, session, where, False
+    ld.block = ld.planes = ld.out_block = ld.out16 = ld.peaks = None
+    raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
+    same = raw and all(r is not None for r in raw) and len({(r[0].shape[0], r[1]) for r in raw}) == 1
+    if not same:                       # float / multi-channel / 24-bit files, the debug slice: css_inference's own float path
+        ld.fallback = True
+        return ld
+    assert len(raw) == (NUM_MICS_MC if session.is_mc else 1), f'expecting {NUM_MICS_MC} microphones'
+    n, c = raw[0][0].shape[0], len(raw)
+    ld.sr = raw[0][1]
+    ld.block = pool.take(n * c * 2)
+    planes = ld.block[:n * c * 2].view(np.int16).reshape(c, n)
+    for k in range(c):
+        np.copyto(planes[k], raw[k][0])
+    ld.planes = [planes[k] for k in range(c)]
+    return ld
+
+
+def _write_session(ld: _Loaded, n_out: int, pool: _PinnedPool) -> List[str]:
+    """input_mixture.wav + sep_stream{i}.wav of one finished session (css.py:96-106), then its buffers go back to the pool."""
+    mixture = ld.planes[0].astype(np.float32) / np.float32(32768.0)
+    write_wav(ld.where.directory / 'input_mixture.wav', samps=mixture, sr=ld.sr)
+    names = []
+    for i in range(ld.out16.shape[0]):
+        path = ld.where.stream_path(i)
+        _LOG.info(f"CSS: saving separated wav to {path}")
+        write_pcm16_samples(path, ld.out16[i, :n_out], ld.sr)
+        names.append(str(path))
+    pool.give(ld.block)
+    pool.give(ld.out_block)
+    ld.block = ld.planes = ld.out_block = ld.out16 = None
+    return names
+
+
 def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_from_cache: bool = False,
-                 rank: Optional[int] = None, world: Optional[int] = None, device=None):
+                 rank: Optional[int] = None, world: Optional[int] = None, device=None,
+                 queue_depth: int = 12, io_threads: int = 8, max_batch_segments: int = 256, linear_mode: str = "exact_f32",
+                 separators: Optional[Dict[bool, object]] = None):
     """Run CSS on the sessions this rank owns; returns a DataFrame with those rows plus
-    ``sep_wav_file_names`` -- every row is exactly what ``css_inference`` returns for it (css/css.py:51-107)."""
+    ``sep_wav_file_names`` -- every row is exactly what ``css_inference`` returns for it (css/css.py:51-107).
+
+    ``queue_depth``: sessions enqueued between two ``css_wait`` (their page-locked buffers are alive together);
+    ``io_threads``: worker threads that decode the next sessions' wav files and write the finished sessions' files;
+    ``max_batch_segments``: segments per mask-estimator batch of the resident handles (sessions of a queue share batches up
+    to it); ``linear_mode``: see ``HipSeparator`` (default: the reference's float32 operand precision); ``separators``:
+    models already resident on the GPU, ``{is_mc: HipSeparator}`` -- they are used instead of ``models_dir`` and NOT closed
+    (a caller that runs the loop repeatedly, e.g. ``bench.py``'s ``sessions_from_files`` leg)."""
     import dataclasses
     import pandas as pd
     rank, world = _rank_world(rank, world)
@@ -54,19 +141,80 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
         dev_index = int(cfg.device_id)
     device = f"cuda:{dev_index}"
     cfg = dataclasses.replace(cfg, device_id=dev_index)
-    resident: Dict[bool, object] = {}
-    rows = []
+    resident: Dict[bool, object] = dict(separators or {})
+    borrowed = set(resident)
+    positions = list(range(rank, len(sessions_df), world))
+    rows: Dict[int, object] = {}
+    pool = _PinnedPool()
+
+    def model_for(is_mc: bool):
+        if is_mc not in resident:   # one resident model per kind, loaded on first use
+            resident[is_mc], _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if is_mc else cfg.checkpoint_sc),
+                                                device=device, max_batch_segments=max_batch_segments, linear_mode=linear_mode)
+            resident[is_mc].eval()
+        return resident[is_mc]
+
+    io = ThreadPoolExecutor(max_workers=max(int(io_threads), 1), thread_name_prefix="css-io")
     try:
-        for pos in range(rank, len(sessions_df), world):
+        # ---- shortcuts (pass-through, cache hit) are answered at once; the rest is decoded ahead by the worker threads
+        work = []
+        for pos in positions:
             session = sessions_df.iloc[pos]
-            is_mc = bool(session.is_mc)
-            shortcut = cfg.pass_through_ch0 or (fetch_from_cache and (Path(out_dir) / "css_inference" / session.session_id).exists())
-            if not shortcut and is_mc not in resident:   # one resident model per kind, loaded on first use
-                resident[is_mc], _ = load_css_model(Path(models_dir) / (cfg.checkpoint_mc if is_mc else cfg.checkpoint_sc),
-                                                    device=device)
-            _LOG.info(f"CSS [{rank}/{world}] session {session.session_id}")
-            rows.append(css_inference(out_dir, models_dir, session, cfg, fetch_from_cache, separator=resident.get(is_mc)))
+            where = _SessionOutput.plan(out_dir, session, cfg, fetch_from_cache)
+            if where.shortcut is not None:
+                rows[pos] = css_inference(out_dir, models_dir, session, cfg, fetch_from_cache)
+            else:
+                work.append((pos, session, where))
+        ahead = max(2 * int(queue_depth), 2)
+        loads: List = []      # loads[k]: the decode of work[k], submitted in order
+
+        def prefetch(upto):
+            while len(loads) < min(upto, len(work)):
+                j = len(loads)
+                loads.append(io.submit(_decode_session, work[j][0], work[j][1], work[j][2], cfg, pool))
+
+        writes = []
+        k = 0
+        while k < len(work):
+            prefetch(k + ahead)
+            # ---- one queue: up to queue_depth consecutive sessions of ONE model kind (a handle is one model)
+            kind = bool(work[k][1].is_mc)
+            batch: List[_Loaded] = []
+            sep = None
+            while k < len(work) and len(batch) < queue_depth and bool(work[k][1].is_mc) == kind:
+                ld = loads[k].result()
+                prefetch(k + 1 + ahead)
+                if ld.fallback:
+                    if batch:
+                        break     # drain what is queued first, then take this one synchronously
+                    _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id} (float path)")
+                    rows[ld.pos] = css_inference(out_dir, models_dir, ld.session, cfg, fetch_from_cache, separator=model_for(kind))
+                    k += 1
+                    continue
+                sep = model_for(kind)
+                sep.to(device)
+                h, desc = sep.handle, sep.desc
+                run_cfg = make_run_cfg(cfg, ld.sr, len(ld.planes), desc.frame_len, desc.frame_hop)
+                n_out = int(_lib.plan(desc, run_cfg, ld.planes[0].shape[0]).n_out)
+                S = int(desc.num_spks)
+                ld.out_block = pool.take(S * n_out * 2 + 64)
+                ld.out16 = ld.out_block[64:64 + S * n_out * 2].view(np.int16).reshape(S, n_out)
+                ld.peaks = ld.out_block[:4 * S].view(np.float32)
+                _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id}")
+                h.run_enqueue_pcm16(ld.planes, run_cfg, ld.out16, ld.peaks)
+                batch.append(ld)
+                k += 1
+            if batch:
+                sep.handle.wait()
+                for ld in batch:   # the four files of each finished session leave on the worker threads, beside the next queue
+                    writes.append((ld.pos, ld.session, io.submit(_write_session, ld, ld.out16.shape[1], pool)))
+        for pos, session, fut in writes:
+            result = session.copy()
+            result['sep_wav_file_names'] = fut.result()
+            rows[pos] = result
     finally:
-        for sep in resident.values():
-            sep.close()
-    return pd.DataFrame(rows)
+        io.shutdown(wait=True)
+        for kind, sep in resident.items():
+            if kind not in borrowed:
+                sep.close()
+    return pd.DataFrame([rows[p] for p in positions])

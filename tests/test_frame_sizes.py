@@ -113,8 +113,66 @@ def test_hip_path_vs_reference(golden, mc_state, name):
         # the Python drop-in on the same separator object
         wavs, side = CSS.separate_and_stitch(mix, sep, 16000, "cuda:0", css_cfg)
         assert int(side["segment_frames"]) == Ts and np.array_equal(np.stack(wavs), h.run(pcm, run_cfg))
-        # what the other geometry cannot do says so
-        with pytest.raises(L.CssError):
-            h.run_pcm16([np.zeros(pcm.shape[0], np.int16)] * 7, run_cfg)
+        # ---- round 6: the sharded driver for this geometry (the seam carries the synthesis rows of the last ovl - 1 frames): 2, 3 and
+        # 8 virtual ranks, own ranges and the all-gathered whole, bit for bit the fused pass -- in both arithmetic modes
+        from test_hip_parity import virtual_rank_run
+        PAR = pkg("parallel")
+        for mode in ("exact_f32", "split_f16"):
+            h.set_linear_mode(mode)
+            fused = h.run(pcm, run_cfg).copy()
+            for world in (2, 3, 8):
+                assert np.array_equal(virtual_rank_run(PAR, L, h, pcm, run_cfg, world), fused), (mode, world)
+        h.set_linear_mode("exact_f32")
+        # ---- ... and the PCM16 wav edges (css_run_pcm16, css_run_enqueue_pcm16): bit for bit load_audio -> css_run -> write_wav
+        q16 = np.clip(np.rint(pcm * 0.2 * 32768.0), -32768, 32767).astype(np.int16)
+        planes = [np.ascontiguousarray(q16[:, c]) for c in range(7)]
+        fl32 = np.ascontiguousarray(q16.astype(np.float32) / np.float32(32768.0))
+        wav = h.run(fl32, run_cfg)
+        got16, peaks = h.run_pcm16(planes, run_cfg)
+        for i in range(S):
+            assert peaks[i] == np.max(np.abs(wav[i]))
+            y = wav[i] * 0.99 / (np.max(np.abs(wav[i])) + 1e-7)                         # utils/audio_utils.py:44-45
+            assert np.array_equal(got16[i], np.clip(np.rint(y.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16))
+        pl16 = L.pinned_empty((7, q16.shape[0]), np.int16)
+        pl16[:] = q16.T
+        o16, pk = L.pinned_empty(got16.shape, np.int16), L.pinned_empty((S,), np.float32)
+        h.run_enqueue_pcm16([pl16[c] for c in range(7)], run_cfg, o16, pk)
+        h.wait()
+        assert np.array_equal(o16, got16) and np.array_equal(pk, peaks)
+    finally:
+        sep.close()
+
+
+@pytest.mark.gpu
+def test_enqueue_of_another_frame_size_applies_the_range_rule(mc_state, golden):
+    """on a handle with frame_len / hop other than 512 / 256 css_run_enqueue runs the pass inside the call; a pass
+    that leaves the split-f16 range must be repeated in float32 (or refused with CSS_ERR_RANGE) there, as css_run does."""
+    L, CSS, SEP = pkg("_lib"), pkg("css"), pkg("separator")
+    g = golden("frames_r5.npz")
+    st = dict(mc_state[0])
+    key = pkg("weights").PREFIX + "conformer.encoders.0.feed_forward_in.net.0.weight"
+    st[key] = np.asarray(st[key], np.float32) * np.float32(3e5)          # ReLU outputs past 65504: the next split operand overflows
+    cfg = SEP.ConformerCssCfg(extractor_conf=SEP.ExtractorCfg(frame_len=400, frame_hop=160),
+                              nnet_conf=SEP.NnetCfg(conformer_conf=SEP.ConformerCfg(attention_dim=512, attention_heads=8, num_blocks=18, dropout_rate=0.0)))
+    sep = SEP.HipSeparator(st, cfg, device=0, max_batch_segments=16, linear_mode="split_f16")
+    try:
+        h = sep.handle
+        run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7, 400, 160)
+        pcm = L.pinned_copy(np.ascontiguousarray(_mix(g)[0, :6 * 16000]))
+        h.set_linear_mode("exact_f32")
+        ref = h.run(pcm, run_cfg).copy()
+        h.set_linear_mode("split_f16")
+        before = h.range_status()[0]
+        out = L.pinned_empty(ref.shape, np.float32)
+        out[:] = np.nan
+        h.run_enqueue(pcm, run_cfg, out)
+        h.wait()
+        assert h.range_status() == (before + 1, True) and h.linear_mode() == "split_f16"
+        assert np.array_equal(out, ref)                                   # the float32 repeat's result, bit for bit
+        h.set_range_fallback(False)
+        with pytest.raises(L.CssError) as e:
+            h.run_enqueue(pcm, run_cfg, out)
+        assert e.value.code == L.CSS_ERR_RANGE
+        h.wait()
     finally:
         sep.close()

@@ -74,6 +74,8 @@ def virtual_rank_run(PAR, L, h, pcm, run_cfg, world, poison=False):
     be = PAR.HipShardBackend(h, dev)
     n, c = pcm.shape
     T, hop = int(run_cfg.c.segment_frames), int(run_cfg.c.hop_frames)
+    if int(h.desc.frame_len) != 2 * int(h.desc.frame_hop):
+        return _virtual_rank_run_general(PAR, L, h, be, pcm, run_cfg, world, torch)
     pieces = {0: [], 1: [], 2: []}
     ss = None
     for phase in range(3):
@@ -106,6 +108,50 @@ def virtual_rank_run(PAR, L, h, pcm, run_cfg, world, poison=False):
                 assert lo == edge and tuple(own.shape) == (S, hi - lo) and torch.equal(own, out[:, lo:hi]), (r, lo, hi)
                 edge = hi
             assert edge == out.shape[1]
+    pieces.clear()
+    be.close()
+    return out.numpy()
+
+
+def _virtual_rank_run_general(PAR, L, h, be, pcm, run_cfg, world, torch):
+    """virtual_rank_run for frame geometries other than frame_len = 2 hop: exchange 3 carries the synthesis rows of a rank's
+    last ovl - 1 frames (parallel.py), every rank finishes its own range with the single-GPU overlap-add; both gathers."""
+    n, c = pcm.shape
+    T, hop = int(run_cfg.c.segment_frames), int(run_cfg.c.hop_frames)
+    fl, fh, S_ = int(h.desc.frame_len), int(h.desc.frame_hop), int(h.desc.num_spks)
+    mk = lambda r: PAR.ShardedSession(be, S_, T, hop, fh, r, world, frame_len=fl)
+    pieces = {0: [], 1: [], 2: [], 3: []}
+    ss = None
+    for phase in range(4):
+        for r in range(world):
+            h.begin(pcm, n, c, run_cfg)
+            ss = mk(r)
+            assert ss.general and ss.K == -(-fl // fh) - 1
+            piece = ss.segments_and_costs()
+            if phase >= 1:
+                piece = ss.masks_and_activity(torch.stack(pieces[0]) if world > 1 else None)
+            if phase >= 2:
+                piece = ss.gate_and_istft(torch.stack(pieces[1]) if world > 1 else None)
+            if phase >= 3:
+                piece = ss.finish_range(None, torch.stack(pieces[2]))
+            with be.on_stream():
+                pieces[phase].append(piece.clone() if piece is not None else None)
+    with be.on_stream():
+        # gather="range": the ranks' finished ranges tile the output
+        edge, parts = 0, []
+        for r in range(world):
+            lo, hi = mk(r).own_range()
+            assert lo == edge and tuple(pieces[3][r].shape) == (S_, hi - lo), (r, lo, hi, pieces[3][r].shape)
+            parts.append(pieces[3][r])
+            edge = hi
+        out = torch.cat(parts, dim=1)
+        assert edge == ss.n_out == out.shape[1]
+        # gather="all": the padded finished ranges, all-gathered and placed
+        padded = torch.zeros((world, S_, ss.max_len), dtype=torch.float32, device=out.device)
+        for r in range(world):
+            padded[r, :, :parts[r].shape[1]] = parts[r]
+        assert torch.equal(ss.join_shards(padded), out)
+        out = out.cpu()
     pieces.clear()
     be.close()
     return out.numpy()

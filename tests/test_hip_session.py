@@ -203,6 +203,99 @@ def test_pcm16_wav_edges_on_device_are_bit_exact(tmp_path, tiny_models):
     assert back[1] == 16000 and np.array_equal(back[0], pcm16[0])
 
 
+@pytest.mark.parametrize("mode", ["exact_f32", "split_f16"])
+def test_queued_pcm16_sessions_equal_css_run_pcm16(mc_state, mode):
+    """css_run_enqueue_pcm16 (round 6): sessions as mono PCM16 planes through the QUEUE -- sharing estimator batches with each
+    other and with float sessions of the same queue, page-locked or pageable -- give, each, the bits of its own synchronous
+    css_run_pcm16 (samples and peaks); the full 18-block estimator keeps the host passes ahead of the device."""
+    css, L = pkg("css"), pkg("_lib")
+    st, desc = mc_state
+    mk = lambda **kw: css.make_run_cfg(css.CssCfg(show_progressbar=False, **kw), 16000, 7)
+    cfgs = [mk(activity_th=0.3), mk(activity_th=0.45), mk(activity_th=0.3, stitching_loss="mse"), mk(activity_th=0.3), mk(activity_th=0.3)]
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=128, linear_mode=mode)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([33.0, 20.0, 41.0, 12.3, 27.0]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=800 + k)[0, :int(seconds * 16000) - 29 * k]
+            q = np.clip(np.rint(mix * (0.05 if k % 2 else 0.2) * 32768.0), -32768, 32767).astype(np.int16)      # [n, 7]
+            block = L.pinned_empty((7, q.shape[0]), np.int16)
+            block[:] = q.T
+            planes = [block[c] for c in range(7)]
+            ref16, refpk = h.run_pcm16(planes, cfgs[k])
+            f32 = np.ascontiguousarray(q.astype(np.float32) / np.float32(32768.0))
+            sessions.append((planes, cfgs[k], ref16.copy(), refpk.copy(), L.pinned_copy(f32), h.run(f32, cfgs[k]).copy(), block))
+        for pinned_out in (True, False):
+            for rounds in range(2):
+                got = []
+                for k, (planes, cfg, ref16, refpk, f32, reff, _) in enumerate(sessions):
+                    o16 = (L.pinned_empty if pinned_out else np.empty)(ref16.shape, np.int16)
+                    pk = (L.pinned_empty if pinned_out else np.empty)((3,), np.float32)
+                    o16[:] = -1
+                    a = h.run_enqueue_pcm16(planes, cfg, o16, pk)
+                    b = None
+                    if k % 2 == 0:            # a float session of the same queue in between
+                        of = L.pinned_empty(reff.shape, np.float32)
+                        of[:] = np.nan
+                        b = h.run_enqueue(f32, cfg, of)
+                    got.append((a, pk, b))
+                h.wait()
+                for k, ((a, pk, b), (_, _, ref16, refpk, _, reff, _)) in enumerate(zip(got, sessions)):
+                    assert np.array_equal(a, ref16), (mode, pinned_out, rounds, k)
+                    assert np.array_equal(pk, refpk), (mode, pinned_out, rounds, k)
+                    assert b is None or np.array_equal(b, reff), (mode, pinned_out, rounds, k)
+        with pytest.raises(L.CssError):       # a null plane is refused when the session is queued
+            import ctypes as C
+            ptrs = (C.c_void_p * 7)(*([sessions[0][0][0].ctypes.data] * 6 + [None]))
+            o16 = L.pinned_empty(sessions[0][2].shape, np.int16)
+            L.check(h.h, h.lib.css_run_enqueue_pcm16(h.h, ptrs, sessions[0][0][0].shape[0], 7, C.byref(cfgs[0].c), o16.ctypes.data_as(C.c_void_p),
+                                                     o16.shape[1], None))
+        h.wait()
+    finally:
+        sep.close()
+
+
+def test_session_loop_through_the_queue_equals_css_inference(tmp_path, tiny_models):
+    """pipeline.css_sessions (the queue: css_run_enqueue_pcm16 / css_wait, wav decode and file writes on worker threads) against
+    css_inference called session by session as the reference's loop does (inference.py:59-63): the same files, byte for byte,
+    the same rows -- MC and SC sessions interleaved, more sessions than one queue holds, one session that is NOT 16-bit PCM
+    (float path inside the loop), the mode opt-in passed through."""
+    import filecmp
+    import pandas as pd
+    css, wavio, pipe, sep_mod = pkg("css"), pkg("wavio"), pkg("pipeline"), pkg("separator")
+    models_dir, models = tiny_models
+    mix = (pkg("synth").synth_meeting(9.0, 7, seed=31) * 0.25).astype(np.float32)
+    rows = []
+    for i in range(7):
+        is_mc = i not in (2, 5)
+        part = mix[:, 4000 * i: 4000 * i + 70000 + 3000 * i, : (7 if is_mc else 1)]
+        rows.append(_write_session(tmp_path, wavio, part, f"Q{i}_{'mc' if is_mc else 'sc'}", is_mc))
+    # session 3's channel 0 as a 32-bit float wav: not the PCM16 edge's case (css.py::css_inference takes load_audio for it)
+    import struct
+    x = mix[0, 12000:12000 + 79000, 0].astype("<f4")
+    payload = x.tobytes()
+    with open(rows[3]["wav_file_names"][0], "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32) +
+                b"data" + struct.pack("<I", len(payload)) + payload)
+    df = pd.DataFrame(rows)
+    cfg = css.CssCfg(activity_th=0.3, show_progressbar=False)
+    for mode in ("exact_f32", "split_f16"):
+        got = pipe.css_sessions(str(tmp_path / f"queue_{mode}"), models_dir, df, cfg, queue_depth=3, io_threads=3, linear_mode=mode)
+        assert list(got.session_id) == list(df.session_id) and list(got.columns) == list(df.columns) + ["sep_wav_file_names"]
+        resident = {k: sep_mod.load_css_model(os.path.join(models_dir, "notsofar", "conformer1.0", "mc" if k else "sc"), linear_mode=mode)[0] for k in (True, False)}
+        try:
+            for (_, row), (_, grow) in zip(df.iterrows(), got.iterrows()):
+                one = css.css_inference(str(tmp_path / f"single_{mode}"), models_dir, row, cfg, False, separator=resident[bool(row.is_mc)])
+                assert [os.path.basename(a) for a in one["sep_wav_file_names"]] == [os.path.basename(a) for a in grow["sep_wav_file_names"]]
+                for a, b in zip(one["sep_wav_file_names"], grow["sep_wav_file_names"]):
+                    assert filecmp.cmp(a, b, shallow=False), (mode, row.session_id, a)
+                assert filecmp.cmp(os.path.join(os.path.dirname(one["sep_wav_file_names"][0]), "input_mixture.wav"),
+                                   os.path.join(os.path.dirname(grow["sep_wav_file_names"][0]), "input_mixture.wav"), shallow=False)
+        finally:
+            for sep in resident.values():
+                sep.close()
+
+
 def test_device_handoff_to_whisper_front_end(tiny_models):
     """SURVEY.md 8f N4 (css.py:313 "drop silent parts to save ASR compute"): after a device-resident pass, each
     stream's active regions -- the time map -- and Whisper's log-mel features of their concatenation, computed on the
