@@ -273,6 +273,14 @@ int css_run_enqueue(css_handle_t h, const float* pcm_host, int64_t n_samples, in
 int css_set_queue_group(css_handle_t h, int max_sessions);
 /* Blocks until every pass queued on h has finished (results in their wav_host buffers); CssTimings describe the last. */
 int css_wait(css_handle_t h);
+/* Blocks until the FIRST n sessions queued since the last css_wait have finished -- their outputs are in host memory -- and
+ * leaves the later ones running (round 6: a session loop hands finished sessions to its file writers and keeps enqueueing
+ * without ever draining the device; inference_pipeline/inference.py:59-63).  Sessions still held back for company are put on
+ * the streams first.  It is NOT a css_wait: the queue's bookkeeping, the CssTimings and -- in CSS_LINEAR_SPLIT_F16 mode -- the
+ * range verdict stay with css_wait, which may still repeat a session in float32 from the caller's input buffers; so in that
+ * mode the inputs and outputs of a session stay the library's until css_wait, in CSS_LINEAR_EXACT_F32 (no repeat exists) they
+ * are the caller's again once css_wait_sessions has returned for it. */
+int css_wait_sessions(css_handle_t h, int64_t n);
 /* Same with input and output resident in HBM (pcm_dev [n_samples][n_ch], wav_dev [S][n_out]). */
 int css_run_device(css_handle_t h, const float* pcm_dev, int64_t n_samples, int32_t n_ch, const CssRunCfg* cfg,
                    float* wav_dev, int64_t wav_capacity_per_stream);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_enqueue": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_wait": (C.c_int, [_P]),
+    "css_wait_sessions": (C.c_int, [_P, C.c_int64]),
     "css_run_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
     "css_run_enqueue_pcm16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64, _P]),
@@ -384,6 +385,12 @@ class Handle:
             check(self.h, self.lib.css_wait(self.h))
         finally:
             self._queued_keep = []
+
+    def wait_sessions(self, n: int):
+        """Blocks until the first `n` sessions queued since the last wait() have finished (outputs in host memory); the later
+        ones keep running.  Not a wait(): call that eventually (it releases the references this object keeps, and in
+        "split_f16" mode it is where a session that left the operand range is repeated -- from its input buffers)."""
+        check(self.h, self.lib.css_wait_sessions(self.h, int(n)))
 
     def run_device(self, pcm_ptr: int, n: int, c: int, cfg: RunCfg, wav_ptr: int, cap: int):
         check(self.h, self.lib.css_run_device(self.h, C.c_void_p(pcm_ptr), n, c, C.byref(cfg.c),

@@ -198,6 +198,11 @@ struct css_ctx : SessState {
                      std::vector<const int16_t*> planes; int16_t* wav16 = nullptr; float* peaks = nullptr; };   // PCM16 edges: pcm == wav == nullptr
     std::vector<Pending> pending;
     int64_t pending_segments = 0;
+    // css_wait_sessions: one event per session put on the streams since the last css_wait, in queue order, recorded behind the
+    // session's last output copy (nullptr: the session had finished inside its call)
+    std::vector<hipEvent_t> sess_done;
+    std::vector<hipEvent_t> sess_ev_pool;
+    size_t sess_ev_used = 0;
     void* comm = nullptr;          // ncclComm_t of css_comm_init (RCCL, loaded lazily)
     int comm_ranks = 0, comm_rank = -1;
     struct PendingUpload { int64_t s_lo, s_hi; hipEvent_t landed; };
@@ -840,6 +845,7 @@ int css_destroy(css_handle_t h) {
     if (h->range_flag_dev) hipFree(h->range_flag_dev);
     if (h->range_flag_host) hipHostFree(h->range_flag_host);
     for (auto& e : h->ev_pool) hipEventDestroy(e);
+    for (auto& e : h->sess_ev_pool) hipEventDestroy(e);
     if (h->wsplit) hipFree(h->wsplit);
     if (h->wfrag) hipFree(h->wfrag);
     if (h->dft_split) hipFree(h->dft_split);
@@ -1592,6 +1598,18 @@ static void* mapped_host(const void* p) {
     return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
 }
 
+// the completion event of the session whose last output copy was just enqueued on `st` (css_wait_sessions)
+static void mark_session_done(css_ctx* h, hipStream_t st) {
+    if (h->sess_ev_used == h->sess_ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->sess_ev_pool.push_back(e);
+    }
+    hipEvent_t e = h->sess_ev_pool[h->sess_ev_used++];
+    hipEventRecord(e, st);
+    h->sess_done.push_back(e);
+}
+
 static hipEvent_t pool_event(css_ctx* h) {
     if (h->ev_pool_used == h->ev_pool.size()) {
         hipEvent_t e = nullptr;
@@ -1995,6 +2013,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
         HIPCHK(h, hipEventRecord(h->level_free[par], h->tail_stream));
         HIPCHK(h, hipEventRecord(h->pass_end[h->pass_no & 3], h->tail_stream));
         hipEventRecord(h->ev[7], h->tail_stream);
+        mark_session_done(h, h->tail_stream);
         h->tail_pending = true;
         h->pass_no += 1;
         h->queued += 1;
@@ -2020,6 +2039,7 @@ static int run_once(css_handle_t h, int64_t n, int32_t n_ch, const CssRunCfg* cf
     hipEventRecord(h->ev[7], h->stream);
     const auto host_t1 = std::chrono::steady_clock::now();
     if (io.enqueue_only) {   // css_wait synchronises, reads the range word and the timings of the last queued pass
+        mark_session_done(h, h->stream);
         h->queued += 1;
         HIPCHK(h, hipGetLastError());
         return CSS_OK;
@@ -2274,6 +2294,7 @@ static int run_group(css_handle_t h, std::vector<css_ctx::Pending>& grp) {
         } else {
             wave_ola_on(h, 0, TL, 0, TL + 1, q.wav_mapped, q.cap, 0, ts);
         }
+        mark_session_done(h, ts);
         h->perms_done = true;
     }
     hipEventRecord(h->ev[6], ts);
@@ -2376,7 +2397,9 @@ static int enqueue_impl(css_handle_t h, const float* pcm_host, const int16_t* co
         // Frame sizes other than 512 / 256 run the plain stage sequence to its end inside the call (run_once): nothing stays
         // queued, so css_wait would never look at the range word.  The pass therefore takes css_run's own rule here -- queued
         // passes first, then this one, repeated in float32 or refused with CSS_ERR_RANGE when it left the split-f16 range.
-        return run_impl(h, n_samples, n_ch, cfg, io_of(false));
+        rc = run_impl(h, n_samples, n_ch, cfg, io_of(false));
+        if (rc == CSS_OK) h->sess_done.push_back(nullptr);   // (finished inside the call)
+        return rc;
     }
     if (!groupable) {
         if ((rc = flush_pending(h)) != CSS_OK) return rc;
@@ -2439,7 +2462,7 @@ int css_wait(css_handle_t h) {
         const int rc_flush = flush_pending(h);
         if (rc_flush != CSS_OK) { h->queue_log.clear(); return rc_flush; }
     }
-    if (!h->queued) { h->queue_log.clear(); return CSS_OK; }
+    if (!h->queued) { h->queue_log.clear(); h->sess_done.clear(); h->sess_ev_used = 0; return CSS_OK; }
     HIPCHK(h, hipSetDevice(h->device));
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2449,6 +2472,8 @@ int css_wait(css_handle_t h) {
     HIPCHK(h, hipGetLastError());
     const auto t1 = std::chrono::steady_clock::now();
     h->queued = 0;
+    h->sess_done.clear();
+    h->sess_ev_used = 0;
     h->tail_pending = false;
     h->last_piped = -1;
     h->pass_no = 0;
@@ -2481,6 +2506,22 @@ int css_wait(css_handle_t h) {
                                    std::to_string(log.size()) + " (sessions before it hold their float32 results, it and the later ones do not): " + why);
         return rc2;
     }
+    return CSS_OK;
+}
+
+int css_wait_sessions(css_handle_t h, int64_t n) {
+    if (!h || n < 0) return fail(h, CSS_ERR_INVALID_ARG, "bad argument");
+    if (n == 0) return CSS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((int64_t)h->sess_done.size() < n && !h->pending.empty()) {   // sessions still held back for company: off they go
+        const int rc = flush_pending(h);
+        if (rc != CSS_OK) return rc;
+    }
+    if ((int64_t)h->sess_done.size() < n)
+        return fail(h, CSS_ERR_INVALID_ARG, "css_wait_sessions(" + std::to_string(n) + "): only " + std::to_string(h->sess_done.size()) +
+                                                " sessions have been queued since the last css_wait");
+    for (int64_t i = 0; i < n; ++i)
+        if (h->sess_done[(size_t)i]) HIPCHK(h, hipEventSynchronize(h->sess_done[(size_t)i]));
     return CSS_OK;
 }
 

@@ -83,6 +83,11 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 #ifndef F32_SPREAD
 #define F32_SPREAD 1   // the next slab's global loads one per two MFMA groups of this slab instead of as a burst in front of it
 #endif
+#ifndef F32_TRANSPOSED
+#define F32_TRANSPOSED 0   // 1: the MFMA operands swapped (weights first): the accumulators hold the tile TRANSPOSED -- lane = token row,
+                           // a register group = four consecutive output features -- and the fast epilogue stores 16-byte pieces
+                           // straight from the registers, no turn through the LDS patch (same products, same bits)
+#endif
 #ifndef F32_DMA
 #define F32_DMA 0   // 1: global -> LDS by the DMA path (buffer_load ... lds), unpadded 64-byte LDS rows with an XOR swizzle
 #endif
@@ -185,12 +190,22 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, fast ? (int)((int64_t)M * ldc * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res), 0, (fast && has_res) ? (int)((int64_t)M * ldr * 4) : 0, 0x00020000);
     f32x4 rv[2][4];   // residual pieces of the tile being written and of the next one
+#if F32_TRANSPOSED
+    // (accumulator layout: lane (c, h) = token row m0 + 32 i + c, registers 4 q .. 4 q + 3 = features n0 + 32 w + 8 q + 4 h .. + 3)
+    auto prefetch_fast = [&](int i, int slot, int lane_) {
+        const int vo_ = (int)((((int64_t)m0 + (lane_ & 31)) * ldr + n0 + 32 * w + 4 * (lane_ >> 5)) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rv[slot][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_, (int)((32 * i * ldr + 8 * q) * 4), 0));
+    };
+#else
     auto prefetch_fast = [&](int i, int slot, int lane_) {
         const int vo_ = (int)((((int64_t)m0 + (lane_ >> 3)) * ldr + n0 + 32 * w + (lane_ & 7) * 4) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             rv[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_, (int)((32 * i + 8 * j) * ldr * 4), 0));
     };
+#endif
     // (lane_ is `lane` behind a compiler barrier at the call sites below: the 64-bit row addresses of the epilogue must
     // not be formed before the K loop and carried through it -- the loop has no registers to spare)
     auto prefetch = [&](int i, int slot, int lane_) {
@@ -232,6 +247,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
                 if (F32_SPREAD && spread_k0 >= 0 && !(e & 1)) { F32_GLOAD1(spread_k0, ch * 2 + (e >> 1)) __builtin_amdgcn_sched_barrier(0); } \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
                     if (F32_ABLATE & 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i][e]), "v"(b[e])); \
+                    else if (F32_TRANSPOSED) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], a[i][e], acc[i], 0, 0, 0); \
                     else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[e], acc[i], 0, 0, 0);          \
                 }                                                                                                \
                 if (F32_SPREAD && spread_k0 >= 0) __builtin_amdgcn_sched_barrier(0);                             \
@@ -313,6 +329,53 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) bn[e] = bias[n + e < N ? n + e : N - 1];
     }
+#if F32_TRANSPOSED
+    if (fast) {
+        // The accumulators hold the tile transposed (see F32_COMPUTE): a lane's four registers of a group are four consecutive
+        // output features of ITS token row -- a 16-byte piece of the output row as it stands.  No turn through LDS.
+        const int ce = lane_e & 31, he = lane_e >> 5, nw = n0 + 32 * w + 4 * he;
+        const int voC = (int)((((int64_t)m0 + ce) * ldc + nw) * 4);
+        const bool relu = act == ACT_RELU;
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias_n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[q][e] = bias[nw + 8 * q + e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i + 1 < TM && has_res) prefetch_fast(i + 1, (i + 1) & 1, lane_e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][4 * q + e] + bq[q][e];
+                    if (relu) t = fmaxf(t, 0.f);
+                    if (has_res) t = rv[i & 1][q][e] + alpha * t;
+                    o[e] = t;
+                }
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voC, (int)((32 * i * ldc + 8 * q) * 4), 0);
+#if F32_TRANSPOSED >= 2
+                // the store reads its four data registers AFTER it has issued; the next piece's first VALU result must not land in
+                // them before that (tools/store_war_probe.hip: more wait states than the compiler's hazard table pads on gfx950)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+#if F32_TRANSPOSED >= 3
+                asm volatile("s_nop 7");
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+        F32_EPILOGUE_PROBE
+        return;
+    }
+#else
     if (fast) {
         const int voC = (int)((((int64_t)m0 + erow) * ldc + n) * 4);
         const bool relu = act == ACT_RELU;
@@ -339,10 +402,18 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
         F32_EPILOGUE_PROBE
         return;
     }
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+#if F32_TRANSPOSED
+        // (the transposed accumulator: lane c is token row c of the patch, a register group four consecutive columns)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(patch + c * F_PATCH_LD + 8 * q + 4 * h) = f32x4{acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * F_PATCH_LD + c] = acc[i][r];
+#endif
         // (a wave's own LDS writes and reads are in order: no barrier)
         if (i + 1 < TM) prefetch(i + 1, (i + 1) & 1, lane_e);   // (the registers of acc[i] are free now)
 #pragma unroll

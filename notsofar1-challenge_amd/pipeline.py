@@ -70,8 +70,15 @@ class _PinnedPool:
     def give(self, block: np.ndarray):
         with self._lock:
             self._free.append(block)
-            if len(self._free) > 64:
+            while len(self._free) > 96 or sum(b.nbytes for b in self._free) > (4 << 30):
                 self._free.pop(0)
+
+    def clear(self):
+        with self._lock:
+            self._free = []
+
+
+_POOL = _PinnedPool()   # process-wide: a second css_sessions call (or a long one) finds the blocks of the sessions before
 
 
 class _Loaded:
@@ -96,13 +103,15 @@ def _decode_session(pos, session, where, cfg: CssCfg, pool: _PinnedPool) -> _Loa
     for k in range(c):
         np.copyto(planes[k], raw[k][0])
     ld.planes = [planes[k] for k in range(c)]
+    # input_mixture.wav (css.py:96-97: channel 0, peak-normalised) needs nothing from the GPU: written here, off the loop's tail
+    mixture = planes[0].astype(np.float32) / np.float32(32768.0)
+    write_wav(where.directory / 'input_mixture.wav', samps=mixture, sr=ld.sr)
     return ld
 
 
 def _write_session(ld: _Loaded, n_out: int, pool: _PinnedPool) -> List[str]:
-    """input_mixture.wav + sep_stream{i}.wav of one finished session (css.py:96-106), then its buffers go back to the pool."""
-    mixture = ld.planes[0].astype(np.float32) / np.float32(32768.0)
-    write_wav(ld.where.directory / 'input_mixture.wav', samps=mixture, sr=ld.sr)
+    """sep_stream{i}.wav of one finished session (css.py:98-106; input_mixture.wav left with the decode), then its buffers go
+    back to the pool."""
     names = []
     for i in range(ld.out16.shape[0]):
         path = ld.where.stream_path(i)
@@ -117,17 +126,20 @@ def _write_session(ld: _Loaded, n_out: int, pool: _PinnedPool) -> List[str]:
 
 def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_from_cache: bool = False,
                  rank: Optional[int] = None, world: Optional[int] = None, device=None,
-                 queue_depth: int = 12, io_threads: int = 8, max_batch_segments: int = 256, linear_mode: str = "exact_f32",
-                 separators: Optional[Dict[bool, object]] = None):
+                 queue_depth: int = 12, io_threads: int = 4, max_batch_segments: int = 256, linear_mode: str = "exact_f32",
+                 separators: Optional[Dict[bool, object]] = None, stats: Optional[dict] = None):
     """Run CSS on the sessions this rank owns; returns a DataFrame with those rows plus
     ``sep_wav_file_names`` -- every row is exactly what ``css_inference`` returns for it (css/css.py:51-107).
 
-    ``queue_depth``: sessions enqueued between two ``css_wait`` (their page-locked buffers are alive together);
-    ``io_threads``: worker threads that decode the next sessions' wav files and write the finished sessions' files;
+    ``queue_depth``: sessions the loop waits for at a time; up to twice as many are in flight (their page-locked buffers
+    are alive together);
+    ``io_threads``: worker threads that decode the next sessions' wav files and write the finished sessions' files (4: more
+    of them only contend with the enqueueing thread for the interpreter -- 8 and 16 measured slower, tools/session_loop_probe.py);
     ``max_batch_segments``: segments per mask-estimator batch of the resident handles (sessions of a queue share batches up
     to it); ``linear_mode``: see ``HipSeparator`` (default: the reference's float32 operand precision); ``separators``:
     models already resident on the GPU, ``{is_mc: HipSeparator}`` -- they are used instead of ``models_dir`` and NOT closed
-    (a caller that runs the loop repeatedly, e.g. ``bench.py``'s ``sessions_from_files`` leg)."""
+    (a caller that runs the loop repeatedly, e.g. ``bench.py``'s ``sessions_from_files`` leg); ``stats``: a dict that receives
+    where the loop's wall time went (seconds: until the first session was on the queue, inside css_wait, after the last css_wait)."""
     import dataclasses
     import pandas as pd
     rank, world = _rank_world(rank, world)
@@ -145,7 +157,7 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
     borrowed = set(resident)
     positions = list(range(rank, len(sessions_df), world))
     rows: Dict[int, object] = {}
-    pool = _PinnedPool()
+    pool = _POOL
 
     def model_for(is_mc: bool):
         if is_mc not in resident:   # one resident model per kind, loaded on first use
@@ -154,6 +166,10 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
             resident[is_mc].eval()
         return resident[is_mc]
 
+    import time
+    t_start = time.perf_counter()
+    t_first = t_wait = 0.0
+    t_last_wait = t_start
     io = ThreadPoolExecutor(max_workers=max(int(io_threads), 1), thread_name_prefix="css-io")
     try:
         # ---- shortcuts (pass-through, cache hit) are answered at once; the rest is decoded ahead by the worker threads
@@ -174,46 +190,81 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
                 loads.append(io.submit(_decode_session, work[j][0], work[j][1], work[j][2], cfg, pool))
 
         writes = []
+        # ---- the queue as a rolling window: sessions are enqueued as their decodes arrive; once 2 x queue_depth are in flight the
+        # loop waits for the OLDEST queue_depth (css_wait_sessions: the younger ones keep the device busy), hands them to the file
+        # writers and goes on enqueueing.  A full css_wait closes a window when the model kind changes (another handle), a session
+        # takes the float path, every 16 x queue_depth sessions (the handle's bookkeeping) and at the end.  In "split_f16" mode a
+        # css_wait may repeat a session in float32 from its input buffers, so there nothing is released before a full css_wait.
+        rolling = linear_mode == "exact_f32"
+        inflight: List[_Loaded] = []      # queued on `cur` since its last full css_wait, oldest first
+        released = 0                      # how many of them have been handed to the writers
+        cur = None                        # the separator whose queue is open
+
+        def hand_over(upto):
+            nonlocal released
+            for ld in inflight[released:upto]:
+                writes.append((ld.pos, ld.session, io.submit(_write_session, ld, ld.out16.shape[1], pool)))
+            released = max(released, upto)
+
+        def close_window():
+            nonlocal inflight, released, cur, t_wait, t_last_wait
+            if cur is not None and inflight:
+                t0 = time.perf_counter()
+                cur.handle.wait()
+                t_last_wait = time.perf_counter()
+                t_wait += t_last_wait - t0
+                hand_over(len(inflight))
+            inflight, released, cur = [], 0, None
+
         k = 0
         while k < len(work):
             prefetch(k + ahead)
-            # ---- one queue: up to queue_depth consecutive sessions of ONE model kind (a handle is one model)
+            ld = loads[k].result()
+            prefetch(k + 1 + ahead)
             kind = bool(work[k][1].is_mc)
-            batch: List[_Loaded] = []
-            sep = None
-            while k < len(work) and len(batch) < queue_depth and bool(work[k][1].is_mc) == kind:
-                ld = loads[k].result()
-                prefetch(k + 1 + ahead)
-                if ld.fallback:
-                    if batch:
-                        break     # drain what is queued first, then take this one synchronously
-                    _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id} (float path)")
-                    rows[ld.pos] = css_inference(out_dir, models_dir, ld.session, cfg, fetch_from_cache, separator=model_for(kind))
-                    k += 1
-                    continue
-                sep = model_for(kind)
-                sep.to(device)
-                h, desc = sep.handle, sep.desc
-                run_cfg = make_run_cfg(cfg, ld.sr, len(ld.planes), desc.frame_len, desc.frame_hop)
-                n_out = int(_lib.plan(desc, run_cfg, ld.planes[0].shape[0]).n_out)
-                S = int(desc.num_spks)
-                ld.out_block = pool.take(S * n_out * 2 + 64)
-                ld.out16 = ld.out_block[64:64 + S * n_out * 2].view(np.int16).reshape(S, n_out)
-                ld.peaks = ld.out_block[:4 * S].view(np.float32)
-                _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id}")
-                h.run_enqueue_pcm16(ld.planes, run_cfg, ld.out16, ld.peaks)
-                batch.append(ld)
+            if ld.fallback:
+                close_window()
+                _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id} (float path)")
+                rows[ld.pos] = css_inference(out_dir, models_dir, ld.session, cfg, fetch_from_cache, separator=model_for(kind))
                 k += 1
-            if batch:
-                sep.handle.wait()
-                for ld in batch:   # the four files of each finished session leave on the worker threads, beside the next queue
-                    writes.append((ld.pos, ld.session, io.submit(_write_session, ld, ld.out16.shape[1], pool)))
+                continue
+            sep = model_for(kind)
+            if cur is not sep or len(inflight) >= 16 * queue_depth:
+                close_window()
+                cur = sep
+            sep.to(device)
+            h, desc = sep.handle, sep.desc
+            run_cfg = make_run_cfg(cfg, ld.sr, len(ld.planes), desc.frame_len, desc.frame_hop)
+            n_out = int(_lib.plan(desc, run_cfg, ld.planes[0].shape[0]).n_out)
+            S = int(desc.num_spks)
+            ld.out_block = pool.take(S * n_out * 2 + 64)
+            ld.out16 = ld.out_block[64:64 + S * n_out * 2].view(np.int16).reshape(S, n_out)
+            ld.peaks = ld.out_block[:4 * S].view(np.float32)
+            _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id}")
+            h.run_enqueue_pcm16(ld.planes, run_cfg, ld.out16, ld.peaks)
+            if not t_first:
+                t_first = time.perf_counter() - t_start
+            inflight.append(ld)
+            k += 1
+            if rolling and len(inflight) - released >= 2 * queue_depth:
+                t0 = time.perf_counter()
+                h.wait_sessions(released + queue_depth)
+                t_last_wait = time.perf_counter()
+                t_wait += t_last_wait - t0
+                hand_over(released + queue_depth)
+            elif not rolling and len(inflight) >= queue_depth:
+                close_window()
+        close_window()
         for pos, session, fut in writes:
             result = session.copy()
             result['sep_wav_file_names'] = fut.result()
             rows[pos] = result
     finally:
         io.shutdown(wait=True)
+        if stats is not None:
+            t_end = time.perf_counter()
+            stats.update({"total_s": t_end - t_start, "until_first_enqueue_s": t_first, "in_css_wait_s": t_wait,
+                          "after_last_css_wait_s": t_end - t_last_wait, "sessions": len(positions)})
         for kind, sep in resident.items():
             if kind not in borrowed:
                 sep.close()
