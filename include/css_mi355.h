@@ -40,6 +40,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct css_ctx* css_handle_t;
 
@@ -478,6 +482,9 @@ int css_comm_all_gather(css_handle_t h, const void* send_dev, void* recv_dev, in
  * parallel.py's plan; a host in another language addresses them through css_buffer_devptr.  parallel.HipShardBackend takes this
  * route with comm="cabi": the same driver, RCCL reached through these entry points instead of torch.distributed.) */
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

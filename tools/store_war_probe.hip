@@ -110,10 +110,35 @@ __global__ __launch_bounds__(1024) void probe_kernel(unsigned* out, int iters, i
         "v_add_u32 v23, " #P "*4+3, %1\n"                                                    \
         "buffer_store_dwordx4 v[20:23], %0, %2, 0 offen offset:" #P "*16\n"                  \
         NOPS
+// (the epilogue's own form: the piece's offset in an SGPR, the values formed by two-source VALU instructions)
+#define BURST_PIECE_S(P, NOPS)                                                               \
+        "s_movk_i32 s20, " #P "*16\n"                                                        \
+        "v_add_u32 v20, %2, %0\n"                                                            \
+        "v_add_u32 v21, 1, v20\n"                                                            \
+        "v_add_u32 v22, 2, v20\n"                                                            \
+        "v_add_u32 v23, 3, v20\n"                                                            \
+        "v_add_u32 %0, 4, %0\n"                                                              \
+        "buffer_store_dwordx4 v[20:23], %1, %3, s20 offen\n"                                 \
+        NOPS
+#define BURST_BODY_S(NOPS)                                                                   \
+    {                                                                                        \
+        unsigned step_ = 0;                                                                  \
+        asm volatile(BURST_PIECE_S(0, NOPS) BURST_PIECE_S(1, NOPS) BURST_PIECE_S(2, NOPS) BURST_PIECE_S(3, NOPS) \
+            "v_add_u32 v20, %2, %0\n" "s_nop 7\n"                                            \
+            : "+v"(step_) : "v"(off), "v"(tag), "s"(rs), "v"(poison) : "v20", "v21", "v22", "v23", "s20", "memory"); \
+    }
 #define BURST_BODY(NOPS)                                                                     \
     asm volatile(BURST_PIECE(0, NOPS) BURST_PIECE(1, NOPS) BURST_PIECE(2, NOPS) BURST_PIECE(3, NOPS) \
         "v_mov_b32 v20, %3\n" "s_nop 7\n"                                                    \
         : : "v"(off), "v"(tag), "s"(rs), "v"(poison) : "v20", "v21", "v22", "v23", "memory");
+
+template <int K>
+__device__ __forceinline__ void burst_sreg(int off, unsigned tag, i32x4 rs, unsigned poison) {
+    if constexpr (K == 0) { BURST_BODY_S("") }
+    else if constexpr (K == 1) { BURST_BODY_S("s_nop 0\n") }
+    else if constexpr (K == 2) { BURST_BODY_S("s_nop 1\n") }
+    else { BURST_BODY_S("s_nop 7\n") }
+}
 
 template <int K>
 __device__ __forceinline__ void burst(int off, unsigned tag, i32x4 rs, unsigned poison) {
@@ -128,7 +153,7 @@ __device__ __forceinline__ void burst(int off, unsigned tag, i32x4 rs, unsigned 
     else { BURST_BODY("s_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\n") }
 }
 
-template <int K>
+template <int K, bool SREG = false>
 __global__ __launch_bounds__(1024) void burst_kernel(unsigned* out, int iters, int siblings, float* sink, const float* src) {
     __shared__ float lds[4096];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -165,15 +190,16 @@ __global__ __launch_bounds__(1024) void burst_kernel(unsigned* out, int iters, i
     for (int it = 0; it < iters; ++it) {
         const int off = (it * 64 + lane) * 64;
         const unsigned tag = (unsigned)(it * 64 + lane) * 16u + 0x100u;
-        burst<K>(off, tag, rs, 0xDEADBEEFu);
+        if constexpr (SREG) burst_sreg<K>(off, tag, rs, 0xDEADBEEFu);
+        else burst<K>(off, tag, rs, 0xDEADBEEFu);
     }
 }
 
-template <int K>
+template <int K, bool SREG = false>
 static void run_burst(unsigned* dev, float* sink, const float* src, int blocks, int iters, int siblings) {
     const size_t n = (size_t)blocks * 4 * iters * 64 * 16;
     hipMemset(dev, 0, n * 4);
-    hipLaunchKernelGGL(burst_kernel<K>, dim3(blocks), dim3(1024), 0, 0, dev, iters, siblings, sink, src);
+    hipLaunchKernelGGL((burst_kernel<K, SREG>), dim3(blocks), dim3(1024), 0, 0, dev, iters, siblings, sink, src);
     hipDeviceSynchronize();
     std::vector<unsigned> h(n);
     hipMemcpy(h.data(), dev, n * 4, hipMemcpyDeviceToHost);
@@ -187,7 +213,7 @@ static void run_burst(unsigned* dev, float* sink, const float* src, int blocks, 
                 else ++other;
             }
     const char* who = siblings == 0 ? "test waves alone                          " : (siblings == 1 ? "3 MFMA waves beside each test wave        " : "3 MFMA + load + LDS waves beside each one ");
-    printf("  %2d wait states, %s: dwords holding the NEXT piece's value, by position %zu %zu %zu %zu of %zu pieces (other mismatches %zu)\n", K, who,
+    printf("  %2d wait states, soffset %s, %s: dwords holding the NEXT piece's value, by position %zu %zu %zu %zu of %zu pieces (other mismatches %zu)\n", K, SREG ? "in an SGPR " : "immediate  ", who,
            next[0], next[1], next[2], next[3], (size_t)blocks * 4 * iters * 64 * 4, other);
 }
 
@@ -244,6 +270,10 @@ int main() {
         run_burst<6>(dev, sink, src, blocks, iters / 4, siblings);
         run_burst<8>(dev, sink, src, blocks, iters / 4, siblings);
         run_burst<16>(dev, sink, src, blocks, iters / 4, siblings);
+        run_burst<0, true>(dev, sink, src, blocks, iters / 4, siblings);
+        run_burst<1, true>(dev, sink, src, blocks, iters / 4, siblings);
+        run_burst<2, true>(dev, sink, src, blocks, iters / 4, siblings);
+        run_burst<8, true>(dev, sink, src, blocks, iters / 4, siblings);
     }
     return 0;
 }
