@@ -202,9 +202,9 @@ def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, de
     stages of the C ABI (css_begin, css_stage_stft, css_stage_mvdr, ..., css_stage_istft); the masks go straight into the
     library's device buffer through a zero-copy torch view.  Nothing is computed on the host.
 
-    The stages implement the transform of the reference's ConformerCssWrapper (512-point Hann analysis, hop 256, sqrt-Hann
-    synthesis, feature.py:88-167); a separator whose own `stft` is a different transform is rejected: its masks would not
-    belong to these spectra."""
+    The stages implement the transform of the reference's ConformerCssWrapper in the stand-in's geometry (the shipped one:
+    512-sample Hann analysis window, hop 256, sqrt-Hann synthesis, feature.py:19-45,88-167); a separator whose own `stft` is a
+    different transform is rejected: its masks would not belong to these spectra."""
     import torch
     from .parallel import HipShardBackend
     assert not getattr(separator, "training", False)
@@ -238,8 +238,8 @@ def _separate_and_stitch_protocol(speech_mix: np.ndarray, separator, fs: int, de
                 ours = torch.complex(X[:, :F, :k], X[:, F:2 * F, :k]).permute(1, 2, 0)[None]
                 scale = float(ours.abs().max()) + 1e-30
                 if tuple(theirs.shape[:2]) != (1, F) or float((theirs[:, :, :k].to(dev) - ours).abs().max()) > 1e-3 * scale:
-                    raise ValueError("the separator's stft() is not the transform of the HIP stages (512-point Hann, hop 256, "
-                                     "conformer_wrapper.py:106-129): its masks cannot be applied to these spectra")
+                    raise ValueError(f"the separator's stft() is not the transform of the HIP stages ({desc.frame_len}-sample Hann window, hop "
+                                     f"{desc.frame_hop}, conformer_wrapper.py:106-129): its masks cannot be applied to these spectra")
             for i in range(nseg):                                # css.py:182-250, one call per segment as in the reference
                 t = max(min(T, frames - i * hop), 0)
                 seg = torch.zeros((1, F, T, c), dtype=torch.complex64, device=dev)
