@@ -88,6 +88,20 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
                            // a register group = four consecutive output features -- and the fast epilogue stores 16-byte pieces
                            // straight from the registers, no turn through the LDS patch (same products, same bits)
 #endif
+#ifndef F32_STORE_GUARD
+#define F32_STORE_GUARD 1   // 0 (tools): without the wait state behind the fast epilogue's 16-byte stores
+#endif
+// A buffer store of more than 64 bits reads its data registers AFTER it has issued: a VALU result written to one of them in the
+// very next slot is what gets stored.  LLVM pads that slot unless the store's soffset is an SGPR (GCNHazardRecognizer::
+// createsVALUHazard) -- and the fast epilogue's stores carry their row offset exactly there.  gfx950 does corrupt such a pair
+// inside this kernel (seen twice: F32_TRANSPOSED=1, and the shipped epilogue as `-O1 -g` schedules it -- DESIGN.md 3.1c), so the
+// wait state is put there by construction: the asm reads the stored registers, so nothing may redefine them in front of it, and
+// it is itself one slot.  (tests/test_store_hazard_scan.py scans every unit's ISA for the pair.)
+#if F32_STORE_GUARD
+#define F32_AFTER_STORE(o) asm volatile("s_nop 0" : : "v"(o));
+#else
+#define F32_AFTER_STORE(o)
+#endif
 #ifndef F32_DMA
 #define F32_DMA 0   // 1: global -> LDS by the DMA path (buffer_load ... lds), unpadded 64-byte LDS rows with an XOR swizzle
 #endif
@@ -360,6 +374,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
                 }
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voC, (int)((32 * i * ldc + 8 * q) * 4), 0);
+                F32_AFTER_STORE(o)
 #if F32_TRANSPOSED >= 2
                 // the store reads its four data registers AFTER it has issued; the next piece's first VALU result must not land in
                 // them before that (tools/store_war_probe.hip: more wait states than the compiler's hazard table pads on gfx950)
@@ -397,6 +412,7 @@ __device__ __forceinline__ void f32_tile(const GemmArgs& g, const float* __restr
                 }
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voC, (int)((32 * i + 8 * j) * ldc * 4), 0);
+                F32_AFTER_STORE(o)
             }
         }
         F32_EPILOGUE_PROBE

@@ -4,12 +4,14 @@
     python tools/scan_store_war.py [file.hip ...]        (default: every unit of notsofar1-challenge_amd/csrc)
 
 A buffer store of more than 64 bits reads its data registers AFTER it has issued; a VALU instruction that writes one of them in
-the very next slot corrupts what is stored (tools/store_war_probe.hip: with 0 wait states a quarter of the 16-byte pieces carry
-the later value in their first dword, with 1 none).  LLVM pads that slot (GCNHazardRecognizer::createsVALUHazard) -- except when
-the store's `soffset` operand is an SGPR, where it assumes there is no hazard.  On gfx950 there is: `buffer_store_dwordx4
-v[16:19], v64, s[56:59], s8 offen` directly followed by `v_add_f32 v16, ...` is what made F32_TRANSPOSED=1 write a few hundred
-wrong elements per launch.  This script compiles each unit to assembly and lists every such store whose data registers are
-written by the instruction(s) within `WINDOW` slots behind it (s_nop N counts N + 1 slots)."""
+the very next slot corrupts what is stored.  LLVM pads that slot (GCNHazardRecognizer::createsVALUHazard) -- except when the
+store's `soffset` operand is an SGPR, where it assumes there is no hazard.  On gfx950 there is, inside gemm_f32.hip's epilogue:
+`buffer_store_dwordx4 v[16:19], v64, s[56:59], s8 offen` directly followed by `v_add_f32 v16, ...` made F32_TRANSPOSED=1 write a
+few hundred wrong elements per launch, and `buffer_store_dwordx4 v[4:7], v9, s[44:47], s8 offen` -> `v_max_f32 v4, 0, v0` did
+the same to the shipped epilogue as -O1 -g schedules it (profiles/r06_store_guard.txt).  The kernel now glues one wait state to
+every such store (F32_STORE_GUARD).  This script compiles each unit to assembly and lists every such store whose data registers
+are written by the instruction(s) within `WINDOW` slots behind it (s_nop N counts N + 1 slots).  SCAN_FLAGS adds compiler flags
+(e.g. "-O1 -g -DF32_STORE_GUARD=0")."""
 import os
 import re
 import subprocess
