@@ -38,7 +38,38 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         : "v"(off), "v"(tag), "s"(rs), "v"(poison)                                           \
         : "v20", "v21", "v22", "v23", "s20", "memory");
 
+// the form both failing builds of gemm_f32.hip contain: the soffset SGPR is an SGPR-spill reload -- written by v_readlane_b32, the
+// compiler's 5 wait states (s_nop 4), the store, the overwrite
+#define PROBE_BODY_R(NOPS)                                                                   \
+    asm volatile(                                                                            \
+        "v_mov_b32 v24, 0\n"                                                                 \
+        "v_mov_b32 v20, %1\n"                                                                \
+        "v_add_u32 v21, 1, %1\n"                                                             \
+        "v_add_u32 v22, 2, %1\n"                                                             \
+        "v_add_u32 v23, 3, %1\n"                                                             \
+        "s_nop 7\n"                                                                          \
+        "v_readlane_b32 s20, v24, 17\n"                                                      \
+        "s_nop 4\n"                                                                          \
+        "buffer_store_dwordx4 v[20:23], %0, %2, s20 offen\n"                                 \
+        NOPS                                                                                 \
+        "v_max_f32_e32 v20, %3, %3\n"                                                        \
+        "v_mov_b32 v21, %3\n"                                                                \
+        "v_mov_b32 v22, %3\n"                                                                \
+        "v_mov_b32 v23, %3\n"                                                                \
+        "s_nop 7\n"                                                                          \
+        :                                                                                    \
+        : "v"(off), "v"(tag), "s"(rs), "v"(poison)                                           \
+        : "v20", "v21", "v22", "v23", "v24", "s20", "memory");
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__device__ __forceinline__ void store_then_overwrite_readlane(int off, unsigned tag, i32x4 rs, unsigned poison) {
+    if constexpr (K == 0) { PROBE_BODY_R("") }
+    else if constexpr (K == 1) { PROBE_BODY_R("s_nop 0\n") }
+    else if constexpr (K == 2) { PROBE_BODY_R("s_nop 1\n") }
+    else { PROBE_BODY_R("s_nop 3\n") }
+}
 
 template <int K>
 __device__ __forceinline__ void store_then_overwrite_sreg(int off, unsigned tag, i32x4 rs, unsigned poison) {
@@ -64,7 +95,7 @@ __device__ __forceinline__ void store_then_overwrite(int off, unsigned tag, i32x
 }
 
 // 16 waves per block, one block per CU: waves 0..3 (one per SIMD) run the store test, waves 4..15 (three per SIMD) the MFMA stream
-template <int K, bool SREG = false>
+template <int K, int SREG = 0>
 __global__ __launch_bounds__(1024) void probe_kernel(unsigned* out, int iters, int with_mfma, float* sink) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave >= 4) {
@@ -94,7 +125,8 @@ __global__ __launch_bounds__(1024) void probe_kernel(unsigned* out, int iters, i
     for (int it = 0; it < iters; ++it) {
         const int off = (it * 64 + lane) * 16;
         const unsigned tag = (unsigned)(it * 64 + lane) * 4u + 0x100u;
-        if constexpr (SREG) store_then_overwrite_sreg<K>(off, tag, rs, 0xDEADBEEFu);
+        if constexpr (SREG == 2) store_then_overwrite_readlane<K>(off, tag, rs, 0xDEADBEEFu);
+        else if constexpr (SREG == 1) store_then_overwrite_sreg<K>(off, tag, rs, 0xDEADBEEFu);
         else store_then_overwrite<K>(off, tag, rs, 0xDEADBEEFu);
     }
 }
@@ -217,7 +249,7 @@ static void run_burst(unsigned* dev, float* sink, const float* src, int blocks, 
            next[0], next[1], next[2], next[3], (size_t)blocks * 4 * iters * 64 * 4, other);
 }
 
-template <int K, bool SREG = false>
+template <int K, int SREG = 0>
 static void run(unsigned* dev, float* sink, int blocks, int iters, int with_mfma) {
     const size_t n = (size_t)blocks * 4 * iters * 64 * 4;
     hipMemset(dev, 0, n * 4);
@@ -234,7 +266,7 @@ static void run(unsigned* dev, float* sink, int blocks, int iters, int with_mfma
                 else if (v != want) ++other;
             }
     printf("  %2d wait states, soffset %s, %s: poisoned dwords by position %zu %zu %zu %zu of %zu pieces (other mismatches %zu)\n", K,
-           SREG ? "in an SGPR " : "immediate 0", with_mfma ? "3 MFMA waves beside each test wave" : "test waves alone               ", bad[0], bad[1], bad[2], bad[3],
+           SREG == 2 ? "SGPR<-readlane" : (SREG ? "in an SGPR " : "immediate 0"), with_mfma ? "3 MFMA waves beside each test wave" : "test waves alone               ", bad[0], bad[1], bad[2], bad[3],
            (size_t)blocks * 4 * iters * 64, other);
 }
 
@@ -254,10 +286,14 @@ int main() {
         run<8>(dev, sink, blocks, iters, with_mfma);
         run<16>(dev, sink, blocks, iters, with_mfma);
         run<32>(dev, sink, blocks, iters, with_mfma);
-        run<0, true>(dev, sink, blocks, iters, with_mfma);
-        run<1, true>(dev, sink, blocks, iters, with_mfma);
-        run<2, true>(dev, sink, blocks, iters, with_mfma);
-        run<4, true>(dev, sink, blocks, iters, with_mfma);
+        run<0, 1>(dev, sink, blocks, iters, with_mfma);
+        run<1, 1>(dev, sink, blocks, iters, with_mfma);
+        run<2, 1>(dev, sink, blocks, iters, with_mfma);
+        run<4, 1>(dev, sink, blocks, iters, with_mfma);
+        run<0, 2>(dev, sink, blocks, iters, with_mfma);
+        run<1, 2>(dev, sink, blocks, iters, with_mfma);
+        run<2, 2>(dev, sink, blocks, iters, with_mfma);
+        run<4, 2>(dev, sink, blocks, iters, with_mfma);
     }
     printf("four pieces in a row from the same registers: { v_add_u32 v20..v23 ; buffer_store_dwordx4 v[20:23] ; K wait states } x 4\n");
     float* src; hipMalloc(&src, (size_t)(1 << 20) * 16 + 64); hipMemset(src, 0, (size_t)(1 << 20) * 16 + 64);
