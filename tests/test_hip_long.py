@@ -147,6 +147,95 @@ def test_masks_deep_in_the_meeting_vs_oracle(L, long_run, mc_state):
     _report("masks_1800s_vs_oracle_max_abs", worst)
 
 
+@pytest.mark.parametrize("mode", ["exact_f32", "split_f16"])
+def test_whole_meeting_vs_the_reference(L, long_run, golden, mode):
+    """configs[3] against the REFERENCE's own run of the same 1800 s meeting (tests/golden/gen_golden_r6b.py, e2e1800_r6.npz;
+    until round 6 this configuration was held to the oracle only): all 1208 permutations, both activity maps, the stitched
+    masks, every segment's masks on a grid, the three waveforms every 128th sample."""
+    from test_oracle_golden_r2 import unpack_bits
+    g = golden("e2e1800_r6.npz")
+    h, run_cfg = long_run["h"], long_run["run_cfg"]
+    h.set_linear_mode(mode)
+    try:
+        free = h.run(long_run["pcm"], run_cfg)
+        nseg, TL = 1209, 112_499
+        assert int(g["num_segments"]) == nseg and free.shape == (S, int(g["wav_len"]))
+        m = h.read(L.BUF_MASKS).reshape(S + 1, F, nseg, T)
+        perms = h.read(L.BUF_PERMS)
+        act_b = h.read(L.BUF_ACT_B).astype(bool).T
+        act_f = h.read(L.BUF_ACT_FINAL).astype(bool).T
+        mask_st = h.read(L.BUF_MASK_ST)
+        shape = tuple(g["activity_shape"])
+        perm_diff = [i + 1 for i in range(nseg - 1) if tuple(perms[i + 1]) != tuple(g["pit_perm"][i])]
+        ab = int((act_b != unpack_bits(g["activity_b"], shape)).sum())
+        af = int((act_f != unpack_bits(g["activity_final"], shape)).sum())
+        grid = np.moveaxis(m[:, ::32, :, ::24], (0, 1, 2, 3), (3, 1, 0, 2))            # [nseg, 9, 8, 4]
+        per_seg = np.abs(grid - g["masks_grid"]).reshape(nseg, -1).max(axis=1)
+        ms = np.abs(mask_st.transpose(1, 2, 0)[::32, ::16] - g["mask_stitched"])
+        ref = g["wav_dec128"]
+        got = free[:, ::128]
+        whole = [rel_rms(got[k], ref[k]) for k in range(S)]
+        # per hop block (93 frames = 186 decimated samples), relative to the stream's own RMS (a silent block has no RMS of its own)
+        nb = ref.shape[1] // 186
+        d = (got[:, :nb * 186].astype(np.float64) - ref[:, :nb * 186]).reshape(S, nb, 186)
+        blk = np.sqrt((d ** 2).mean(axis=2)) / g["wav_rms"][:, None]
+        # Which segments can be compared at all.  (a) 39 of the 1209 segments have an IPD feature on the other side of the atan2
+        # branch cut than the reference's (DESIGN.md hazard 7: a value at +-pi moves by 2 pi with the last bit of the transform;
+        # the oracle puts most segments of this meeting within 1e-5 of the cut, fixture key cut_distance_per_segment) -- their
+        # masks differ by up to 0.07, every other segment's by at most 5e-6.  The reference is deterministic across thread
+        # counts there (its features do not depend on them: self_t4_*), and moves the same way when its own conv1d runs on
+        # another backend (self_t8_nomkldnn_*).  (b) Where the masks agree, the reference's own winner-take-all near-ties
+        # remain: against ITSELF at 4 threads it has 1163 - 1169 of 1209 hop blocks within 1e-4 and 0.9e-4 - 1.6e-4 whole-meeting.
+        differ = per_seg > 5e-6
+        near = np.zeros(nb, bool)
+        for i in np.flatnonzero(differ):
+            near[max(i - 1, 0):min(i + 3, nb)] = True       # a segment covers two hop blocks; the gate's dilation reaches one more
+        away = ~near
+        dd = d[:, away].reshape(S, -1)
+        rr = ref[:, :nb * 186].reshape(S, nb, 186)[:, away].reshape(S, -1).astype(np.float64)
+        away_err = [float(np.sqrt((dd[k] ** 2).mean() / (rr[k] ** 2).mean())) for k in range(S)]
+        self_blk = g["self_t4_hop_block_rel"]
+        rep = {
+            "segments": nseg, "permutations_that_differ_at_boundaries": perm_diff, "activity_b_bits_that_differ": ab, "activity_final_bits_that_differ": af,
+            "segments_with_grid_masks_within_5e-6": int((~differ).sum()), "segments_beyond": np.flatnonzero(differ).tolist(),
+            "largest_branch_cut_distance_of_a_segment_beyond": float(g["cut_distance_per_segment"][differ].max()) if differ.any() else 0.0,
+            "grid_masks_max_abs": float(per_seg.max()), "grid_masks_max_abs_elsewhere": float(per_seg[~differ].max()),
+            "grid_masks_median_of_segment_max": float(np.median(per_seg)),
+            "stitched_masks_max_abs": float(ms.max()), "stitched_masks_within_5e-6": round(float((ms <= 5e-6).mean()), 6),
+            "waveform_rel_rms_whole_meeting": whole,
+            "hop_blocks": nb, "hop_blocks_within_1e-4": [int((blk[k] < 1e-4).sum()) for k in range(S)],
+            "hop_blocks_within_1e-3": [int((blk[k] < 1e-3).sum()) for k in range(S)], "hop_block_worst": [float(blk[k].max()) for k in range(S)],
+            "hop_blocks_away_from_those_segments": int(away.sum()),
+            "of_them_within_1e-4": [int((blk[k][away] < 1e-4).sum()) for k in range(S)],
+            "waveform_rel_rms_there": away_err,
+            "reference_against_itself_4_threads": {"segments_beyond_5e-6": int((g["self_t4_grid_max_abs"] > 5e-6).sum()),
+                                                   "hop_blocks_within_1e-4": [int((self_blk[k] < 1e-4).sum()) for k in range(S)],
+                                                   "of_the_same_blocks_within_1e-4": [int((self_blk[k][away] < 1e-4).sum()) for k in range(S)],
+                                                   "waveform_rel_rms_whole_meeting": [float(x) for x in g["self_t4_wav_rel_rms"]]}}
+        if "self_t8_nomkldnn_grid_max_abs" in g:
+            rep["reference_against_itself_other_conv_backend"] = {
+                "segments_beyond_5e-6": int((g["self_t8_nomkldnn_grid_max_abs"] > 5e-6).sum()),
+                "of_them_also_ours": int(((g["self_t8_nomkldnn_grid_max_abs"] > 5e-6) & differ).sum()),
+                "grid_masks_max_abs": float(g["self_t8_nomkldnn_grid_max_abs"].max()),
+                "hop_blocks_within_1e-4": [int((g["self_t8_nomkldnn_hop_block_rel"][k] < 1e-4).sum()) for k in range(S)],
+                "waveform_rel_rms_whole_meeting": [float(x) for x in g["self_t8_nomkldnn_wav_rel_rms"]]}
+        _report(f"config4_1800s_{mode}_vs_reference", rep)
+        # decisions: exact, all of them
+        assert perm_diff == [] and ab == 0 and af == 0, (perm_diff, ab, af)
+        # masks: within the survey's 5e-6 on every segment but those with a feature across the branch cut
+        assert int(differ.sum()) <= 48 and float(g["cut_distance_per_segment"][differ].max()) < 2.5e-5, rep
+        assert float(np.median(per_seg)) < 3e-6
+        # waveforms away from those segments: what winner-take-all near-ties leave (2 415 of the reference's decisions sit inside
+        # 1e-5; against itself at 4 threads it has 96.5 % of these blocks within 1e-4 and 0.9e-4 - 1.6e-4 over the whole meeting;
+        # measured here: 93.7 - 96.0 % and 1.5e-4 - 3.5e-4).  The whole meeting, the 39 segments included, is where the reference
+        # is against itself on its other conv backend: 2.8e-3 / 5.1e-3 / 3.4e-3 (measured here 3.3e-3 / 7.1e-3 / 3.2e-3).
+        for k in range(S):
+            assert int((blk[k][away] < 1e-4).sum()) >= 0.92 * int(away.sum()), rep
+            assert away_err[k] < 5e-4 and whole[k] < 1e-2, rep
+    finally:
+        h.set_linear_mode("exact_f32")
+
+
 def _report(key, value):
     """parity bookkeeping: the measured margins of this run, next to the test output (profiles/r04_parity_coverage.json)"""
     import json

@@ -35,3 +35,21 @@ def test_near_tie_list_and_float64(golden):
     i = int(np.flatnonzero((near == [4, 132, 145]).all(axis=1))[0])
     top2 = np.sort(g6["near_masks_t2"][i])[-2:]
     assert top2[0] == top2[1]                               # an EXACT tie in the reference's own 2-thread run
+
+
+def test_configs3_fixture_is_the_planned_meeting(golden):
+    """e2e1800_r6.npz (tests/golden/gen_golden_r6b.py): the reference's own run of configs[3].  Its shape is the oracle's plan for
+    28.8 M samples (css/css.py:144-171: 1209 segments, 112 499 frames, a ragged last segment), and what it says about the
+    reference on this meeting -- thousands of winner-take-all decisions inside 1e-5, most segments with an IPD feature within
+    1e-5 of the atan2 branch cut -- is what tests/test_hip_long.py::test_whole_meeting_vs_the_reference leans on."""
+    import css_oracle as O
+    g = golden("e2e1800_r6.npz")
+    plan = O.make_plan(28_800_000, 16000, O.OracleCssCfg(activity_th=0.3))
+    assert (plan.num_segments, plan.mix_frames) == (1209, 112_499) == (int(g["num_segments"]), int(g["activity_shape"][0]))
+    assert int(g["wav_len"]) == (112_499 - 1) * 256 + 512 and g["wav_dec128"].shape == (3, -(-int(g["wav_len"]) // 128))
+    assert g["pit_perm"].shape == (1208, 3) and g["masks_grid"].shape == (1209, 9, 8, 4)
+    assert np.array_equal(np.sort(g["pit_perm"], axis=1), np.tile(np.arange(3), (1208, 1)))
+    assert float(g["masks_grid"].min()) > 0.0 and float(g["masks_grid"].max()) < 1.0
+    assert int(g["wta_margin_below_1e-5_per_segment"].sum()) > 2000                  # 2 415 of 57.8 M decisions
+    cut = g["cut_distance_per_segment"]
+    assert cut.shape == (1209,) and float(np.median(cut)) < 1e-5                     # hazard 7 is the rule on this meeting, not the exception
