@@ -23,6 +23,7 @@ for mode in exact_f32 split_f16; do
   done
 done
 python tools/summarize_gemm_pmc.py gpurun_out ${tag} > gpurun_out/${tag}_gemm_pmc.md
+python tools/summarize_estimator_pmc.py gpurun_out ${tag} > gpurun_out/${tag}_estimator_pmc.md
 fi
 if [ "$part" = all ] || [ "$part" = small ]; then
 # the memory-bound kernels either side of the estimator on the 30-MIN meeting (north_star: "rocprof HBM GB/s on STFT / covariance"):
