@@ -243,6 +243,26 @@ int css_plan(const CssModelDesc* desc, const CssRunCfg* cfg, int64_t n_samples, 
  * costs [n_boundaries][S*S] -> perms [(n_boundaries+1)][S]; perms[0] = identity. */
 int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, int32_t* perms);
 
+/* CssCfg's fields in the reference's own units (css/css.py:24-48), for a host without the Python shim. */
+typedef struct CssCfgSeconds {
+    double segment_size_sec;        /* 3.0   css.py:26                                                */
+    double hop_size_sec;            /* 1.5   css.py:27                                                */
+    double seg_weight_m0_sec;       /* 0.15  css.py:30                                                */
+    double seg_weight_m1_sec;       /* 0.3   css.py:31                                                */
+    double activity_dilation_sec;   /* 0.4   css.py:33                                                */
+    double activity_erosion_sec;    /* 0.2   css.py:34                                                */
+    double activity_th;             /* 0.4   css.py:32 (configs/inference/inference_v1.yaml:17: 0.3)  */
+    double mask_floor_db;           /* mc_mask_floor_db (0) or sc_mask_floor_db (-inf), css.py:223    */
+    int32_t mc_mvdr, stitching_loss /* 0 'l1', 1 'mse' */, stitching_input /* 0 'mask', 1 'separation_result' */, normalize_segment_power;
+} CssCfgSeconds;
+/* css/css.py:144-152 (seconds -> frames, with the reference's own double expressions and truncations) and css.py:341-390
+ * (calc_segment_weight: the three trapezoid windows, torch.linspace's float32 evaluation order) -- what
+ * notsofar1-challenge_amd/css.py::make_run_cfg does in Python, bit for bit (tests/test_cabi.py).  `windows` receives
+ * 3 * segment_frames floats (first | middle | last segment) and out->w_first / w_mid / w_last point into it; `cap` is its size
+ * in floats.  CSS_ERR_WEIGHT_WINDOW: css.py:374 "not enough frames to fit weighting window"; CSS_ERR_MASK_FLOOR: css.py:224;
+ * CSS_ERR_INVALID_ARG: a segmentation outside 2 .. CSS_MAX_SEGMENT_FRAMES frames with 1 <= hop < segment, or cap too small. */
+int css_make_run_cfg(const CssModelDesc* desc, const CssCfgSeconds* cfg, int32_t fs, CssRunCfg* out, float* windows, int64_t cap);
+
 /* ---- the hot path: css/css.py:110 separate_and_stitch -------------------------------------- */
 /* pcm_host [n_samples][n_ch] float32 (exactly css/helpers.py:40 load_audio's layout, batch squeezed)
  * -> wav_host [S][n_out].  One H2D of the PCM, one D2H of the waveforms. */

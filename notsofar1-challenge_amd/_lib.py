@@ -67,6 +67,12 @@ class CssPlan(C.Structure):
                 ("zero_weight", C.c_int32)]
 
 
+class CssCfgSeconds(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("segment_size_sec", "hop_size_sec", "seg_weight_m0_sec", "seg_weight_m1_sec",
+                                           "activity_dilation_sec", "activity_erosion_sec", "activity_th", "mask_floor_db")] + \
+               [(n, C.c_int32) for n in ("mc_mvdr", "stitching_loss", "stitching_input", "normalize_segment_power")]
+
+
 class CssKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms", C.c_float), ("launches", C.c_int32)]
 
@@ -95,6 +101,7 @@ SIGNATURES = {
     "css_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "css_host_free": (C.c_int, [_P]),
     "css_plan": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssRunCfg), C.c_int64, C.POINTER(CssPlan)]),
+    "css_make_run_cfg": (C.c_int, [C.POINTER(CssModelDesc), C.POINTER(CssCfgSeconds), C.c_int32, C.POINTER(CssRunCfg), _FP, C.c_int64]),
     "css_pit_scan": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "css_run": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),
     "css_run_enqueue": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(CssRunCfg), _P, C.c_int64]),

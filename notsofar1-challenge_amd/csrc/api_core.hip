@@ -601,6 +601,54 @@ int css_plan(const CssModelDesc* desc, const CssRunCfg* cfg, int64_t n_samples, 
     return plan_impl(*desc, *cfg, n_samples, out);
 }
 
+// css.py:341-390 calc_segment_weight; the taper is torch.linspace(0.1, 1, m1 - m0) in float32: ATen evaluates the lower half as
+// start + step * i and the upper half as end - step * (steps - 1 - i), each one fused multiply-add
+static void segment_weight(int T, int m0, int m1, bool first, bool last, float* w) {
+    for (int t = 0; t < T; ++t) w[t] = 1.f;
+    for (int t = 0; t < m0; ++t) w[t] = w[T - 1 - t] = 0.f;
+    const int steps = m1 - m0;
+    const float start = 0.1f, end = 1.f;
+    const float step = steps > 1 ? (end - start) / (float)(steps - 1) : 0.f;
+    for (int i = 0; i < steps; ++i) {
+        const float v = steps == 1 ? start : (i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end));
+        w[m0 + i] = v;
+        w[T - 1 - m0 - i] = v;
+    }
+    if (first) for (int t = 0; t < m0; ++t) w[t] = 0.1f;
+    if (last) for (int t = 0; t < m0; ++t) w[T - 1 - t] = 0.1f;
+}
+
+int css_make_run_cfg(const CssModelDesc* desc, const CssCfgSeconds* c, int32_t fs, CssRunCfg* out, float* windows, int64_t cap) {
+    if (!desc || !c || !out || !windows || fs <= 0 || desc->frame_len < 2 || desc->frame_hop < 1 || !(c->segment_size_sec > 0)) return CSS_ERR_INVALID_ARG;
+    // Python's int() truncates towards zero, // floors (css.py:145-152; the operands are non-negative here)
+    const int64_t seg_samples = (int64_t)(c->segment_size_sec * (double)fs);
+    if (seg_samples < desc->frame_len) return CSS_ERR_INVALID_ARG;
+    const int64_t T = (seg_samples - desc->frame_len) / desc->frame_hop + 1;
+    const int64_t hop = (int64_t)((double)T * c->hop_size_sec / c->segment_size_sec);
+    if (T < 2 || T > CSS_MAX_SEGMENT_FRAMES || hop < 1 || hop >= T) return CSS_ERR_INVALID_ARG;
+    const int m0 = (int)((double)T * c->seg_weight_m0_sec / c->segment_size_sec), m1 = (int)((double)T * c->seg_weight_m1_sec / c->segment_size_sec);
+    if (m0 < 0 || m1 < m0) return CSS_ERR_INVALID_ARG;
+    if (!(T > 2 * m1)) return CSS_ERR_WEIGHT_WINDOW;   // css.py:374
+    if (c->mask_floor_db > 0) return CSS_ERR_MASK_FLOOR;   // css.py:224
+    if (cap < 3 * T) return CSS_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->segment_frames = (int32_t)T;
+    out->hop_frames = (int32_t)hop;
+    out->dilation_frames = (int32_t)((double)T * c->activity_dilation_sec / c->segment_size_sec);
+    out->erosion_frames = (int32_t)((double)T * c->activity_erosion_sec / c->segment_size_sec);
+    out->mc_mvdr = c->mc_mvdr != 0;
+    out->stitching_loss = c->stitching_loss;
+    out->stitching_input = c->stitching_input;
+    out->normalize_segment_power = c->normalize_segment_power != 0;
+    out->mask_floor = (float)std::pow(10.0, c->mask_floor_db / 20.0);   // css.py:225 (-inf dB -> 0)
+    out->activity_th = (float)c->activity_th;
+    segment_weight((int)T, m0, m1, true, false, windows);
+    segment_weight((int)T, m0, m1, false, false, windows + T);
+    segment_weight((int)T, m0, m1, false, true, windows + 2 * T);
+    out->w_first = windows; out->w_mid = windows + T; out->w_last = windows + 2 * T;
+    return CSS_OK;
+}
+
 int css_pit_scan(const double* costs, int64_t n_boundaries, int32_t num_spks, int32_t* perms) {
     if (!perms || n_boundaries < 0 || num_spks < 1 || num_spks > 4 || (n_boundaries > 0 && !costs)) return CSS_ERR_INVALID_ARG;
     pit_scan_host(costs, n_boundaries, num_spks, perms);

@@ -343,3 +343,28 @@ def test_device_handoff_to_whisper_front_end(tiny_models):
             h.handoff_logmel(wav.data_ptr(), int(plan.n_out), 3)
     finally:
         sep.close()
+
+
+def test_c_host_equals_the_python_shim(tmp_path):
+    """examples/c_host.c -- a host in plain C on include/css_mi355.h (css_make_run_cfg, css_plan, css_host_alloc, css_create,
+    css_run, css_run_enqueue, css_wait), compiled with gcc on the box -- against the Python shim on the same model and
+    recording: the waveforms it writes are HipSeparator's, bit for bit, and its queued sessions equal its css_run."""
+    import subprocess
+    from test_cabi import _build_c_host, _write_c_host_inputs
+    CSS, W, L = pkg("css"), pkg("weights"), pkg("_lib")
+    desc = W.ModelDesc(num_blocks=2)
+    state = W.apply_golden_recipe(W.portable_state_dict(desc, 21))
+    mix = pkg("synth").synth_meeting(21.0, 7, seed=5)[0]
+    exe = _build_c_host(tmp_path)
+    _write_c_host_inputs(tmp_path, desc, state, mix)
+    out = subprocess.run([exe, str(tmp_path / "model.bin"), str(tmp_path / "pcm.f32"), "7", str(tmp_path / "wav.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "every session equals css_run bit for bit: yes" in out.stdout, out.stdout
+    sep = pkg("separator").HipSeparator(state, None, device=0, max_batch_segments=256)
+    try:
+        ref = sep.handle.run(np.ascontiguousarray(mix), CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7))
+        got = np.fromfile(tmp_path / "wav.f32", dtype=np.float32).reshape(ref.shape)
+        assert np.isfinite(got).all() and float(np.abs(got).max()) > 1e-3
+        assert np.array_equal(got, ref)
+    finally:
+        sep.close()
