@@ -53,3 +53,20 @@ def test_configs3_fixture_is_the_planned_meeting(golden):
     assert int(g["wta_margin_below_1e-5_per_segment"].sum()) > 2000                  # 2 415 of 57.8 M decisions
     cut = g["cut_distance_per_segment"]
     assert cut.shape == (1209,) and float(np.median(cut)) < 1e-5                     # hazard 7 is the rule on this meeting, not the exception
+
+
+def test_nulls_fixture_and_the_oracle_on_a_muted_array(golden, mc_state):
+    """nulls_r6.npz (tests/golden/gen_golden_r6c.py): the reference on digital zeros.  A muted array gives exact zeros and identity
+    permutations (mvdr_util.py:58-75's 1e-15 diagonal loading keeps the solve defined) -- and so does the oracle; the gap
+    recording is exactly zero where every contributing frame is, and its beamformer is undefined (complex64 noise) around the
+    gap: fewer than two thirds of its seconds are comparable at 1e-4."""
+    import css_oracle as O
+    g = golden("nulls_r6.npz")
+    assert float(np.abs(g["all_zero_wav_dec16"]).max()) == 0.0 and (g["all_zero_pit_perm"] == np.arange(3)).all()
+    w, side = O.separate_and_stitch(np.zeros((1, 8 * 16000, 7), np.float32), O.ConformerParams(mc_state[0]), 16000, O.OracleCssCfg(activity_th=0.3))
+    assert all(float(np.abs(x).max()) == 0.0 for x in w) and [tuple(p) for p in side["perms"][1:]] == [tuple(p) for p in g["all_zero_pit_perm"]]
+    z = np.unpackbits(g["gap_wav_is_zero_dec16"])[:g["gap_wav_dec16"].size].reshape(g["gap_wav_dec16"].shape).astype(bool)
+    t = np.flatnonzero(z.all(axis=0))[1:]        # (sample 0 is zero in every output: the synthesis window starts at 0)
+    assert t.size > 6000 and t[0] * 16 >= 8 * 16000 and t[-1] * 16 < int(15.5 * 16000)        # inside the gap, most of it
+    defined = (g["gap_oracle_c64_vs_c128_per_second"].max(axis=1) < 1e-4) & (g["gap_oracle_c64_vs_reference_per_second"].max(axis=1) < 1e-4)
+    assert 8 <= int(defined.sum()) < 16
