@@ -210,6 +210,13 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
             nonlocal inflight, released, cur, t_wait, t_last_wait
             if cur is not None and inflight:
                 t0 = time.perf_counter()
+                if rolling:
+                    # drain in small steps: the writers start on the oldest sessions while the youngest are still on the device,
+                    # so that what is left to write after the last wait is a few sessions, not the whole window
+                    step = max(int(queue_depth) // 3, 1)
+                    while len(inflight) - released > step:
+                        cur.handle.wait_sessions(released + step)
+                        hand_over(released + step)
                 cur.handle.wait()
                 t_last_wait = time.perf_counter()
                 t_wait += t_last_wait - t0
