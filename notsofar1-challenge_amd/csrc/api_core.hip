@@ -620,6 +620,13 @@ static void segment_weight(int T, int m0, int m1, bool first, bool last, float* 
 
 int css_make_run_cfg(const CssModelDesc* desc, const CssCfgSeconds* c, int32_t fs, CssRunCfg* out, float* windows, int64_t cap) {
     if (!desc || !c || !out || !windows || fs <= 0 || desc->frame_len < 2 || desc->frame_hop < 1 || !(c->segment_size_sec > 0)) return CSS_ERR_INVALID_ARG;
+    // (a double outside int64's range has no defined conversion: every duration must be a finite, sane number of seconds;
+    //  the floor in dB may be -inf -- css.py:41 sc_mask_floor_db -- but not NaN or +inf)
+    const double secs[6] = {c->segment_size_sec, c->hop_size_sec, c->seg_weight_m0_sec, c->seg_weight_m1_sec, c->activity_dilation_sec, c->activity_erosion_sec};
+    for (double v : secs)
+        if (!std::isfinite(v) || v < 0.0 || v > 86400.0) return CSS_ERR_INVALID_ARG;
+    if (!std::isfinite(c->activity_th) || std::isnan(c->mask_floor_db)) return CSS_ERR_INVALID_ARG;
+    if (c->stitching_loss < 0 || c->stitching_loss > 1 || c->stitching_input < 0 || c->stitching_input > 1) return CSS_ERR_INVALID_ARG;
     // Python's int() truncates towards zero, // floors (css.py:145-152; the operands are non-negative here)
     const int64_t seg_samples = (int64_t)(c->segment_size_sec * (double)fs);
     if (seg_samples < desc->frame_len) return CSS_ERR_INVALID_ARG;

@@ -239,6 +239,11 @@ def test_make_run_cfg_in_c_equals_the_python_shim(L, golden):
     bad = L.CssCfgSeconds(3.0, 1.5, 0.15, 0.3, 0.4, 0.2, 0.4, 3.0, 1, 0, 0, 0)
     assert lib.css_make_run_cfg(C.byref(L.make_desc(W.ModelDesc.mc_v1())), C.byref(bad), 16000, C.byref(out), win.ctypes.data_as(C.POINTER(C.c_float)), win.size) == L.CSS_ERR_MASK_FLOOR
     assert lib.css_make_run_cfg(C.byref(L.make_desc(W.ModelDesc.mc_v1())), C.byref(sec), 16000, C.byref(out), win.ctypes.data_as(C.POINTER(C.c_float)), 100) == L.CSS_ERR_INVALID_ARG
+    for field, value in (("segment_size_sec", float("nan")), ("hop_size_sec", float("inf")), ("seg_weight_m0_sec", -1.0), ("activity_th", float("nan")),
+                         ("mask_floor_db", float("nan")), ("stitching_loss", 7), ("segment_size_sec", 1e12)):
+        bad = L.CssCfgSeconds(3.0, 1.5, 0.15, 0.3, 0.4, 0.2, 0.4, 0.0, 1, 0, 0, 0)
+        setattr(bad, field, value)
+        assert lib.css_make_run_cfg(C.byref(L.make_desc(W.ModelDesc.mc_v1())), C.byref(bad), 16000, C.byref(out), win.ctypes.data_as(C.POINTER(C.c_float)), win.size) == L.CSS_ERR_INVALID_ARG, field
 
 
 def _build_c_host(tmp_path):
