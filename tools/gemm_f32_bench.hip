@@ -35,8 +35,9 @@ int main(int argc, char** argv) {
     struct Shape { int N, K; const char* name; int mode; };   // mode 1: bias + residual (alpha 0.5), 0: bias only
     Shape shapes[] = {{512, 512, "attn-out", 1}, {1024, 512, "ffn-up", 0}, {512, 1024, "ffn-down", 1}, {1536, 512, "qkv", 0}, {512, 1824, "embed", 0}};
     int Ms[] = {7440, 22320, 22320, 22320, 29760};
+    if (getenv("GEMM_BENCH_M")) Ms[1] = atoi(getenv("GEMM_BENCH_M"));   // the second height of the table (the headline's shared batch: 44640)
     const int layouts[] = {8, 1, 13, 12, 0};   // round-4 kernel (8 waves) | gemm_f32.hip (tiles up to 128 rows) | up to 96 | up to 64
-    const size_t maxA = (size_t)29760 * 2048, maxB = (size_t)2048 * 1824, maxC = (size_t)29760 * 2048;
+    const size_t maxA = (size_t)44640 * 2048, maxB = (size_t)2048 * 1824, maxC = (size_t)44640 * 2048;
     float *A, *B, *C, *R;
     hipMalloc(&A, maxA * 4); hipMalloc(&B, maxB * 4 + 4096); hipMalloc(&C, maxC * 4); hipMalloc(&R, maxC * 4);
     std::vector<float> h(maxA);
