@@ -368,3 +368,52 @@ def test_c_host_equals_the_python_shim(tmp_path):
         assert np.array_equal(got, ref)
     finally:
         sep.close()
+
+
+def test_wait_sessions_releases_the_oldest_first(mc_state):
+    """css_wait_sessions(h, n) (round 6): after it returns the FIRST n sessions queued since the last css_wait hold their final
+    outputs -- float and PCM16 sessions, held-back ones flushed on demand -- while the later ones keep running; n beyond what
+    was queued is an error, n = 0 a no-op, and css_wait starts the count again."""
+    css, L = pkg("css"), pkg("_lib")
+    st, desc = mc_state
+    cfg = css.make_run_cfg(css.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    sep = pkg("separator").HipSeparator(st, None, device=0, max_batch_segments=256)
+    try:
+        h = sep.handle
+        sessions = []
+        for k, seconds in enumerate([12.0, 31.0, 7.5, 44.0, 18.0, 25.0, 9.0, 36.0, 15.0]):
+            mix = pkg("synth").synth_meeting(seconds, 7, seed=900 + k)[0]
+            q = np.clip(np.rint(mix * 0.1 * 32768.0), -32768, 32767).astype(np.int16)
+            if k % 3 == 1:
+                blk = L.pinned_empty((7, q.shape[0]), np.int16)
+                blk[:] = q.T
+                planes = [blk[c] for c in range(7)]
+                ref, _ = h.run_pcm16(planes, cfg)
+                sessions.append(("pcm16", planes, ref.copy(), blk))
+            else:
+                f32 = L.pinned_copy(np.ascontiguousarray(q.astype(np.float32) / np.float32(32768.0)))
+                sessions.append(("float", f32, h.run(f32, cfg).copy(), None))
+        for rounds in range(2):
+            outs = []
+            for kind, src, ref, _ in sessions:
+                o = L.pinned_empty(ref.shape, ref.dtype)
+                o[...] = 77
+                if kind == "pcm16":
+                    h.run_enqueue_pcm16(src, cfg, o, L.pinned_empty((3,), np.float32))
+                else:
+                    h.run_enqueue(src, cfg, o)
+                outs.append(o)
+            h.wait_sessions(0)
+            for n in (1, 2, 5, 9):
+                h.wait_sessions(n)          # (the first call also flushes what was still held back for company)
+                for k in range(n):
+                    assert np.array_equal(outs[k], sessions[k][2]), (rounds, n, k)
+            with pytest.raises(L.CssError, match="only 9 sessions"):
+                h.wait_sessions(10)
+            h.wait()
+            with pytest.raises(L.CssError, match="only 0 sessions"):
+                h.wait_sessions(1)
+            for k in range(9):
+                assert np.array_equal(outs[k], sessions[k][2])
+    finally:
+        sep.close()
