@@ -283,3 +283,19 @@ def test_c_host_compiles_as_c99_and_plans(tmp_path, L):
     assert f"{n} samples x 7 channels = {plan.num_segments} segments of 186 frames, {plan.n_out} output samples per stream" in out.stdout, out.stdout + out.stderr
     if L.load().css_device_count() < 1:
         assert out.returncode == 3 and "no HIP device" in out.stderr
+
+
+def test_every_handle_entry_point_rejects_a_null_handle(L):
+    """Every entry point whose first parameter is the handle returns a negative status for NULL (no GPU needed, nothing
+    dereferenced) -- called with zeros / NULLs for the rest, as a host with a failed css_create would."""
+    lib = L.load()
+    text = open(os.path.join(ROOT, "include", "css_mi355.h")).read()
+    names = re.findall(r"^int\s+(css_\w+)\s*\(\s*css_handle_t\s+h", text, flags=re.M)
+    assert len(names) >= 50
+    for n in names:
+        restype, argtypes = L.SIGNATURES[n]
+        args = []
+        for a in argtypes[1:]:
+            args.append(0 if a in (C.c_int, C.c_int32, C.c_int64, C.c_size_t) else (0.0 if a in (C.c_float, C.c_double) else None))
+        rc = getattr(lib, n)(None, *args)
+        assert rc < 0 or (n == "css_destroy" and rc == 0), (n, rc)       # (destroying nothing is not an error, as free(NULL))
