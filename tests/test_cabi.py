@@ -299,3 +299,23 @@ def test_every_handle_entry_point_rejects_a_null_handle(L):
             args.append(0 if a in (C.c_int, C.c_int32, C.c_int64, C.c_size_t) else (0.0 if a in (C.c_float, C.c_double) else None))
         rc = getattr(lib, n)(None, *args)
         assert rc < 0 or (n == "css_destroy" and rc == 0), (n, rc)       # (destroying nothing is not an error, as free(NULL))
+
+
+def test_plan_matches_oracle_on_random_inputs(L):
+    """css_plan against the oracle's index arithmetic (css/css.py:155-171) for random lengths and segmentations (hypothesis):
+    frames, segments, the last segment's valid frames, the output length and the zero-weight verdict."""
+    from hypothesis import given, settings, strategies as st
+    css, w = pkg("css"), pkg("weights")
+    desc = w.ModelDesc.mc_v1()
+
+    @settings(max_examples=300, deadline=None)
+    @given(n=st.integers(min_value=0, max_value=40_000_000), seg=st.sampled_from([1.0, 2.0, 3.0, 3.3, 4.0, 8.0]), frac=st.sampled_from([0.25, 0.5, 0.75]))
+    def check(n, seg, frac):
+        kw = dict(segment_size_sec=seg, hop_size_sec=seg * frac, seg_weight_m0_sec=0.05 * seg, seg_weight_m1_sec=0.1 * seg)
+        rc = css.make_run_cfg(css.CssCfg(**kw), 16000, 7)
+        p, op = L.plan(desc, rc, n), O.make_plan(n, 16000, O.OracleCssCfg(**kw))
+        assert (p.stft_frames, p.mix_frames, p.num_segments, p.n_out) == (op.stft_frames, op.mix_frames, op.num_segments, (op.mix_frames - 1) * 256 + 512), (n, kw)
+        assert p.last_valid == op.seg_range(op.num_segments - 1)[2], (n, kw)
+        assert (rc.c.segment_frames, rc.c.hop_frames) == (op.segment_frames, op.hop_frames)
+
+    check()
