@@ -665,3 +665,50 @@ def test_eight_second_segments_dense_hop_vs_oracle(L, CSS, mix60):
             assert rel_rms(wavs[k], ow[k]) < 1e-4, k
     finally:
         sep.close()
+
+
+def test_random_lengths_and_knobs_decisions_vs_oracle(L, CSS, mix60):
+    """Stitching and gating on RANDOM recording lengths and CssCfg knobs (seeded): every length lands the last segment's valid
+    frames somewhere else in 94 .. 186 (css.py:185-190), with random activity thresholds, dilation / erosion lengths, stitching
+    losses and window margins.  The decisions -- every permutation, both activity maps -- are the oracle's stitching stage's on
+    the same (HIP) masks, and the queue gives the synchronous call's bits.  A one-block model: what is tested here does not depend
+    on the estimator."""
+    import css_oracle as O
+    W = pkg("weights")
+    desc = W.ModelDesc(num_blocks=1)
+    state = W.apply_golden_recipe(W.portable_state_dict(desc, 31))
+    sep = pkg("separator").HipSeparator(state, None, device=0, max_batch_segments=64)
+    rs = np.random.RandomState(606)
+    F, S = 257, 3
+    try:
+        h = sep.handle
+        for case in range(20):
+            n = int(rs.randint(48_320 + 256, 16 * 16000))
+            off = int(rs.randint(0, mix60.shape[1] - n))
+            kw = dict(activity_th=float(rs.choice([0.2, 0.3, 0.4, 0.55])), activity_dilation_sec=float(rs.choice([0.0, 0.2, 0.4, 0.8])),
+                      activity_erosion_sec=float(rs.choice([0.0, 0.1, 0.2, 0.5])), stitching_loss=str(rs.choice(["l1", "mse"])),
+                      seg_weight_m0_sec=float(rs.choice([0.0, 0.15, 0.3])), seg_weight_m1_sec=float(rs.choice([0.3, 0.45, 0.6])))
+            run_cfg = CSS.make_run_cfg(CSS.CssCfg(show_progressbar=False, **kw), 16000, 7)
+            pcm = L.pinned_copy(np.ascontiguousarray(mix60[0, off:off + n]))
+            w = h.run(pcm, run_cfg).copy()
+            plan = h.get_plan()
+            T = run_cfg.c.segment_frames
+            m = h.read(L.BUF_MASKS).reshape(S + 1, F, int(plan.num_segments), T)
+            perms = h.read(L.BUF_PERMS)
+            act_b = h.read(L.BUF_ACT_B).astype(bool)
+            act_f = h.read(L.BUF_ACT_FINAL).astype(bool)
+            hip_masks = lambda i, seg=None: (np.ascontiguousarray(np.moveaxis(m[:S, :, i], 0, 2)), np.ascontiguousarray(np.moveaxis(m[S:, :, i], 0, 2)))
+            _, side = O.separate_and_stitch(pcm[None], None, 16000, O.OracleCssCfg(mc_mvdr=False, **kw), separate_fn=hip_masks)
+            assert side["plan"].num_segments == plan.num_segments and side["plan"].mix_frames == plan.mix_frames, (case, n)
+            assert np.array_equal(np.array(side["perms"], dtype=np.int32), perms), (case, n, kw)
+            diff = np.argwhere(side["activity_b"].T != act_b)
+            for s_, t_ in diff:      # a bit may differ only where the mean mask sits on the threshold to float32 rounding
+                assert abs(float(side["activity"][t_, s_]) - kw["activity_th"]) < 2e-6, (case, s_, t_)
+            if len(diff) == 0:
+                assert np.array_equal(side["activity_final"][0].T, act_f), (case, n, kw)
+            out = L.pinned_empty(w.shape, np.float32)
+            h.run_enqueue(pcm, run_cfg, out)
+            h.wait()
+            assert np.array_equal(out, w), case
+    finally:
+        sep.close()
