@@ -712,3 +712,21 @@ def test_random_lengths_and_knobs_decisions_vs_oracle(L, CSS, mix60):
             assert np.array_equal(out, w), case
     finally:
         sep.close()
+
+
+@pytest.mark.parametrize("seconds,worlds", [(4.0, (2, 3, 8)), (7.6, (3, 5, 8)), (13.0, (7, 8))])
+def test_more_ranks_than_segments(L, CSS, sep_mc, mix60, seconds, worlds):
+    """A short recording sharded over MORE ranks than it has segments (2, 4 and 8 segments over up to 8 ranks): the ranks
+    without a segment own no frames and take part in every exchange with empty pieces; the result is the fused pass's, bit for bit."""
+    PAR = pkg("parallel")
+    n = int(seconds * 16000) + 17
+    pcm = L.pinned_copy(np.ascontiguousarray(mix60[0, 3000:3000 + n]))
+    run_cfg = CSS.make_run_cfg(CSS.CssCfg(activity_th=0.3, show_progressbar=False), 16000, 7)
+    h = sep_mc.handle
+    ref = h.run(pcm, run_cfg).copy()
+    nseg = int(h.get_plan().num_segments)
+    for world in worlds:
+        plans = PAR.all_plans(nseg, int(h.get_plan().mix_frames), int(h.get_plan().stft_frames), 186, 93, 256, world)
+        assert sum(1 for p in plans if p.own_seg_hi == p.own_seg_lo) == max(world - nseg, 0)
+        out = virtual_rank_run(PAR, L, h, pcm, run_cfg, world)
+        assert np.array_equal(out, ref), (seconds, world, nseg)
