@@ -83,13 +83,13 @@ _POOL = _PinnedPool()   # process-wide: a second css_sessions call (or a long on
 
 class _Loaded:
     """One session decoded for the queue: its mono PCM16 planes in ONE page-locked block ([C][n] int16)."""
-    __slots__ = ("pos", "session", "where", "sr", "block", "planes", "out_block", "out16", "peaks", "fallback")
+    __slots__ = ("pos", "session", "where", "sr", "block", "planes", "out_block", "out16", "peaks", "fallback", "mixture_written")
 
 
 def _decode_session(pos, session, where, cfg: CssCfg, pool: _PinnedPool) -> _Loaded:
     ld = _Loaded()
     ld.pos, ld.session, ld.where, ld.fallback = pos, session, where, False
-    ld.block = ld.planes = ld.out_block = ld.out16 = ld.peaks = None
+    ld.block = ld.planes = ld.out_block = ld.out16 = ld.peaks = ld.mixture_written = None
     raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
     same = raw and all(r is not None for r in raw) and len({(r[0].shape[0], r[1]) for r in raw}) == 1
     if not same:                       # float / multi-channel / 24-bit files, the debug slice: css_inference's own float path
@@ -103,10 +103,14 @@ def _decode_session(pos, session, where, cfg: CssCfg, pool: _PinnedPool) -> _Loa
     for k in range(c):
         np.copyto(planes[k], raw[k][0])
     ld.planes = [planes[k] for k in range(c)]
-    # input_mixture.wav (css.py:96-97: channel 0, peak-normalised) needs nothing from the GPU: written here, off the loop's tail
-    mixture = planes[0].astype(np.float32) / np.float32(32768.0)
-    write_wav(where.directory / 'input_mixture.wav', samps=mixture, sr=ld.sr)
     return ld
+
+
+def _write_mixture(ld: _Loaded):
+    """input_mixture.wav (css.py:96-97: channel 0, peak-normalised) needs nothing from the GPU: its own task, off the decode's
+    critical path (the loop enqueues the session as soon as its planes are in page-locked memory) and off the loop's tail."""
+    mixture = ld.planes[0].astype(np.float32) / np.float32(32768.0)
+    write_wav(ld.where.directory / 'input_mixture.wav', samps=mixture, sr=ld.sr)
 
 
 def _write_session(ld: _Loaded, n_out: int, pool: _PinnedPool) -> List[str]:
@@ -118,6 +122,8 @@ def _write_session(ld: _Loaded, n_out: int, pool: _PinnedPool) -> List[str]:
         _LOG.info(f"CSS: saving separated wav to {path}")
         write_pcm16_samples(path, ld.out16[i, :n_out], ld.sr)
         names.append(str(path))
+    if ld.mixture_written is not None:
+        ld.mixture_written.result()          # (it reads channel 0 from the block that goes back to the pool here)
     pool.give(ld.block)
     pool.give(ld.out_block)
     ld.block = ld.planes = ld.out_block = ld.out16 = None
@@ -249,6 +255,7 @@ def css_sessions(out_dir: str, models_dir: str, sessions_df, cfg: CssCfg, fetch_
             ld.peaks = ld.out_block[:4 * S].view(np.float32)
             _LOG.info(f"CSS [{rank}/{world}] session {ld.session.session_id}")
             h.run_enqueue_pcm16(ld.planes, run_cfg, ld.out16, ld.peaks)
+            ld.mixture_written = io.submit(_write_mixture, ld)
             if not t_first:
                 t_first = time.perf_counter() - t_start
             inflight.append(ld)
