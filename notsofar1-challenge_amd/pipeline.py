@@ -36,7 +36,7 @@ import numpy as np
 from . import _lib
 from .css import CssCfg, _SessionOutput, css_inference, make_run_cfg
 from .separator import _device_index, load_css_model
-from .wavio import NUM_MICS_MC, read_wav_pcm16, write_pcm16_samples, write_wav
+from .wavio import NUM_MICS_MC, probe_wav_pcm16, read_pcm16_payload_into, write_pcm16_samples, write_wav
 
 _LOG = logging.getLogger('css')
 
@@ -90,18 +90,18 @@ def _decode_session(pos, session, where, cfg: CssCfg, pool: _PinnedPool) -> _Loa
     ld = _Loaded()
     ld.pos, ld.session, ld.where, ld.fallback = pos, session, where, False
     ld.block = ld.planes = ld.out_block = ld.out16 = ld.peaks = ld.mixture_written = None
-    raw = None if cfg.slice_audio_for_debug else [read_wav_pcm16(p) for p in session.wav_file_names]
-    same = raw and all(r is not None for r in raw) and len({(r[0].shape[0], r[1]) for r in raw}) == 1
+    probes = None if cfg.slice_audio_for_debug else [probe_wav_pcm16(p) for p in session.wav_file_names]
+    same = probes and all(r is not None for r in probes) and len({(r[0], r[1]) for r in probes}) == 1
     if not same:                       # float / multi-channel / 24-bit files, the debug slice: css_inference's own float path
         ld.fallback = True
         return ld
-    assert len(raw) == (NUM_MICS_MC if session.is_mc else 1), f'expecting {NUM_MICS_MC} microphones'
-    n, c = raw[0][0].shape[0], len(raw)
-    ld.sr = raw[0][1]
+    assert len(probes) == (NUM_MICS_MC if session.is_mc else 1), f'expecting {NUM_MICS_MC} microphones'
+    n, c = probes[0][0], len(probes)
+    ld.sr = probes[0][1]
     ld.block = pool.take(n * c * 2)
     planes = ld.block[:n * c * 2].view(np.int16).reshape(c, n)
-    for k in range(c):
-        np.copyto(planes[k], raw[k][0])
+    for k in range(c):                 # straight from the file into the page-locked plane
+        read_pcm16_payload_into(session.wav_file_names[k], probes[k][2], planes[k])
     ld.planes = [planes[k] for k in range(c)]
     return ld
 

@@ -83,6 +83,44 @@ def read_wav_pcm16(path):
     return np.frombuffer(payload, dtype="<i2"), int(fmt[2])
 
 
+def probe_wav_pcm16(path):
+    """-> (n_samples, sample_rate, byte offset of the samples) if `path` is a mono 16-bit PCM wav whose chunks can be walked from
+    its first 64 KB, else None.  With read_pcm16_payload_into: the session loop's decode, straight from the file into page-locked
+    memory (read_wav_pcm16 makes three copies of the payload on its way there)."""
+    with open(path, "rb") as f:
+        head = f.read(65536)
+        f.seek(0, os.SEEK_END)
+        file_size = f.tell()
+    if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt = 12, None
+    while pos + 8 <= len(head):
+        cid, size = head[pos:pos + 4], struct.unpack("<I", head[pos + 4:pos + 8])[0]
+        if cid == b"fmt " and pos + 24 <= len(head):
+            fmt = struct.unpack("<HHIIHH", head[pos + 8:pos + 24])
+        elif cid == b"data":
+            if fmt is None or fmt[0] != 1 or fmt[1] != 1 or fmt[5] != 16:
+                return None
+            size = min(size, file_size - (pos + 8))
+            return size // 2, int(fmt[2]), pos + 8
+        pos += 8 + size + (size & 1)
+    return None
+
+
+def read_pcm16_payload_into(path, offset: int, out: np.ndarray) -> None:
+    """The int16 samples at `offset` of `path` into `out` (contiguous int16, little-endian host), no intermediate copy."""
+    assert out.dtype == np.int16 and out.flags.c_contiguous
+    with open(path, "rb", buffering=0) as f:
+        f.seek(offset)
+        view = memoryview(out).cast("B")
+        got = 0
+        while got < len(view):
+            n = f.readinto(view[got:])
+            if not n:
+                raise ValueError(f"{path}: truncated data chunk")
+            got += n
+
+
 def write_pcm16_samples(path, pcm: np.ndarray, sr: int) -> None:
     """Writes already encoded int16 samples as a mono 16-bit PCM wav."""
     pcm = np.ascontiguousarray(pcm, dtype="<i2")
@@ -90,11 +128,12 @@ def write_pcm16_samples(path, pcm: np.ndarray, sr: int) -> None:
     dir_name = os.path.dirname(str(path))
     if dir_name:
         os.makedirs(dir_name, exist_ok=True)
-    payload = pcm.tobytes()
-    hdr = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + \
-        struct.pack("<IHHIIHH", 16, 1, 1, int(sr), int(sr) * 2, 2, 16) + b"data" + struct.pack("<I", len(payload))
+    nbytes = pcm.size * 2
+    hdr = b"RIFF" + struct.pack("<I", 36 + nbytes) + b"WAVE" + b"fmt " + \
+        struct.pack("<IHHIIHH", 16, 1, 1, int(sr), int(sr) * 2, 2, 16) + b"data" + struct.pack("<I", nbytes)
     with open(path, "wb") as f:
-        f.write(hdr + payload)
+        f.write(hdr)
+        f.write(memoryview(pcm).cast("B"))     # (no second copy of the samples)
 
 
 def write_pcm16(path, samps: np.ndarray, sr: int) -> None:
