@@ -13,9 +13,10 @@ session (``css.py:85``) and, per session, reads 7 wav files, separates, writes 4
 * the sessions of a rank go through the library's QUEUE (round 6): ``css_run_enqueue_pcm16`` / ``css_wait``,
   i.e. the schedule ``bench.py`` times -- queued sessions share mask-estimator batches, a session's PCIe legs
   hide under its neighbours' kernels, both wav edges (int16 -> float scaling; peak normalisation and PCM16
-  encoding, ``utils/audio_utils.py:37-49``) run on the device -- while worker threads decode the NEXT
-  sessions' wav files into page-locked memory and write the PREVIOUS sessions' four files.  Every file holds
-  what ``css_inference`` writes for that session, bit for bit (``tests/test_hip_session.py``);
+  encoding, ``utils/audio_utils.py:37-49``) run on the device -- while worker threads read the NEXT
+  sessions' wav payloads straight into page-locked memory (no intermediate copy) and write the PREVIOUS
+  sessions' four files (``input_mixture.wav`` as a task of its own as soon as the session is queued).  Every
+  file holds what ``css_inference`` writes for that session, bit for bit (``tests/test_hip_session.py``);
 * everything else -- directory layout, wav naming, cache rule, ``pass_through_ch0``, sessions whose files are
   not mono 16-bit PCM -- is ``css_inference`` itself, one synchronous call per such session.
 
